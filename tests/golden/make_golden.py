@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the
+reference (gusye1234/recad @ /root/reference) in the build container.
+
+This script is the provenance of every ``*.npz`` in this directory.  It is run
+by hand in the container that has ``/root/reference`` (the GPU box does not);
+nothing under ``tests/`` or the product imports it.  It copies no reference
+source: it drives the reference's public objects
+
+    recad.dataset.from_config / recad.model.from_config / victim.train_step /
+    victim.forward / Normal.user_item_model_generate
+
+and records inputs (graph, tables, the exact minibatches the reference's own
+sampler produced) and outputs (per-step loss, step-1 gradients, tables, scores,
+top-K lists, HR@K rows).
+
+Usage:
+    python tests/golden/make_golden.py [--scratch /tmp/recad_golden_scratch]
+
+Determinism: the reference is bit-reproducible only with 1 intra-op thread
+(SURVEY.md section 8c), so we pin ``torch.set_num_threads(1)``.
+"""
+import argparse
+import os
+import shutil
+import sys
+import zipfile
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def seeded_table(seed, rows, dim, std):
+    """Initial tables the tests can regenerate without storing them (PCG64)."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((rows, dim), dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+def seeded_uniform(seed, rows, dim, lo, hi):
+    rng = np.random.default_rng(seed)
+    return (rng.random((rows, dim), dtype=np.float32) * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+
+
+def dict_to_csr(d, n_rows):
+    ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    for u, items in d.items():
+        ptr[int(u) + 1] = len(items)
+    ptr = np.cumsum(ptr)
+    idx = np.zeros(ptr[-1], dtype=np.int32)
+    for u, items in d.items():
+        idx[ptr[int(u)]:ptr[int(u) + 1]] = np.asarray(items, dtype=np.int32)
+    return ptr.astype(np.int32), idx
+
+
+class OneBatch:
+    """Stand-in for dataset.generate_batch that replays a fixed list of batches."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __call__(self, **kw):
+        for b in self.batches:
+            yield b
+
+
+def run_per_step(model, dataset, batches):
+    """Call the reference's train_step once per recorded batch -> exact per-step loss."""
+    import torch
+
+    orig = dataset.generate_batch
+    losses = []
+    snaps = {}
+    try:
+        for i, b in enumerate(batches):
+            dataset.generate_batch = OneBatch([b])
+            (loss,) = model.train_step(progress_bar=None)
+            losses.append(loss)
+            if i == 0:
+                snaps["grad1"] = {n: p.grad.detach().clone().numpy() for n, p in model.named_parameters() if p.grad is not None}
+                snaps["after1"] = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
+    finally:
+        dataset.generate_batch = orig
+    snaps["after_all"] = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
+    return np.asarray(losses, dtype=np.float64), snaps
+
+
+def eval_rows(recad, model, dataset, target_ids, topks):
+    """Reference evaluation for ONE model: candidate dict exactly as
+    Normal.normal_evaluate builds it, rows from Normal.user_item_model_generate,
+    plus per-user scores so the tests can compare top-K lists."""
+    import torch
+
+    info = dataset.info_describe()
+    train_dict, n_items = info["train_dict"], info["n_items"]
+    full = set(range(n_items))
+    cand = {}
+    for k, v in train_dict.items():
+        s = set(v)
+        if any(t in s for t in target_ids):
+            continue
+        cand[k] = list(full - s)
+    wf = object.__new__(recad.workflow.Normal)  # only the bound method is needed
+    rows = recad.workflow.Normal.user_item_model_generate(wf, model, cand, topks, target_ids, torch.device("cpu"))
+    # per-user top-100 by the reference's own forward; stable sort, ties reported
+    users = np.array(sorted(cand.keys()), dtype=np.int32)
+    top_ids = np.full((len(users), 100), -1, dtype=np.int32)
+    top_scores = np.zeros((len(users), 100), dtype=np.float32)
+    min_gap = np.zeros(len(users), dtype=np.float32)
+    with torch.no_grad():
+        for r, u in enumerate(users):
+            iids = torch.tensor(cand[int(u)], dtype=torch.int64)
+            s = model(torch.full_like(iids, int(u)), iids).numpy()
+            order = np.lexsort((iids.numpy(), -s.astype(np.float64)))  # score desc, id asc
+            k = min(100, len(order))
+            top_ids[r, :k] = iids.numpy()[order[:k]]
+            top_scores[r, :k] = s[order[:k]]
+            kk = min(101, len(order))
+            ss = s[order[:kk]].astype(np.float64)
+            gaps = (ss[:-1] - ss[1:]) / np.maximum(np.abs(ss[:-1]), 1e-30)
+            min_gap[r] = gaps.min() if len(gaps) else 1.0
+    return rows, users, top_ids, top_scores, min_gap
+
+
+def golden_lightgcn(recad, torch, name, dim, layers, tag, max_steps=None, row_stride=1, eval_stride=1,
+                    graph_from_train=False, epochs=1):
+    torch.manual_seed(2023)
+    np.random.seed(2023)
+    ds = recad.dataset.from_config("implicit", name, need_graph=True, sample="pairwise", download=False)
+    if graph_from_train:
+        # The reference builds its graph from whatever read_data() saw LAST (the test
+        # split, implicit.py:173-192,206-209).  Passing the train edges as test_dict
+        # makes the reference itself build the *intended* train graph.
+        td = ds.info_describe()["train_dict"]
+        ds = ds.reset(train_dict=td, test_dict=td)
+    info = ds.info_describe()
+    U, I = info["n_users"], info["n_items"]
+    g = info["graph"]
+    model = recad.model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=layers).I(dataset=ds)
+    ref_init_user = model.embedding_user.weight.detach().clone().numpy()
+    ref_init_item = model.embedding_item.weight.detach().clone().numpy()
+    # replace with tables the tests can regenerate
+    model.embedding_user.weight.data.copy_(torch.from_numpy(seeded_table(11, U, dim, 0.1)))
+    model.embedding_item.weight.data.copy_(torch.from_numpy(seeded_table(12, I, dim, 0.1)))
+
+    batches = []
+    for _ in range(epochs):
+        batches += list(ds.generate_batch())
+    if max_steps:
+        batches = batches[:max_steps]
+    with torch.no_grad():
+        lu, li = model.computer()
+        light0 = torch.cat([lu, li]).numpy()
+    losses, snaps = run_per_step(model, ds, batches)
+    B = max(len(b["users"]) for b in batches)
+    bt = np.full((len(batches), 3, B), -1, dtype=np.int32)
+    blen = np.zeros(len(batches), dtype=np.int32)
+    for s, b in enumerate(batches):
+        n = len(b["users"])
+        blen[s] = n
+        bt[s, 0, :n] = b["users"].numpy()
+        bt[s, 1, :n] = b["positive_items"].numpy()
+        bt[s, 2, :n] = b["negative_items"].numpy()
+    target_ids, topks = [0], [10, 20, 50, 100]
+    rows, users, top_ids, top_scores, min_gap = eval_rows(recad, model, ds, target_ids, topks)
+    tptr, tidx = dict_to_csr(info["train_dict"], U)
+    tsptr, tsidx = dict_to_csr(info["test_dict"], U)
+    rs = slice(None, None, row_stride)
+    es = slice(None, None, eval_stride)
+    out = dict(
+        n_users=U, n_items=I, dim=dim, layers=layers, lam=1e-4, lr=1e-3, row_stride=row_stride, eval_stride=eval_stride,
+        graph_row=g.indices()[0].numpy().astype(np.int32), graph_col=g.indices()[1].numpy().astype(np.int32),
+        graph_val=g.values().numpy(),
+        train_ptr=tptr, train_idx=tidx, test_ptr=tsptr, test_idx=tsidx,
+        traindata_size=ds.traindataSize,
+        batches=bt, batch_len=blen, losses=losses,
+        light0=light0[rs],
+        grad1_user=snaps["grad1"]["embedding_user.weight"][rs], grad1_item=snaps["grad1"]["embedding_item.weight"][rs],
+        after1_user=snaps["after1"]["embedding_user.weight"][rs], after1_item=snaps["after1"]["embedding_item.weight"][rs],
+        final_user=snaps["after_all"]["embedding_user.weight"][rs], final_item=snaps["after_all"]["embedding_item.weight"][rs],
+        final_user_sum=snaps["after_all"]["embedding_user.weight"].astype(np.float64).sum(0),
+        final_item_sum=snaps["after_all"]["embedding_item.weight"].astype(np.float64).sum(0),
+        eval_rows=rows, eval_users=users, top_ids=top_ids[es], top_scores=top_scores[es], top_min_gap=min_gap,
+        target_ids=np.asarray(target_ids, dtype=np.int32), topks=np.asarray(topks, dtype=np.int32),
+    )
+    if row_stride == 1:
+        out["ref_init_user"] = ref_init_user
+        out["ref_init_item"] = ref_init_item
+    else:
+        out["ref_init_user"] = ref_init_user[rs]
+        out["ref_init_item"] = ref_init_item[rs]
+    np.savez_compressed(os.path.join(OUT, f"lightgcn_{tag}.npz"), **out)
+    print(f"lightgcn_{tag}: U={U} I={I} nnz={g._nnz()} steps={len(batches)} loss0={losses[0]:.6f} lossN={losses[-1]:.6f}")
+
+
+def pointwise_batches(ds, max_steps):
+    batches = []
+    for b in ds.generate_batch():
+        batches.append(b)
+        if max_steps and len(batches) >= max_steps:
+            break
+    return batches
+
+
+def pack_pointwise(batches):
+    B = max(len(b["users"]) for b in batches)
+    bt = np.full((len(batches), 3, B), -1, dtype=np.int32)
+    blen = np.zeros(len(batches), dtype=np.int32)
+    for s, b in enumerate(batches):
+        n = len(b["users"])
+        blen[s] = n
+        bt[s, 0, :n] = b["users"].numpy()
+        bt[s, 1, :n] = b["items"].numpy()
+        bt[s, 2, :n] = b["labels"].numpy()
+    return bt, blen
+
+
+def golden_mf(recad, torch, name, dim, tag, max_steps=None, row_stride=1, eval_stride=1):
+    torch.manual_seed(2023)
+    np.random.seed(2023)
+    ds = recad.dataset.from_config("implicit", name, need_graph=False, sample="pointwise", download=False)
+    info = ds.info_describe()
+    U, I = info["n_users"], info["n_items"]
+    model = recad.model.from_config("victim", "mf", embedding_size=dim).I(dataset=ds)
+    ref_init = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
+    model.user_emb.weight.data.copy_(torch.from_numpy(seeded_uniform(21, U, dim, 0, 0.005)))
+    model.item_emb.weight.data.copy_(torch.from_numpy(seeded_uniform(22, I, dim, 0, 0.005)))
+    model.user_bias.weight.data.copy_(torch.from_numpy(seeded_uniform(23, U, 1, -0.01, 0.01)))
+    model.item_bias.weight.data.copy_(torch.from_numpy(seeded_uniform(24, I, 1, -0.01, 0.01)))
+    batches = pointwise_batches(ds, max_steps)
+    losses, snaps = run_per_step(model, ds, batches)
+    bt, blen = pack_pointwise(batches)
+    target_ids, topks = [0], [10, 20, 50, 100]
+    rows, users, top_ids, top_scores, min_gap = eval_rows(recad, model, ds, target_ids, topks)
+    tptr, tidx = dict_to_csr(info["train_dict"], U)
+    rs = slice(None, None, row_stride)
+    es = slice(None, None, eval_stride)
+    out = dict(
+        n_users=U, n_items=I, dim=dim, lr=1e-3, mean=float(model.mean.item()), row_stride=row_stride, eval_stride=eval_stride,
+        train_ptr=tptr, train_idx=tidx, batches=bt, batch_len=blen, losses=losses,
+        target_ids=np.asarray(target_ids, dtype=np.int32), topks=np.asarray(topks, dtype=np.int32),
+        eval_rows=rows, eval_users=users, top_ids=top_ids[es], top_scores=top_scores[es], top_min_gap=min_gap,
+    )
+    for k in ("user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight"):
+        kk = k.replace(".weight", "")
+        out[f"grad1_{kk}"] = snaps["grad1"][k][rs]
+        out[f"after1_{kk}"] = snaps["after1"][k][rs]
+        out[f"final_{kk}"] = snaps["after_all"][k][rs]
+        out[f"ref_init_{kk}"] = ref_init[k][rs]
+    np.savez_compressed(os.path.join(OUT, f"mf_{tag}.npz"), **out)
+    print(f"mf_{tag}: U={U} I={I} steps={len(batches)} loss0={losses[0]:.6f} lossN={losses[-1]:.6f}")
+
+
+def golden_ncf(recad, torch, name, factor, layers, tag, max_steps=None, row_stride=1, eval_stride=1, dense_stride=1):
+    torch.manual_seed(2023)
+    np.random.seed(2023)
+    ds = recad.dataset.from_config("implicit", name, need_graph=False, sample="pointwise", download=False)
+    info = ds.info_describe()
+    U, I = info["n_users"], info["n_items"]
+    model = recad.model.from_config("victim", "ncf", factor_num=factor, num_layers=layers).I(dataset=ds)
+    E = factor * 2 ** (layers - 1)
+    ref_init = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
+    model.embed_user_GMF.weight.data.copy_(torch.from_numpy(seeded_table(31, U, factor, 0.01)))
+    model.embed_item_GMF.weight.data.copy_(torch.from_numpy(seeded_table(32, I, factor, 0.01)))
+    model.embed_user_MLP.weight.data.copy_(torch.from_numpy(seeded_table(33, U, E, 0.01)))
+    model.embed_item_MLP.weight.data.copy_(torch.from_numpy(seeded_table(34, I, E, 0.01)))
+    # dense weights: regenerable too (xavier-scale uniform from PCG64), biases stay 0 as the reference sets them
+    dense_names = [n for n, p in model.named_parameters() if not n.startswith("embed_") and p.dim() == 2]
+    for j, n in enumerate(dense_names):
+        p = dict(model.named_parameters())[n]
+        a = float(np.sqrt(6.0 / (p.shape[0] + p.shape[1])))
+        p.data.copy_(torch.from_numpy(seeded_uniform(40 + j, p.shape[0], p.shape[1], -a, a)))
+    batches = pointwise_batches(ds, max_steps)
+    with torch.no_grad():
+        b0 = batches[0]
+        pred0 = model(b0["users"], b0["items"]).numpy()
+    losses, snaps = run_per_step(model, ds, batches)
+    bt, blen = pack_pointwise(batches)
+    target_ids, topks = [0], [10, 20, 50, 100]
+    rows, users, top_ids, top_scores, min_gap = eval_rows(recad, model, ds, target_ids, topks)
+    tptr, tidx = dict_to_csr(info["train_dict"], U)
+    rs = slice(None, None, row_stride)
+    es = slice(None, None, eval_stride)
+    out = dict(
+        n_users=U, n_items=I, factor=factor, layers=layers, lr=1e-3, row_stride=row_stride, eval_stride=eval_stride,
+        train_ptr=tptr, train_idx=tidx, batches=bt, batch_len=blen, losses=losses, pred0=pred0,
+        target_ids=np.asarray(target_ids, dtype=np.int32), topks=np.asarray(topks, dtype=np.int32),
+        eval_rows=rows, eval_users=users, top_ids=top_ids[es], top_scores=top_scores[es], top_min_gap=min_gap,
+    )
+    out["dense_names"] = np.asarray(dense_names)
+    out["dense_stride"] = dense_stride
+    for n in snaps["after_all"]:
+        emb = n.startswith("embed_")
+        pick = (lambda a: a[rs]) if emb else (lambda a: a.reshape(-1)[::dense_stride])
+        if n in snaps["grad1"]:
+            out["grad1_" + n] = pick(snaps["grad1"][n])
+        out["after1_" + n] = pick(snaps["after1"][n])
+        out["final_" + n] = pick(snaps["after_all"][n])
+        out["ref_init_" + n] = pick(ref_init[n])[:4096]
+    np.savez_compressed(os.path.join(OUT, f"ncf_{tag}.npz"), **out)
+    print(f"ncf_{tag}: U={U} I={I} E={E} steps={len(batches)} loss0={losses[0]:.6f} lossN={losses[-1]:.6f}")
+
+
+def golden_graph_inject(recad, torch, name, tag):
+    """Graph before/after inject_data: the normalised adjacency the
+    reference builds for a poisoned dataset, for the build's own graph builder."""
+    np.random.seed(7)
+    ds = recad.dataset.from_config("implicit", name, need_graph=True, sample="pairwise", download=False)
+    info = ds.info_describe()
+    U, I = info["n_users"], info["n_items"]
+    rng = np.random.default_rng(5)
+    fake = np.zeros((50, I), dtype=np.float32)
+    for r in range(50):
+        cols = rng.choice(I, size=36, replace=False)
+        fake[r, cols] = rng.integers(1, 6, size=36)
+        fake[r, 0] = 5.0
+    ds2 = ds.inject_data("explicit", fake, filter_num=4)
+    i2 = ds2.info_describe()
+    g2 = i2["graph"]
+    tptr, tidx = dict_to_csr(i2["train_dict"], i2["n_users"])
+    np.savez_compressed(
+        os.path.join(OUT, f"inject_{tag}.npz"),
+        n_users=U, n_items=I, fake=fake, n_users_after=i2["n_users"], n_items_after=i2["n_items"],
+        train_ptr_after=tptr, train_idx_after=tidx, traindata_size_after=ds2.traindataSize,
+        graph_row=g2.indices()[0].numpy().astype(np.int32), graph_col=g2.indices()[1].numpy().astype(np.int32),
+        graph_val=g2.values().numpy(),
+    )
+    print(f"inject_{tag}: U {U}->{i2['n_users']} nnz_after={g2._nnz()} train_after={ds2.traindataSize}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scratch", default="/tmp/recad_golden_scratch")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(os.path.join(args.scratch, "data"), exist_ok=True)
+    if not os.path.exists(os.path.join(args.scratch, "data", "dev")):
+        shutil.copytree(os.path.join(REF, "data", "dev"), os.path.join(args.scratch, "data", "dev"))
+    if not os.path.exists(os.path.join(args.scratch, "data", "game")):
+        with zipfile.ZipFile(os.path.join(REF, "data", "game.zip")) as z:
+            z.extractall(os.path.join(args.scratch, "data"))
+    os.chdir(args.scratch)  # reference resolves ./data and ./generated from cwd
+    sys.path.insert(0, REF)
+    import torch
+
+    torch.set_num_threads(1)
+    import recad
+
+    recad.utils.TQDM = False
+    jobs = {
+        "lgn_dev": lambda: golden_lightgcn(recad, torch, "dev", 64, 3, "dev_d64"),
+        "lgn_dev2": lambda: golden_lightgcn(recad, torch, "dev", 128, 2, "dev_d128_l2_tg", graph_from_train=True, epochs=3),
+        "lgn_game": lambda: golden_lightgcn(recad, torch, "game", 64, 3, "game_d64", row_stride=8, eval_stride=8),
+        "lgn_game_tg": lambda: golden_lightgcn(recad, torch, "game", 64, 3, "game_d64_tg", row_stride=8, eval_stride=8,
+                                               graph_from_train=True),
+        "mf_dev": lambda: golden_mf(recad, torch, "dev", 64, "dev_e64"),
+        "mf_game": lambda: golden_mf(recad, torch, "game", 64, "game_e64", max_steps=24, row_stride=8, eval_stride=8),
+        "ncf_dev": lambda: golden_ncf(recad, torch, "dev", 8, 3, "dev_f8_l3"),
+        "ncf_game": lambda: golden_ncf(recad, torch, "game", 32, 5, "game_f32_l5", max_steps=6, row_stride=32, eval_stride=16,
+                                            dense_stride=7),
+        "inject_dev": lambda: golden_graph_inject(recad, torch, "dev", "dev"),
+    }
+    for k, fn in jobs.items():
+        if args.only and k not in args.only.split(","):
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
