@@ -1,0 +1,90 @@
+"""Loading of the golden fixtures (tests/golden/*.npz, made by make_golden.py) and
+regeneration of the seeded inputs that script used instead of storing them."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def seeded_table(seed, rows, dim, std):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((rows, dim), dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+def seeded_uniform(seed, rows, dim, lo, hi):
+    rng = np.random.default_rng(seed)
+    return (rng.random((rows, dim), dtype=np.float32) * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+
+
+def lightgcn_init(g):
+    U, I, d = int(g["n_users"]), int(g["n_items"]), int(g["dim"])
+    return seeded_table(11, U, d, 0.1), seeded_table(12, I, d, 0.1)
+
+
+def mf_init(g):
+    U, I, d = int(g["n_users"]), int(g["n_items"]), int(g["dim"])
+    return (seeded_uniform(21, U, d, 0, 0.005), seeded_uniform(22, I, d, 0, 0.005),
+            seeded_uniform(23, U, 1, -0.01, 0.01), seeded_uniform(24, I, 1, -0.01, 0.01))
+
+
+def ncf_init(g):
+    U, I, f, L = int(g["n_users"]), int(g["n_items"]), int(g["factor"]), int(g["layers"])
+    E = f * 2 ** (L - 1)
+    emb = (seeded_table(31, U, f, 0.01), seeded_table(32, I, f, 0.01), seeded_table(33, U, E, 0.01),
+           seeded_table(34, I, E, 0.01))
+    W, b = [], []
+    names = [str(n) for n in g["dense_names"]]
+    pw = None
+    for j, n in enumerate(names):
+        if n.startswith("MLP_layers"):
+            l = len(W)
+            inn = f * 2 ** (L - l)
+            out = inn // 2
+            a = float(np.sqrt(6.0 / (inn + out)))
+            W.append(seeded_uniform(40 + j, out, inn, -a, a))
+            b.append(np.zeros(out, dtype=np.float32))
+        else:
+            a = float(np.sqrt(6.0 / (1 + 2 * f)))
+            pw = seeded_uniform(40 + j, 1, 2 * f, -a, a)
+    return emb, W, b, pw, np.zeros(1, dtype=np.float32)
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+TIE_RTOL = 2e-6  # adjacent scores closer than this (relative) are "tied" for ranking purposes
+
+
+def compare_topk_lists(mine, ref_ids, ref_scores, score_rtol=1e-5):
+    """Top-K parity as north_star states it: index lists identical on tie-free
+    prefixes.  `mine` = [(ids, scores)] per user.  Every position where the ids
+    differ must sit inside a run of reference scores that are tied to within
+    TIE_RTOL (the reference's own order there is unspecified); the
+    score at every rank must agree to score_rtol.  Returns #users whose list is
+    identical outright."""
+    exact = 0
+    for r, (ids, sc) in enumerate(mine):
+        rid, rsc = ref_ids[r], ref_scores[r].astype(np.float64)
+        valid = rid >= 0
+        assert np.array_equal(np.asarray(ids)[~valid], rid[~valid])
+        assert np.allclose(np.asarray(sc)[valid], rsc[valid], rtol=score_rtol, atol=1e-7), r
+        diff = np.nonzero((np.asarray(ids) != rid) & valid)[0]
+        if len(diff) == 0:
+            exact += 1
+            continue
+        scale = np.maximum(np.abs(rsc), 1e-30)
+        for k in diff:
+            lo = abs(rsc[k] - rsc[k - 1]) / scale[k] if k > 0 else np.inf
+            hi = abs(rsc[k] - rsc[k + 1]) / scale[k] if k + 1 < len(rsc) and rid[k + 1] >= 0 else np.inf
+            # the last slot can also trade places with the (unrecorded) 101st item
+            edge = k == len(rsc) - 1
+            assert min(lo, hi) <= TIE_RTOL or edge, (r, k, lo, hi)
+    return exact
