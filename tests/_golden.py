@@ -88,3 +88,17 @@ def compare_topk_lists(mine, ref_ids, ref_scores, score_rtol=1e-5):
             edge = k == len(rsc) - 1
             assert min(lo, hi) <= TIE_RTOL or edge, (r, k, lo, hi)
     return exact
+
+
+def adam_close(a, b, lr, steps, rtol=1e-4, outlier_frac=1e-3, travel_frac=0.25):
+    """Parity of Adam-trained tensors.  Adam's m/(sqrt(v)+eps) maps summation-order
+    noise on near-cancelling gradient entries to O(lr) differences, so a pure
+    max-norm bound is not meaningful for every entry: require (1) all but
+    `outlier_frac` of the entries within rtol*max|b|, and (2) no entry further than
+    travel_frac of the distance Adam can move it in `steps` steps."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    diff = np.abs(a - b)
+    scale = max(np.abs(b).max(), 1e-30)
+    bad = float((diff > rtol * scale).mean())
+    return bad <= outlier_frac and diff.max() <= travel_frac * lr * steps, (bad, diff.max())

@@ -157,7 +157,7 @@ def test_ncf_train(name):
             for nme, gr, t in zip(names, grads, P.tensors()):
                 assert G.relerr(pick(nme, gr), g["grad1_" + nme].reshape(pick(nme, gr).shape)) < 2e-5, nme
                 assert G.relerr(pick(nme, t), g["after1_" + nme].reshape(pick(nme, t).shape)) < 2e-5, nme
-    # Adam's m/(sqrt(v)+eps) turns summation-order noise on near-zero gradients into
-    # O(lr) steps; worst element measured 1.02e-4 of max|w| after 6 steps -> 2e-4 here.
+    steps = len(g["batch_len"])
     for nme, t in zip(names, P.tensors()):
-        assert G.relerr(pick(nme, t), g["final_" + nme].reshape(pick(nme, t).shape)) < 2 * TABLE_RTOL, nme
+        ok, info = G.adam_close(pick(nme, t), g["final_" + nme], 1e-3, steps)
+        assert ok, (nme, info)
