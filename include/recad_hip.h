@@ -1,0 +1,144 @@
+/*
+ * recad_hip.h -- C ABI of librecad_hip.so, the MI355X (gfx950) implementation of RecAD's
+ * victim-model hot path.  Plain pointers and sizes only; every pointer marked "device"
+ * is a HIP device pointer owned by the caller (e.g. torch.Tensor.data_ptr()); `stream`
+ * is a hipStream_t passed as void*.  Nothing here allocates caller-visible memory.
+ *
+ * The reference (gusye1234/recad v0.0.2) is pure Python on ATen: it has NO FFI for this
+ * path.  Its boundary is the duck-typed victim class; each entry point
+ * below names the reference code it replaces (paths under /root/reference), and
+ * INTEGRATION.md shows the ctypes binding a maintainer would add to the reference.
+ *
+ * Return value: 0 on success, negative on error (RK_E*); rk_last_error() gives the text.
+ * Thread-safety: one handle per host thread; entry points are asynchronous on `stream`
+ * unless stated otherwise.
+ */
+#ifndef RECAD_HIP_H
+#define RECAD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_ABI_VERSION 1
+#define RK_OK 0
+#define RK_EINVAL (-22)   /* bad argument / unsupported shape */
+#define RK_EHIP (-5)      /* a HIP runtime call failed */
+#define RK_ENOMEM (-12)
+
+/* number of float partials rk_*_train_epoch writes per step */
+#define RK_LOSS_PARTIALS 256
+
+int rk_abi_version(void);
+const char *rk_last_error(void);
+/* Device sanity: returns 0 and fills name (<=255 chars) when a gfx950 device is current. */
+int rk_device_info(char *name, int32_t name_len, int32_t *cu_count);
+
+/* ---------------------------------------------------------------- graph ------------ */
+/* Coalesced COO -> CSR.  Replaces the layout ATen's sparse.mm consumes: the int64 [2,nnz]
+ * index tensor + fp32 values built at recad/dataset/implicit.py:320-326,295-296.
+ * coo_row must be non-decreasing (torch .coalesce()).  All device pointers. */
+int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int64_t *coo_col,
+                  const float *coo_val, int32_t *rowptr /*[n_rows+1]*/, int32_t *col /*[nnz]*/,
+                  float *val /*[nnz]*/, void *stream);
+
+/* Degree-descending row schedule for rk_spmm_csr (load balance for power-law rows).
+ * Synchronous (reads rowptr back once per graph build).  row_perm: device int32[n_rows].
+ * n_long_rows: rows (a prefix of row_perm) that get a whole workgroup each. */
+int rk_csr_schedule(int32_t n_rows, const int32_t *rowptr, int32_t *row_perm, int32_t *n_long_rows,
+                    void *stream);
+
+/* D^-1/2 A D^-1/2 of the bipartite user-item graph straight into CSR, on device.
+ * Replaces ImplicitData.getSparseGraph, recad/dataset/implicit.py:243-298 (scipy dok/lil).
+ * r_ptr/r_idx: user->item CSR (device, item ids sorted ascending within a user).
+ * Outputs: rowptr[U+I+1], col[2E], val[2E] (device).  Uses `tmp` int32[I+1] device scratch. */
+int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t *r_ptr, const int32_t *r_idx,
+                      int32_t *rowptr, int32_t *col, float *val, int32_t *tmp, void *stream);
+
+/* Y = A.X (+ add).  Replaces torch.sparse.mm(g, all_emb), recad/model/victim/lightgcn.py:107.
+ * X is given as two row blocks (rows < x_split in x_lo, the rest in x_hi) so the user and
+ * item tables need no torch.cat (lightgcn.py:88).  add (nullable) has the same row count as Y. */
+int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
+                const int32_t *row_perm, int32_t n_long_rows, int32_t dim, const float *x_lo,
+                const float *x_hi, int32_t x_split, const float *add, float *y, void *stream);
+
+/* ---------------------------------------------------------------- LightGCN --------- */
+typedef struct rk_lightgcn_desc {
+    int32_t n_users, n_items, dim, n_layers;
+    float lambda, lr, beta1, beta2, eps;      /* default.py:105-115; torch.optim.Adam defaults */
+    int32_t reserved0;
+    /* normalised adjacency, CSR over N = n_users + n_items nodes (device) */
+    const int32_t *rowptr, *col;
+    const float *val;
+    const int32_t *row_perm;
+    int32_t n_long_rows, reserved1;
+    /* parameters and Adam moments, row-major fp32 (device); updated in place */
+    float *user_emb, *item_emb;               /* embedding_user/.item.weight, lightgcn.py:40-45 */
+    float *m_user, *v_user, *m_item, *v_item; /* exp_avg / exp_avg_sq of torch.optim.Adam */
+    /* workspace, each float[N*dim] (device) */
+    float *buf_a, *buf_b, *light, *gprop, *gego;
+    float *grad;                              /* nullable: receives dLoss/dE0 [N*dim] */
+    int32_t *state;                           /* device int32[16], owned by the handle's user */
+    float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] */
+} rk_lightgcn_desc;
+#define RK_MAX_GRAPH_STEPS 64
+
+typedef struct rk_lightgcn *rk_lightgcn_t;
+
+int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *out);
+int rk_lightgcn_destroy(rk_lightgcn_t h);
+
+/* LightGCN.computer(), recad/model/victim/lightgcn.py:82-113: desc.light[N,dim] =
+ * mean_l(A^l [U;I]).  Users are rows [0,U), items rows [U,N). */
+int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream);
+
+/* One epoch of LightGCN.train_step, recad/model/victim/lightgcn.py:137-169, over the
+ * pre-sampled triplets (device int64[n], the tensors ImplicitData.generate_batch yields,
+ * recad/dataset/implicit.py:416-437): ceil(n/batch) steps of forward, BPR loss + L2 reg,
+ * backward, dense Adam.  adam_t0 = optimizer steps already taken.  loss_partials: device
+ * float[ceil(n/batch)*RK_LOSS_PARTIALS]; step s's loss is the sum of its RK_LOSS_PARTIALS
+ * entries (fixed order => reproducible).  apply_update=0 leaves parameters untouched and
+ * only fills desc.grad (testing).  graph_steps>1 replays a hipGraph of that many steps. */
+int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                            int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,
+                            int32_t apply_update, int32_t graph_steps, void *stream);
+
+/* ---------------------------------------------------------------- shared ops ------- */
+/* out[b] = <utab[users[b]], itab[items[b]]> (+ ubias[users[b]] + ibias[items[b]] + mean when
+ * ubias != NULL).  LightGCN.forward tail (lightgcn.py:179-182) and MF.forward (mf.py:40-47). */
+int rk_pair_scores(int32_t dim, const float *utab, const float *itab, const float *ubias, const float *ibias,
+                   float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, void *stream);
+
+/* Dense torch.optim.Adam step on one tensor (recad/utils.py:181-183): t = 1-based step. */
+int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
+                 float beta1, float beta2, float eps, void *stream);
+
+/* Full-catalog scoring + top-K + target rank for a block of users: replaces the per-user
+ * loop of Normal.user_item_model_generate, recad/workflow/normal.py:57-93.
+ *   scores[b,i] = <urows[b], itab[i]> (+ ubias_rows[b] + ibias[i] + mean when ibias != NULL)
+ * computed with fp32 MFMA; items in the user's seen list (CSR seen_ptr/seen_idx indexed by
+ * user_ids[b]) are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K]
+ * sorted by (score desc, item id asc), padded with -1/-inf; for each target t its score and
+ * rank among the unseen items (hit@k <=> rank < k).  scratch: device float[nb*n_items]. */
+int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const int32_t *user_ids, const float *itab,
+                  int32_t n_items, const float *ubias_rows, const float *ibias, float mean,
+                  const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
+                  float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
+                  int32_t *target_rank, float *scratch, void *stream);
+
+/* ---------------------------------------------------------------- MF --------------- */
+/* One epoch of MF.train_step, recad/model/victim/mf.py:49-69: logits (mf.py:40-47),
+ * BCE-with-logits (mf.py:32,59-60), backward, dense Adam on the four tables.
+ * grads: device float[U*d + I*d + U + I] scratch (zeroed by the call).
+ * moments: m then v, same layout as grads, each [U*d + I*d + U + I]. */
+int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, float *user_emb, float *item_emb,
+                      float *user_bias, float *item_bias, float mean, float *m, float *v, float *grads,
+                      const int64_t *users, const int64_t *items, const int64_t *labels, int64_t n,
+                      int32_t batch, int32_t adam_t0, float lr, float beta1, float beta2, float eps,
+                      float *loss_partials, int32_t apply_update, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECAD_HIP_H */

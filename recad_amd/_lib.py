@@ -1,0 +1,115 @@
+"""ctypes binding of librecad_hip.so (include/recad_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails this
+module raises.  Pointers are taken from torch tensors with ``data_ptr()``; torch is only
+the owner of device memory and streams here.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librecad_hip.so")
+RK_LOSS_PARTIALS = 256
+RK_MAX_GRAPH_STEPS = 64
+ABI_VERSION = 1
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+class LightGCNDesc(C.Structure):
+    """rk_lightgcn_desc (include/recad_hip.h)."""
+
+    _fields_ = [
+        ("n_users", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("n_layers", C.c_int32),
+        ("lam", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("reserved0", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("row_perm", C.c_void_p),
+        ("n_long_rows", C.c_int32), ("reserved1", C.c_int32),
+        ("user_emb", C.c_void_p), ("item_emb", C.c_void_p),
+        ("m_user", C.c_void_p), ("v_user", C.c_void_p), ("m_item", C.c_void_p), ("v_item", C.c_void_p),
+        ("buf_a", C.c_void_p), ("buf_b", C.c_void_p), ("light", C.c_void_p), ("gprop", C.c_void_p), ("gego", C.c_void_p),
+        ("grad", C.c_void_p), ("state", C.c_void_p), ("coef", C.c_void_p),
+    ]
+
+
+_lib = None
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_SIGNATURES = {
+    "rk_abi_version": [],
+    "rk_last_error": [],
+    "rk_device_info": [C.c_char_p, _I32, C.POINTER(_I32)],
+    "rk_coo_to_csr": [_I32, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "rk_csr_schedule": [_I32, _P, _P, C.POINTER(_I32), _P],
+    "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P],
+    "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
+    "rk_lightgcn_destroy": [_P],
+    "rk_lightgcn_propagate": [_P, _P],
+    "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],
+    "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
+    "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
+    "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,
+                          _F, _P, _I32, _P],
+}
+_RESTYPES = {"rk_last_error": C.c_char_p}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load librecad_hip.so once; raise HipLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  recad_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise HipLibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        if handle.rk_abi_version() != ABI_VERSION:
+            raise HipLibraryMissing(f"{LIB_PATH} has ABI {handle.rk_abi_version()}, expected {ABI_VERSION}; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rk_last_error()
+        raise HipCallError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipCallError("recad_amd kernels need tensors on a HIP device (got a CPU tensor); "
+                           "move the model/dataset to 'cuda' first -- there is no CPU fallback")
+    if not t.is_contiguous():
+        raise HipCallError("recad_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipCallError("no HIP device visible: recad_amd's hot path only runs on an MI355X (gfx950)")

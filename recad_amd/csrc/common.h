@@ -1,0 +1,74 @@
+// Shared host/device helpers for librecad_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/recad_hip.h"
+
+#define RK_EXPORT extern "C" __attribute__((visibility("default")))
+
+extern thread_local char rk_err_buf[512];
+
+#define RK_FAIL(code, ...)                                        \
+    do {                                                          \
+        snprintf(rk_err_buf, sizeof(rk_err_buf), __VA_ARGS__);    \
+        return (code);                                            \
+    } while (0)
+
+#define RK_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) RK_FAIL(RK_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define RK_CHECK_LAUNCH() RK_HIP(hipGetLastError())
+
+static constexpr int kWave = 64;
+
+// Row r of a logical [n_rows, d] matrix stored as two blocks (rows < split in lo, the rest in hi).
+__device__ __forceinline__ const float *row2(const float *lo, const float *hi, int split, int r, int d)
+{
+    return r < split ? lo + (size_t)r * d : hi + (size_t)(r - split) * d;
+}
+__device__ __forceinline__ float *row2(float *lo, float *hi, int split, int r, int d)
+{
+    return r < split ? lo + (size_t)r * d : hi + (size_t)(r - split) * d;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Adam coefficients for 1-based step t, torch.optim.Adam single-tensor math:
+// step_size = lr / (1 - b1^t); bc2s = sqrt(1 - b2^t).  Computed in double like Python does.
+struct AdamCoef {
+    float step_size, bc2s;
+};
+__host__ __device__ inline AdamCoef adam_coef(int t, float lr, float b1, float b2)
+{
+    double bc1 = 1.0 - pow((double)b1, (double)t);
+    double bc2 = 1.0 - pow((double)b2, (double)t);
+    AdamCoef c;
+    c.step_size = (float)((double)lr / bc1);
+    c.bc2s = (float)sqrt(bc2);
+    return c;
+}
+
+// One element of torch.optim.Adam (lerp / addcmul / addcdiv order).
+__device__ __forceinline__ void adam_elem(float &p, float &m, float &v, float g, float w1, float b2, float w2,
+                                          float step_size, float bc2s, float eps)
+{
+    m = m + w1 * (g - m);
+    v = v * b2 + w2 * g * g;
+    float denom = sqrtf(v) / bc2s + eps;
+    p = p - step_size * (m / denom);
+}
+
+// device state words (int32) shared by the kernels of a training epoch
+enum { ST_STEP_BASE = 0, ST_ADAM_T = 1, ST_NTRIP_LO = 2, ST_NTRIP_HI = 3, ST_BATCH = 4, ST_WORDS = 16 };

@@ -1,0 +1,310 @@
+// LightGCN victim hot path on gfx950: propagate (lightgcn.py:82-113), BPR train step
+// (lightgcn.py:137-169) as 2L+1 launches per step, optionally replayed from a hipGraph.
+#include <algorithm>
+
+#include "spmm.h"
+
+thread_local char rk_err_buf[512] = "";
+
+struct rk_lightgcn {
+    rk_lightgcn_desc d;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int exec_steps = 0, exec_update = -1;
+    const void *cap_key[4] = {nullptr, nullptr, nullptr, nullptr};  // pointers baked into exec
+};
+
+__global__ void state_init_kernel(int *state, int step_base, int adam_t, long long n, int batch)
+{
+    state[ST_STEP_BASE] = step_base;
+    state[ST_ADAM_T] = adam_t;
+    state[ST_NTRIP_LO] = (int)(unsigned)(n & 0xffffffffLL);
+    state[ST_NTRIP_HI] = (int)(n >> 32);
+    state[ST_BATCH] = batch;
+}
+
+// ---------------------------------------------------------------- BPR forward+backward
+struct BprArgs {
+    int U, d, L;
+    float lam;
+    const float *light, *user_emb, *item_emb;
+    float *gprop, *gego;
+    const int64_t *users, *pos, *neg;
+    float *loss_partials;
+    const int *state;
+    float *coef;  // coef[2k], coef[2k+1] for step k of the chunk
+    int k;
+    float lr, b1, b2;
+};
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// One wave per triplet, lanes stride over the embedding; 6 row gathers (lightgcn.py:124-129),
+// dot products by wave shuffle, softplus / reg (lightgcn.py:149-165), and the scatter-add of
+// d(loss)/d(light) and d(reg)/d(E0) with no-return float atomics.
+__global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
+{
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int step = a.state[ST_STEP_BASE] + a.k;
+    const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
+    const int B = a.state[ST_BATCH];
+    const long long off = (long long)step * B;
+    const int nb = (int)max(0LL, min((long long)B, ntrip - off));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
+        a.coef[2 * a.k] = c.step_size;
+        a.coef[2 * a.k + 1] = c.bc2s;
+    }
+    const float invB = nb > 0 ? 1.0f / (float)nb : 0.f;
+    const float inv_layers = 1.0f / (float)(a.L + 1);
+    const float creg = a.lam * invB;
+    const int d = a.d;
+    float sp_sum = 0.f, reg_sum = 0.f;
+    const int wave_id = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
+    for (int b = wave_id; b < nb; b += n_waves) {
+        const long long u = a.users[off + b], p = a.pos[off + b], n = a.neg[off + b];
+        const float *lu = a.light + (size_t)u * d, *lp = a.light + (size_t)(a.U + p) * d, *ln = a.light + (size_t)(a.U + n) * d;
+        const float *eu = a.user_emb + (size_t)u * d, *ep = a.item_emb + (size_t)p * d, *en = a.item_emb + (size_t)n * d;
+        float ps = 0.f, ns = 0.f, r = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float xu = lu[k];
+            ps += xu * lp[k];
+            ns += xu * ln[k];
+            const float a0 = eu[k], a1 = ep[k], a2 = en[k];
+            r += a0 * a0 + a1 * a1 + a2 * a2;
+        }
+        ps = wave_sum(ps); ns = wave_sum(ns); r = wave_sum(r);
+        const float x = ns - ps;
+        sp_sum += softplus_f(x);
+        reg_sum += r;
+        const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
+        float *gu = a.gprop + (size_t)u * d, *gp = a.gprop + (size_t)(a.U + p) * d, *gn = a.gprop + (size_t)(a.U + n) * d;
+        float *hu = a.gego + (size_t)u * d, *hp = a.gego + (size_t)(a.U + p) * d, *hn = a.gego + (size_t)(a.U + n) * d;
+        for (int k = lane; k < d; k += 64) {
+            const float xu = lu[k];
+            const float du = dx * (ln[k] - lp[k]), dp = -dx * xu, dn = dx * xu;
+            unsafeAtomicAdd(gu + k, du);
+            unsafeAtomicAdd(gp + k, dp);
+            unsafeAtomicAdd(gn + k, dn);
+            unsafeAtomicAdd(hu + k, du + creg * eu[k]);
+            unsafeAtomicAdd(hp + k, dp + creg * ep[k]);
+            unsafeAtomicAdd(hn + k, dn + creg * en[k]);
+        }
+    }
+    if (lane == 0) { red[0][w] = sp_sum; red[1][w] = reg_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        a.loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
+    }
+}
+
+// standalone dense Adam (L == 0 and the MF/NCF tables)
+__global__ void adam_kernel(long long n, float *p, const float *g, float *m, float *v, float step_size, float bc2s,
+                            float b1, float b2, float eps)
+{
+    const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, mm, vv, g[i], w1, b2, w2, step_size, bc2s, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+RK_EXPORT int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
+                           float beta1, float beta2, float eps, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (t < 1) RK_FAIL(RK_EINVAL, "rk_adam_step: t must be >= 1");
+    const AdamCoef c = adam_coef(t, lr, beta1, beta2);
+    const int grid = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long long)n, param, grad, m, v,
+                       c.step_size, c.bc2s, beta1, beta2, eps);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------- handle
+static int check_desc(const rk_lightgcn_desc &d)
+{
+    if (d.n_users <= 0 || d.n_items <= 0 || d.dim <= 0 || d.n_layers < 0) RK_FAIL(RK_EINVAL, "lightgcn: bad sizes");
+    if (d.dim > 512) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 512 unsupported", d.dim);
+    if (!d.rowptr || !d.col || !d.val || !d.row_perm) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
+    if (!d.user_emb || !d.item_emb || !d.m_user || !d.v_user || !d.m_item || !d.v_item)
+        RK_FAIL(RK_EINVAL, "lightgcn: parameter/moment pointers missing");
+    if (!d.buf_a || !d.buf_b || !d.light || !d.gprop || !d.gego || !d.state || !d.coef)
+        RK_FAIL(RK_EINVAL, "lightgcn: workspace pointers missing");
+    return RK_OK;
+}
+
+RK_EXPORT int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *out)
+{
+    if (!desc || !out) RK_FAIL(RK_EINVAL, "rk_lightgcn_create: null argument");
+    int rc = check_desc(*desc);
+    if (rc) return rc;
+    rk_lightgcn *h = new rk_lightgcn();
+    h->d = *desc;
+    *out = h;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_lightgcn_destroy(rk_lightgcn_t h)
+{
+    if (!h) return RK_OK;
+    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+    return RK_OK;
+}
+
+static SpmmArgs base_args(const rk_lightgcn_desc &d)
+{
+    SpmmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_rows = d.n_users + d.n_items;
+    a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.perm = d.row_perm; a.n_long = d.n_long_rows;
+    a.d = d.dim;
+    return a;
+}
+
+static void set_x(SpmmArgs &a, const float *x, int n_rows) { a.x_lo = x; a.x_hi = x; a.x_split = n_rows; }
+
+// forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
+static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s)
+{
+    const int N = d.n_users + d.n_items, L = d.n_layers;
+    const float inv = 1.0f / (float)(L + 1);
+    if (L == 0) {
+        RK_HIP(hipMemcpyAsync(d.light, d.user_emb, sizeof(float) * (size_t)d.n_users * d.dim, hipMemcpyDeviceToDevice, s));
+        RK_HIP(hipMemcpyAsync(d.light + (size_t)d.n_users * d.dim, d.item_emb, sizeof(float) * (size_t)d.n_items * d.dim,
+                              hipMemcpyDeviceToDevice, s));
+        return RK_OK;
+    }
+    float *bufs[2] = {d.buf_a, d.buf_b};
+    for (int l = 1; l <= L; ++l) {
+        SpmmArgs a = base_args(d);
+        if (l == 1) { a.x_lo = d.user_emb; a.x_hi = d.item_emb; a.x_split = d.n_users; }
+        else set_x(a, bufs[l & 1], N);
+        a.e.y = (l < L) ? bufs[(l + 1) & 1] : nullptr;
+        if (l == 1) { a.e.sum_lo = d.user_emb; a.e.sum_hi = d.item_emb; a.e.sum_split = d.n_users; }
+        else { a.e.sum_lo = d.light; a.e.sum_hi = d.light; a.e.sum_split = N; }
+        a.e.sum_out = d.light;
+        a.e.sum_scale = (l == L) ? inv : 1.0f;
+        RK_HIP(spmm_launch(a, s));
+    }
+    return RK_OK;
+}
+
+// backward + Adam for chunk step k; gprop/gego hold the BPR scatter
+static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s)
+{
+    const int N = d.n_users + d.n_items, L = d.n_layers;
+    float *bufs[2] = {d.buf_a, d.buf_b};
+    auto fill_adam = [&](SpmmEpi &e) {
+        if (apply_update) {
+            e.adam = 1;
+            e.p_lo = d.user_emb; e.p_hi = d.item_emb; e.m_lo = d.m_user; e.m_hi = d.m_item; e.v_lo = d.v_user; e.v_hi = d.v_item;
+            e.p_split = d.n_users;
+            e.coef = d.coef + 2 * k;
+            e.b1 = d.beta1; e.b2 = d.beta2; e.eps = d.eps;
+        }
+        e.y = d.grad;  // nullable
+        e.state = d.state;
+        e.bump = bump;
+    };
+    if (L == 0) RK_FAIL(RK_EINVAL, "lightgcn: n_layers == 0 training is not supported by the fused path");
+    for (int j = 1; j <= L; ++j) {
+        SpmmArgs a = base_args(d);
+        set_x(a, j == 1 ? d.gprop : bufs[j & 1], N);
+        const bool last = (j == L);
+        const float *add = last ? d.gego : d.gprop;
+        a.e.add_lo = add; a.e.add_hi = add; a.e.add_split = N;
+        if (last) {
+            a.e.zero1 = d.gego;
+            a.e.zero2 = (L >= 2) ? d.gprop : nullptr;
+            fill_adam(a.e);
+        } else {
+            a.e.y = bufs[(j + 1) & 1];
+        }
+        RK_HIP(spmm_launch(a, s));
+    }
+    if (L == 1) RK_HIP(hipMemsetAsync(d.gprop, 0, sizeof(float) * (size_t)N * d.dim, s));
+    return RK_OK;
+}
+
+static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                       float *loss_partials, int k, int apply_update, int bump, hipStream_t s)
+{
+    int rc = launch_forward(d, s);
+    if (rc) return rc;
+    BprArgs b;
+    b.U = d.n_users; b.d = d.dim; b.L = d.n_layers; b.lam = d.lambda;
+    b.light = d.light; b.user_emb = d.user_emb; b.item_emb = d.item_emb;
+    b.gprop = d.gprop; b.gego = d.gego;
+    b.users = users; b.pos = pos; b.neg = neg;
+    b.loss_partials = loss_partials;
+    b.state = d.state; b.coef = d.coef; b.k = k;
+    b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
+    hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
+    RK_CHECK_LAUNCH();
+    return launch_backward(d, k, apply_update, bump, s);
+}
+
+RK_EXPORT int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream)
+{
+    if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate: null handle");
+    return launch_forward(h->d, (hipStream_t)stream);
+}
+
+RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                      int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,
+                                      int32_t apply_update, int32_t graph_steps, void *stream)
+{
+    if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_train_epoch: null handle");
+    if (n <= 0 || batch <= 0 || !users || !pos || !neg || !loss_partials)
+        RK_FAIL(RK_EINVAL, "rk_lightgcn_train_epoch: bad arguments");
+    if (!apply_update && !h->d.grad) RK_FAIL(RK_EINVAL, "rk_lightgcn_train_epoch: apply_update=0 needs desc.grad");
+    hipStream_t s = (hipStream_t)stream;
+    const rk_lightgcn_desc &d = h->d;
+    const int n_steps = (int)((n + batch - 1) / batch);
+    const int N = d.n_users + d.n_items;
+    // scatter targets start (and, by the self-cleaning epilogues, stay) zero
+    RK_HIP(hipMemsetAsync(d.gprop, 0, sizeof(float) * (size_t)N * d.dim, s));
+    RK_HIP(hipMemsetAsync(d.gego, 0, sizeof(float) * (size_t)N * d.dim, s));
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(1), 0, s, d.state, 0, adam_t0, (long long)n, batch);
+    RK_CHECK_LAUNCH();
+
+    int done = 0;
+    if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
+    if (graph_steps > 1 && n_steps >= graph_steps) {
+        // NOTE: users/pos/neg/loss_partials are baked into the graph; re-capture when they move.
+        const void **cap_key = h->cap_key;
+        const bool same = h->exec && h->exec_steps == graph_steps && h->exec_update == apply_update &&
+                          cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials;
+        if (!same) {
+            if (h->exec) { (void)hipGraphExecDestroy(h->exec); h->exec = nullptr; }
+            if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = RK_OK;
+            for (int k = 0; k < graph_steps && rc == RK_OK; ++k)
+                rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0,
+                                 h->cap_stream);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            RK_HIP(e);
+            RK_HIP(hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            h->exec_steps = graph_steps; h->exec_update = apply_update;
+            cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
+        }
+        for (; done + graph_steps <= n_steps; done += graph_steps) RK_HIP(hipGraphLaunch(h->exec, s));
+    }
+    for (; done < n_steps; ++done) {
+        int rc = launch_step(d, users, pos, neg, loss_partials, 0, apply_update, 1, s);
+        if (rc) return rc;
+    }
+    return RK_OK;
+}

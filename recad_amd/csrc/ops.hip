@@ -1,0 +1,252 @@
+// Graph construction (COO->CSR, degree schedule, normalised adjacency), pairwise scores and
+// the stand-alone SpMM entry point.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "spmm.h"
+
+RK_EXPORT int rk_abi_version(void) { return RK_ABI_VERSION; }
+RK_EXPORT const char *rk_last_error(void) { return rk_err_buf; }
+
+RK_EXPORT int rk_device_info(char *name, int32_t name_len, int32_t *cu_count)
+{
+    int dev = 0;
+    RK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    RK_HIP(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (!strstr(p.gcnArchName, "gfx950")) RK_FAIL(RK_EINVAL, "device %s is not gfx950", p.gcnArchName);
+    return RK_OK;
+}
+
+// rowptr[r] = first e with coo_row[e] >= r  (coo_row non-decreasing)
+__global__ void csr_rowptr_kernel(int n_rows, long long nnz, const int64_t *__restrict__ row, int *__restrict__ rowptr)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    long long lo = 0, hi = nnz;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (row[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    rowptr[r] = (int)lo;
+}
+
+__global__ void csr_copy_kernel(long long nnz, const int64_t *__restrict__ c64, const float *__restrict__ v, int *__restrict__ c32,
+                                float *__restrict__ vout)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (long long)gridDim.x * blockDim.x) {
+        c32[e] = (int)c64[e];
+        vout[e] = v[e];
+    }
+}
+
+RK_EXPORT int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int64_t *coo_col,
+                            const float *coo_val, int32_t *rowptr, int32_t *col, float *val, void *stream)
+{
+    if (n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL) RK_FAIL(RK_EINVAL, "rk_coo_to_csr: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3((n_rows + 1 + 255) / 256), dim3(256), 0, s, n_rows, (long long)nnz, coo_row, rowptr);
+    RK_CHECK_LAUNCH();
+    if (nnz > 0) {
+        const int grid = (int)std::min<long long>((nnz + 255) / 256, 4096);
+        hipLaunchKernelGGL(csr_copy_kernel, dim3(grid), dim3(256), 0, s, (long long)nnz, coo_col, coo_val, col, val);
+        RK_CHECK_LAUNCH();
+    }
+    return RK_OK;
+}
+
+// Rows longer than this get a whole 16-wave workgroup in rk_spmm_csr (>= 32 nonzeros per wave).
+static constexpr int kLongRow = 512;
+
+RK_EXPORT int rk_csr_schedule(int32_t n_rows, const int32_t *rowptr, int32_t *row_perm, int32_t *n_long_rows, void *stream)
+{
+    if (n_rows <= 0 || !rowptr || !row_perm || !n_long_rows) RK_FAIL(RK_EINVAL, "rk_csr_schedule: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int32_t> rp((size_t)n_rows + 1), perm((size_t)n_rows);
+    RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
+    RK_HIP(hipStreamSynchronize(s));
+    std::iota(perm.begin(), perm.end(), 0);
+    // counting sort by degree, descending, stable in row id => deterministic schedule
+    int32_t maxdeg = 0;
+    for (int32_t r = 0; r < n_rows; ++r) maxdeg = std::max(maxdeg, rp[r + 1] - rp[r]);
+    std::vector<int32_t> cnt((size_t)maxdeg + 2, 0);
+    for (int32_t r = 0; r < n_rows; ++r) cnt[(size_t)(maxdeg - (rp[r + 1] - rp[r])) + 1]++;
+    for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+    int32_t nl = 0;
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const int32_t deg = rp[r + 1] - rp[r];
+        perm[(size_t)cnt[(size_t)(maxdeg - deg)]++] = r;
+        if (deg > kLongRow) ++nl;
+    }
+    RK_HIP(hipMemcpyAsync(row_perm, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipStreamSynchronize(s));
+    *n_long_rows = nl;
+    return RK_OK;
+}
+
+// ---- D^-1/2 A D^-1/2 on device (implicit.py:259-277, fp32 like numpy>=2 computes it)
+__global__ void item_count_kernel(long long E, const int *__restrict__ ridx, int *__restrict__ icnt)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&icnt[ridx[e]], 1);
+}
+
+// single-block exclusive scan of icnt[0..I) into rowptr[U+1 .. U+I], on top of the user part
+__global__ void adj_rowptr_kernel(int U, int I, const int *__restrict__ rptr, const int *__restrict__ icnt, int *__restrict__ rowptr)
+{
+    __shared__ int carry;
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int u = tid; u <= U; u += blockDim.x) rowptr[u] = rptr[u];
+    if (tid == 0) carry = rptr[U];
+    __syncthreads();
+    for (int base = 0; base < I; base += blockDim.x) {
+        const int i = base + tid;
+        int v = i < I ? icnt[i] : 0, x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int pre = 0;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        int tot = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += wsum[k];
+        if (i < I) rowptr[U + i + 1] = carry + pre + x;
+        __syncthreads();
+        if (tid == 0) carry += tot;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float dinv_f(int deg)
+{
+    const float v = powf((float)deg + 1e-14f, -0.5f);
+    return isinf(v) ? 0.f : v;
+}
+
+// user rows: direct; item rows: each item row collects its users in increasing user order.
+__global__ void adj_user_rows_kernel(int U, const int *__restrict__ rptr, const int *__restrict__ ridx, const int *__restrict__ rowptr,
+                                     int *__restrict__ col, float *__restrict__ val)
+{
+    const int u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= U) return;
+    const int b = rptr[u], e = rptr[u + 1];
+    const float du = dinv_f(e - b);
+    for (int k = b + lane; k < e; k += 64) {
+        const int i = ridx[k];
+        const int ideg = rowptr[U + i + 1] - rowptr[U + i];
+        col[k] = U + i;
+        val[k] = (du * 1.0f) * dinv_f(ideg);
+    }
+}
+
+// One thread per (user,item) edge finds its slot in the item row by counting smaller users:
+// deterministic without sorting: slot = #edges of item i with user < u.  Done via binary
+// search over users is not possible without the transpose, so use a per-item cursor filled
+// in user order by a single pass per item block (items are few, users visited in order).
+__global__ void adj_item_rows_kernel(int U, int I, const int *__restrict__ rptr, const int *__restrict__ ridx,
+                                     const int *__restrict__ rowptr, int *__restrict__ col, float *__restrict__ val)
+{
+    // one wave per item: scan all users' lists for this item would be O(E*I); instead each
+    // wave owns an item and binary-searches every user's sorted list -- O(U log deg) per item.
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= I) return;
+    const int out0 = rowptr[U + i];
+    const float di = dinv_f(rowptr[U + i + 1] - out0);
+    int written = 0;
+    for (int base = 0; base < U; base += 64) {
+        const int u = base + lane;
+        bool has = false;
+        int deg = 0;
+        if (u < U) {
+            int lo = rptr[u], hi = rptr[u + 1];
+            deg = hi - lo;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ridx[mid] < i) lo = mid + 1; else hi = mid; }
+            has = lo < rptr[u + 1] && ridx[lo] == i;
+        }
+        const unsigned long long m = __ballot(has);
+        if (has) {
+            const int pos = out0 + written + __popcll(m & ((1ULL << lane) - 1ULL));
+            col[pos] = u;
+            val[pos] = (di * 1.0f) * dinv_f(deg);
+        }
+        written += __popcll(m);
+    }
+}
+
+RK_EXPORT int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t *r_ptr, const int32_t *r_idx,
+                                int32_t *rowptr, int32_t *col, float *val, int32_t *tmp, void *stream)
+{
+    if (n_users <= 0 || n_items <= 0 || !r_ptr || !r_idx || !rowptr || !col || !val || !tmp)
+        RK_FAIL(RK_EINVAL, "rk_build_norm_adj: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t E = 0;
+    RK_HIP(hipMemcpyAsync(&E, r_ptr + n_users, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RK_HIP(hipStreamSynchronize(s));
+    RK_HIP(hipMemsetAsync(tmp, 0, sizeof(int32_t) * ((size_t)n_items + 1), s));
+    if (E > 0) {
+        const int grid = (int)std::min<long long>(((long long)E + 255) / 256, 4096);
+        hipLaunchKernelGGL(item_count_kernel, dim3(grid), dim3(256), 0, s, (long long)E, r_idx, tmp);
+        RK_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(adj_rowptr_kernel, dim3(1), dim3(1024), 0, s, n_users, n_items, r_ptr, tmp, rowptr);
+    RK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(adj_user_rows_kernel, dim3((n_users + 3) / 4), dim3(256), 0, s, n_users, r_ptr, r_idx, rowptr, col, val);
+    RK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(adj_item_rows_kernel, dim3((n_items + 3) / 4), dim3(256), 0, s, n_users, n_items, r_ptr, r_idx, rowptr, col, val);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// ---- pairwise scores
+__global__ void pair_scores_kernel(int d, const float *__restrict__ utab, const float *__restrict__ itab, const float *ubias,
+                                   const float *ibias, float mean, const int64_t *__restrict__ users,
+                                   const int64_t *__restrict__ items, long long n, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long b = wave; b < n; b += n_waves) {
+        const long long u = users[b], i = items[b];
+        const float *pu = utab + (size_t)u * d, *pi = itab + (size_t)i * d;
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) s += pu[k] * pi[k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (ubias) s = ((s + ubias[u]) + ibias[i]) + mean;
+            out[b] = s;
+        }
+    }
+}
+
+RK_EXPORT int rk_pair_scores(int32_t dim, const float *utab, const float *itab, const float *ubias, const float *ibias,
+                             float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (dim <= 0 || !utab || !itab || !users || !items || !out) RK_FAIL(RK_EINVAL, "rk_pair_scores: bad arguments");
+    if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_pair_scores: give both biases or neither");
+    const int grid = (int)std::min<long long>((n + 3) / 4, 4096);
+    hipLaunchKernelGGL(pair_scores_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dim, utab, itab, ubias, ibias, mean,
+                       users, items, (long long)n, out);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
+                          const int32_t *row_perm, int32_t n_long_rows, int32_t dim, const float *x_lo,
+                          const float *x_hi, int32_t x_split, const float *add, float *y, void *stream)
+{
+    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !row_perm || !x_lo || !y)
+        RK_FAIL(RK_EINVAL, "rk_spmm_csr: bad arguments");
+    SpmmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.perm = row_perm; a.n_long = n_long_rows; a.d = dim;
+    a.x_lo = x_lo; a.x_hi = x_hi ? x_hi : x_lo; a.x_split = x_hi ? x_split : n_rows;
+    if (add) { a.e.add_lo = add; a.e.add_hi = add; a.e.add_split = n_rows; }
+    a.e.y = y;
+    RK_HIP(spmm_launch(a, (hipStream_t)stream));
+    return RK_OK;
+}

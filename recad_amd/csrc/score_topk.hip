@@ -1,0 +1,227 @@
+// Full-catalog scoring + top-K + target rank (recad/workflow/normal.py:57-93) on gfx950.
+//   pass 1: scores[nb, I] = U_b . Items^T with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the
+//           instruction is a k-ordered fmaf chain, so a score is bit-identical to the scalar
+//           loop  s = fmaf(u[k], v[k], s), k = 0..d-1  (oracle: orc_score_rows).
+//   pass 2: one workgroup per user: mask seen items, rank of each target, radix-select of
+//           the K-th largest score, ordered collection, bitonic sort by (score desc, id asc).
+#include <algorithm>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int kTile = 128;  // users x items per workgroup
+static constexpr int kKC = 32;     // k-chunk staged in LDS (2 x 128 x 33 floats = 33 KiB)
+static constexpr int kLd = kKC + 1;
+
+// stage rows [r0, r0+128) x cols [k0, k0+64) of a row-major [n_rows, d] matrix, zero-filled
+__device__ __forceinline__ void stage_tile(float (*dst)[kLd], const float *__restrict__ src, int n_rows, int d, int r0, int k0)
+{
+    for (int idx = threadIdx.x; idx < kTile * kKC; idx += 256) {
+        const int r = idx / kKC, c = idx % kKC;
+        const int gr = r0 + r, gc = k0 + c;
+        dst[r][c] = (gr < n_rows && gc < d) ? src[(size_t)gr * d + gc] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void score_gemm_kernel(int d, const float *__restrict__ urows, int nb,
+                                                         const float *__restrict__ itab, int n_items,
+                                                         const float *__restrict__ ubias_rows, const float *__restrict__ ibias,
+                                                         float mean, float *__restrict__ out)
+{
+    __shared__ float As[kTile][kLd];
+    __shared__ float Bs[kTile][kLd];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int u0 = blockIdx.y * kTile, i0 = blockIdx.x * kTile;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int k0 = 0; k0 < d; k0 += kKC) {
+        stage_tile(As, urows, nb, d, u0, k0);
+        stage_tile(Bs, itab, n_items, d, i0, k0);
+        __syncthreads();
+        const int kc = min(kKC, d - k0);
+        for (int kk = 0; kk < kc; kk += 2) {
+            const float a0 = As[wr * 64 + lr][kk + lk], a1 = As[wr * 64 + 32 + lr][kk + lk];
+            const float b0 = Bs[wc * 64 + lr][kk + lk], b1 = Bs[wc * 64 + 32 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int u = u0 + wr * 64 + i * 32 + row, it = i0 + wc * 64 + j * 32 + lr;
+                if (u < nb && it < n_items) {
+                    float s = acc[i][j][r];
+                    if (ibias) s = ((s + ubias_rows[u]) + ibias[it]) + mean;
+                    out[(size_t)u * n_items + it] = s;
+                }
+            }
+}
+
+// ---------------------------------------------------------------- pass 2
+__device__ __forceinline__ unsigned score_key(float s)
+{
+    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf)
+    if (s == -INFINITY) return 0u;
+    const unsigned u = __float_as_uint(s);
+    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return k == 0u ? 1u : k;
+}
+
+static constexpr int kMaxK = 256;
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ scores, int n_items, const int *__restrict__ user_ids,
+                                                        const int *__restrict__ seen_ptr, const int *__restrict__ seen_idx, int K,
+                                                        int *__restrict__ top_ids, float *__restrict__ top_scores,
+                                                        const int *__restrict__ targets, int n_targets,
+                                                        float *__restrict__ target_score, int *__restrict__ target_rank)
+{
+    __shared__ int hist[256];
+    __shared__ unsigned long long sel[kMaxK];
+    __shared__ int sh_i[8];
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    float *row = scores + (size_t)b * n_items;
+    const int u = user_ids[b];
+    // target scores before masking (normal.py:83-85)
+    if (tid < n_targets) target_score[(size_t)b * n_targets + tid] = row[targets[tid]];
+    __syncthreads();
+    for (int k = seen_ptr[u] + tid; k < seen_ptr[u + 1]; k += 256) row[seen_idx[k]] = -INFINITY;
+    __threadfence_block();
+    __syncthreads();
+    // rank of every target among the unseen items: #(s > st) + #(s == st and id < target)
+    for (int t = 0; t < n_targets; ++t) {
+        const int tg = targets[t];
+        const float st = target_score[(size_t)b * n_targets + t];
+        int c = 0;
+        for (int i = tid; i < n_items; i += 256) {
+            const float s = row[i];
+            if (s == -INFINITY || i == tg) continue;
+            c += (s > st || (s == st && i < tg)) ? 1 : 0;
+        }
+        c = (int)wave_sum((float)c);  // counts < 2^24: exact in fp32
+        if (lane == 0) wtot[w] = c;
+        __syncthreads();
+        if (tid == 0) target_rank[(size_t)b * n_targets + t] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    // radix select: K-th largest key among the valid ones
+    unsigned prefix = 0u, mask = 0u;
+    int need = K;
+    bool take_all = false;
+    for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_items; i += 256) {
+            const unsigned k = score_key(row[i]);
+            if (k != 0u && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, digit = -1, nd = need;
+            for (int bin = 255; bin >= 0; --bin) {
+                if (cum + hist[bin] >= need) { digit = bin; nd = need - cum; break; }
+                cum += hist[bin];
+            }
+            sh_i[0] = digit;
+            sh_i[1] = nd;
+        }
+        __syncthreads();
+        if (sh_i[0] < 0) { take_all = true; break; }  // fewer than K valid items
+        prefix |= (unsigned)sh_i[0] << shift;
+        mask |= 255u << shift;
+        need = sh_i[1];
+        __syncthreads();
+    }
+    const unsigned T = take_all ? 1u : prefix;
+    const int n_gt_slots = take_all ? K : K - need;
+    // collect: keys > T anywhere in [0, n_gt_slots), keys == T (lowest ids first) after them
+    if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }
+    for (int k = tid; k < kMaxK; k += 256) sel[k] = 0ULL;
+    __syncthreads();
+    for (int base = 0; base < n_items; base += 256) {
+        const int i = base + tid;
+        const unsigned k = i < n_items ? score_key(row[i]) : 0u;
+        const bool gt = take_all ? (k != 0u) : (k > T);
+        const bool eq = !take_all && k == T && k != 0u;
+        if (gt) {
+            const int p = atomicAdd(&sh_i[2], 1);
+            if (p < kMaxK) sel[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+        }
+        const unsigned long long m = __ballot(eq);
+        if (lane == 0) wtot[w] = __popcll(m);
+        __syncthreads();
+        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
+        for (int ww = 0; ww < w; ++ww) pre += wtot[ww];
+        const int eq_base = sh_i[3];
+        if (eq) {
+            const int idx = eq_base + pre;
+            if (idx < need) sel[n_gt_slots + idx] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+        }
+        __syncthreads();
+        if (tid == 0) sh_i[3] = eq_base + wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    // bitonic sort of 256 composite keys, descending => score desc, item id asc
+    for (int size = 2; size <= kMaxK; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = tid ^ stride;
+            if (partner > tid) {
+                const bool desc = (tid & size) == 0;
+                const unsigned long long x = sel[tid], y = sel[partner];
+                if (desc ? (x < y) : (x > y)) { sel[tid] = y; sel[partner] = x; }
+            }
+            __syncthreads();
+        }
+    for (int k = tid; k < K; k += 256) {
+        const unsigned long long e = sel[k];
+        if (e == 0ULL) {
+            top_ids[(size_t)b * K + k] = -1;
+            top_scores[(size_t)b * K + k] = -INFINITY;
+        } else {
+            const int id = (int)(~(unsigned)(e & 0xffffffffULL));
+            top_ids[(size_t)b * K + k] = id;
+            top_scores[(size_t)b * K + k] = row[id];
+        }
+    }
+}
+
+RK_EXPORT int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const int32_t *user_ids, const float *itab,
+                            int32_t n_items, const float *ubias_rows, const float *ibias, float mean,
+                            const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
+                            float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
+                            int32_t *target_rank, float *scratch, void *stream)
+{
+    if (nb <= 0) return RK_OK;
+    if (dim <= 0 || n_items <= 0 || !urows || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
+        RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
+    if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "rk_score_topk: K must be in [1,%d]", kMaxK);
+    if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
+        RK_FAIL(RK_EINVAL, "rk_score_topk: bad targets");
+    if ((ubias_rows == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((n_items + kTile - 1) / kTile, (nb + kTile - 1) / kTile);
+    hipLaunchKernelGGL(score_gemm_kernel, grid, dim3(256), 0, s, dim, urows, nb, itab, n_items, ubias_rows, ibias, mean, scratch);
+    RK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(256), 0, s, scratch, n_items, user_ids, seen_ptr, seen_idx, K, top_ids,
+                       top_scores, targets, n_targets, target_score, target_rank);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
