@@ -1,0 +1,74 @@
+"""Batched full-catalog scoring + top-K + HR@K on device.
+
+Replaces the per-user Python loop + pandas sort of Normal.user_item_model_generate
+(recad/workflow/normal.py:57-93) with rk_score_topk: propagate ONCE, then for blocks of
+users one fp32-MFMA GEMM and one selection kernel.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096):
+    """For every user in user_ids (int array): top-K unseen items and the score/rank of each target.
+
+    seen_ptr/seen_idx: CSR (indexed by user id) of the items to exclude (the train items).
+    Returns dict of host numpy arrays: top_ids[n,K], top_scores[n,K], target_score[n,T], target_rank[n,T].
+    """
+    _lib.require_gpu()
+    utab, itab, ubias, ibias, mean = victim.scoring_tables()
+    dev = itab.device
+    itab = itab.contiguous()
+    n_items, d = itab.shape
+    user_ids_t = torch.as_tensor(np.asarray(user_ids), dtype=torch.int32, device=dev).contiguous()
+    seen_ptr_t = torch.as_tensor(np.asarray(seen_ptr), dtype=torch.int32, device=dev).contiguous()
+    seen_idx_t = torch.as_tensor(np.asarray(seen_idx), dtype=torch.int32, device=dev).contiguous()
+    if seen_idx_t.numel() == 0:
+        seen_idx_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    targets_t = torch.as_tensor(np.asarray(targets), dtype=torch.int32, device=dev).contiguous()
+    n, T = user_ids_t.numel(), targets_t.numel()
+    top_ids = torch.empty(n, K, dtype=torch.int32, device=dev)
+    top_scores = torch.empty(n, K, dtype=torch.float32, device=dev)
+    tscore = torch.empty(n, max(T, 1), dtype=torch.float32, device=dev)
+    trank = torch.empty(n, max(T, 1), dtype=torch.int32, device=dev)
+    chunk = max(1, min(chunk, n))
+    scratch = torch.empty(chunk * n_items, dtype=torch.float32, device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        ids = user_ids_t[s:e]
+        urows = utab.index_select(0, ids.long()).contiguous()
+        ub_rows = ubias.index_select(0, ids.long()).contiguous() if ubias is not None else None
+        _lib.check(_lib.lib().rk_score_topk(
+            d, _lib.ptr(urows), e - s, _lib.ptr(ids), _lib.ptr(itab), n_items, _lib.ptr(ub_rows),
+            _lib.ptr(ibias.contiguous()) if ibias is not None else None, float(mean), _lib.ptr(seen_ptr_t),
+            _lib.ptr(seen_idx_t), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]), _lib.ptr(targets_t), T,
+            _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+    return {
+        "top_ids": top_ids.cpu().numpy(), "top_scores": top_scores.cpu().numpy(),
+        "target_score": tscore[:, :T].cpu().numpy(), "target_rank": trank[:, :T].cpu().numpy(),
+    }
+
+
+def eligible_users(train_ptr, train_idx, targets):
+    """Users the reference evaluates (normal.py:133-143): every user with a train list that
+    contains none of the targets."""
+    train_ptr = np.asarray(train_ptr)
+    train_idx = np.asarray(train_idx)
+    U = len(train_ptr) - 1
+    deg = np.diff(train_ptr)
+    has_target = np.zeros(U, dtype=bool)
+    rows = np.repeat(np.arange(U), deg)
+    hit = np.isin(train_idx, np.asarray(targets))
+    has_target[rows[hit]] = True
+    return np.nonzero((deg > 0) & ~has_target)[0].astype(np.int32)
+
+
+def hr_rows(user_ids, res, topks):
+    """[user, score(target), hit@k...] rows like normal.py:89-92 (one target per row)."""
+    rows = []
+    T = res["target_score"].shape[1]
+    for t in range(T):
+        hits = [(res["target_rank"][:, t] < k).astype(np.float64) for k in topks]
+        rows.append(np.stack([np.asarray(user_ids, dtype=np.float64), res["target_score"][:, t].astype(np.float64)] + hits, 1))
+    return np.concatenate(rows, 0) if rows else np.zeros((0, 2 + len(topks)))

@@ -1,0 +1,94 @@
+"""Device-resident CSR of the normalised adjacency + its SpMM schedule."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class CsrGraph:
+    """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the
+    degree-descending row schedule rk_spmm_csr uses.  Immutable after construction."""
+
+    def __init__(self, n_rows, rowptr, col, val, row_perm, n_long_rows):
+        self.n_rows, self.rowptr, self.col, self.val = n_rows, rowptr, col, val
+        self.row_perm, self.n_long_rows = row_perm, n_long_rows
+
+    @property
+    def nnz(self):
+        return self.col.numel()
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self.rowptr.device == device:
+            return self
+        return CsrGraph(self.n_rows, self.rowptr.to(device), self.col.to(device), self.val.to(device),
+                        self.row_perm.to(device), self.n_long_rows)
+
+    @staticmethod
+    def _schedule(n_rows, rowptr):
+        perm = torch.empty(n_rows, device=rowptr.device, dtype=torch.int32)
+        n_long = C.c_int32(0)
+        _lib.check(_lib.lib().rk_csr_schedule(n_rows, _lib.ptr(rowptr), _lib.ptr(perm), C.byref(n_long),
+                                              _lib.stream_ptr()), "rk_csr_schedule")
+        return perm, int(n_long.value)
+
+    @classmethod
+    def from_torch_coo(cls, coo, device):
+        """From the reference's graph tensor: coalesced sparse COO, int64 indices, fp32 values
+        (recad/dataset/implicit.py:295-296,320-326)."""
+        _lib.require_gpu()
+        coo = coo.coalesce()
+        n = coo.shape[0]
+        idx = coo.indices().to(device)
+        row, col64 = idx[0].contiguous(), idx[1].contiguous()
+        v = coo.values().to(device=device, dtype=torch.float32).contiguous()
+        nnz = v.numel()
+        rowptr = torch.empty(n + 1, device=device, dtype=torch.int32)
+        col = torch.empty(max(nnz, 1), device=device, dtype=torch.int32)[:nnz]
+        val = torch.empty(max(nnz, 1), device=device, dtype=torch.float32)[:nnz]
+        _lib.check(_lib.lib().rk_coo_to_csr(n, nnz, _lib.ptr(row), _lib.ptr(col64), _lib.ptr(v), _lib.ptr(rowptr),
+                                            _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()), "rk_coo_to_csr")
+        perm, n_long = cls._schedule(n, rowptr)
+        return cls(n, rowptr, col, val, perm, n_long)
+
+    @classmethod
+    def from_user_item_csr(cls, n_users, n_items, r_ptr, r_idx, device):
+        """D^-1/2 A D^-1/2 built on device from the user->item CSR (item ids sorted per user);
+        replaces ImplicitData.getSparseGraph (recad/dataset/implicit.py:243-298)."""
+        _lib.require_gpu()
+        r_ptr = torch.as_tensor(r_ptr, dtype=torch.int32).to(device).contiguous()
+        r_idx = torch.as_tensor(r_idx, dtype=torch.int32).to(device).contiguous()
+        E = r_idx.numel()
+        N = n_users + n_items
+        rowptr = torch.empty(N + 1, device=device, dtype=torch.int32)
+        col = torch.empty(max(2 * E, 1), device=device, dtype=torch.int32)[: 2 * E]
+        val = torch.empty(max(2 * E, 1), device=device, dtype=torch.float32)[: 2 * E]
+        tmp = torch.empty(n_items + 1, device=device, dtype=torch.int32)
+        _lib.check(_lib.lib().rk_build_norm_adj(n_users, n_items, _lib.ptr(r_ptr), _lib.ptr(r_idx), _lib.ptr(rowptr),
+                                                _lib.ptr(col), _lib.ptr(val), _lib.ptr(tmp), _lib.stream_ptr()),
+                   "rk_build_norm_adj")
+        perm, n_long = cls._schedule(N, rowptr)
+        return cls(N, rowptr, col, val, perm, n_long)
+
+    def to_torch_coo(self):
+        """The graph in the reference's own format (a coalesced torch sparse COO tensor)."""
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), counts)
+        idx = torch.stack([row, self.col.long()])
+        return torch.sparse_coo_tensor(idx, self.val, (self.n_rows, self.n_rows)).coalesce()
+
+    def spmm(self, x, add=None):
+        """y = A.x (+ add) for a dense [N,d] fp32 tensor (torch.sparse.mm replacement)."""
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().rk_spmm_csr(self.n_rows, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val),
+                                          _lib.ptr(self.row_perm), self.n_long_rows, x.shape[1], _lib.ptr(x), None, 0,
+                                          _lib.ptr(add), _lib.ptr(y), _lib.stream_ptr()), "rk_spmm_csr")
+        return y

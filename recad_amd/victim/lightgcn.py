@@ -1,0 +1,205 @@
+"""LightGCN victim on MI355X: same interface as recad/model/victim/lightgcn.py, hot path in HIP.
+
+forward/backward/Adam run in librecad_hip.so (recad_amd/csrc/lightgcn.hip); this module is
+orchestration only: parameter ownership (nn.Embedding, so .to()/state_dict() behave as in
+the reference), the optimizer object, and the C-ABI handle.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..graph import CsrGraph
+from ..utils import VarDim, get_logger, pick_optim
+from .base import BaseVictim
+
+
+class LightGCN(BaseVictim):
+    victim_name = "lightgcn"
+
+    @classmethod
+    def extra_user_args(cls, kwargs):
+        # recad/model/victim/lightgcn.py:21-28 (pretrained tables are supplied by the caller)
+        return "user_emb, item_emb" if kwargs.get("pretrain", False) else ""
+
+    def _build(self, **config):
+        self.config = config
+        self.dataset = config["dataset"]
+        self.logger = get_logger(__name__, config["logging_level"])
+        info = self.dataset.info_describe()
+        self.num_users, self.num_items = info["n_users"], info["n_items"]
+        self.Graph = info.get("graph_csr", None) or info["graph"]
+        self.latent_dim = config["latent_dim_rec"]
+        self.n_layers = config["lightGCN_n_layers"]
+        self.keep_prob = config["keep_prob"]
+        self.A_split = config["A_split"]
+        if self.A_split:
+            raise ValueError("A_split is not support in LightGCN yet")  # lightgcn.py:38-39
+        if config["dropout"]:
+            raise ValueError("graph dropout is not supported by the HIP path (reference default is 0.0)")
+        # same RNG consumption order as lightgcn.py:40-48
+        self.embedding_user = nn.Embedding(self.num_users, self.latent_dim)
+        self.embedding_item = nn.Embedding(self.num_items, self.latent_dim)
+        if config["pretrain"] == 0:
+            nn.init.normal_(self.embedding_user.weight, std=0.1)
+            nn.init.normal_(self.embedding_item.weight, std=0.1)
+        else:
+            self.embedding_user.weight.data.copy_(torch.from_numpy(config["user_emb"]))
+            self.embedding_item.weight.data.copy_(torch.from_numpy(config["item_emb"]))
+        self.f = nn.Sigmoid()
+        self.optimizer = pick_optim(config["optim"])(self.parameters(), lr=config["lr"])
+        self._fused_adam = isinstance(self.optimizer, torch.optim.Adam) and self._adam_is_default()
+        self._handle = None
+        self._handle_key = None
+        self._ws = None
+        self.graph_steps = 8  # steps per hipGraph replay; 0/1 = plain launches
+
+    # ------------------------------------------------------------------ C-ABI handle
+    def _adam_is_default(self):
+        g = self.optimizer.param_groups[0]
+        return (not g.get("amsgrad", False)) and g.get("weight_decay", 0) == 0 and not g.get("maximize", False)
+
+    def _adam_state(self, p):
+        st = self.optimizer.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        for k in ("exp_avg", "exp_avg_sq"):
+            if st[k].device != p.device:
+                st[k] = st[k].to(p.device)
+        return st
+
+    def _csr(self, device):
+        if not isinstance(self.Graph, CsrGraph):
+            self.Graph = CsrGraph.from_torch_coo(self.Graph, device)
+        return self.Graph.to(device)
+
+    def _ensure_handle(self, want_grad=False):
+        _lib.require_gpu()
+        wu, wi = self.embedding_user.weight, self.embedding_item.weight
+        dev = wu.device
+        if dev.type != "cuda":
+            raise _lib.HipCallError("LightGCN parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
+        su, si = self._adam_state(wu), self._adam_state(wi)
+        key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad))
+        if self._handle is not None and self._handle_key == key:
+            return self._handle
+        self._drop_handle()
+        g = self._csr(dev)
+        N, d = self.num_users + self.num_items, self.latent_dim
+        ws = {k: torch.zeros(N, d, device=dev, dtype=torch.float32) for k in ("buf_a", "buf_b", "light", "gprop", "gego")}
+        ws["grad"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if want_grad else None
+        ws["state"] = torch.zeros(16, device=dev, dtype=torch.int32)
+        ws["coef"] = torch.zeros(2 * _lib.RK_MAX_GRAPH_STEPS, device=dev, dtype=torch.float32)
+        grp = self.optimizer.param_groups[0]
+        betas = grp.get("betas", (0.9, 0.999))
+        desc = _lib.LightGCNDesc(
+            n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
+            lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
+            eps=float(grp.get("eps", 1e-8)),
+            rowptr=_lib.ptr(g.rowptr), col=_lib.ptr(g.col), val=_lib.ptr(g.val), row_perm=_lib.ptr(g.row_perm),
+            n_long_rows=g.n_long_rows,
+            user_emb=_lib.ptr(wu.data), item_emb=_lib.ptr(wi.data),
+            m_user=_lib.ptr(su["exp_avg"]), v_user=_lib.ptr(su["exp_avg_sq"]),
+            m_item=_lib.ptr(si["exp_avg"]), v_item=_lib.ptr(si["exp_avg_sq"]),
+            buf_a=_lib.ptr(ws["buf_a"]), buf_b=_lib.ptr(ws["buf_b"]), light=_lib.ptr(ws["light"]),
+            gprop=_lib.ptr(ws["gprop"]), gego=_lib.ptr(ws["gego"]), grad=_lib.ptr(ws["grad"]),
+            state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
+        self._handle, self._handle_key, self._ws = h, key, ws
+        return h
+
+    def _drop_handle(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.lib().rk_lightgcn_destroy(self._handle)
+            self._handle = None
+            self._handle_key = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference API
+    def computer(self):
+        """lightgcn.py:82-113 -> (users[U,d], items[I,d]); views of the handle's workspace."""
+        h = self._ensure_handle(want_grad=self._ws is not None and self._ws.get("grad") is not None)
+        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "rk_lightgcn_propagate")
+        light = self._ws["light"]
+        return light[: self.num_users], light[self.num_users:]
+
+    def getUsersRating(self, users):
+        all_users, all_items = self.computer()
+        return self.f(torch.matmul(all_users[users.long()], all_items.t()))
+
+    def getEmbedding(self, users, pos_items, neg_items):
+        all_users, all_items = self.computer()
+        return (all_users[users], all_items[pos_items], all_items[neg_items], self.embedding_user(users),
+                self.embedding_item(pos_items), self.embedding_item(neg_items))
+
+    def _run_epoch(self, users, pos, neg, batch, apply_update=True, want_grad=False):
+        h = self._ensure_handle(want_grad=want_grad)
+        n = users.numel()
+        n_steps = (n + batch - 1) // batch
+        loss_partials = torch.empty(n_steps * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)
+        su = self._adam_state(self.embedding_user.weight)
+        t0 = int(su["step"].item()) if apply_update else 0
+        _lib.check(_lib.lib().rk_lightgcn_train_epoch(
+            h, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch, t0, _lib.ptr(loss_partials),
+            1 if apply_update else 0, int(self.graph_steps) if apply_update else 0, _lib.stream_ptr()),
+            "rk_lightgcn_train_epoch")
+        if apply_update:
+            for p in (self.embedding_user.weight, self.embedding_item.weight):
+                self.optimizer.state[p]["step"] += n_steps
+        return loss_partials.view(n_steps, _lib.RK_LOSS_PARTIALS)
+
+    def train_step(self, **config):
+        """One epoch over dataset.generate_batch() (lightgcn.py:132-172) -> (mean step loss,)."""
+        self.train()
+        pbar = config.get("progress_bar", None)
+        if not self._fused_adam:
+            raise NotImplementedError("the HIP LightGCN path fuses torch.optim.Adam (default options); "
+                                      f"optimizer {type(self.optimizer).__name__} is not supported")
+        (users, pos, neg), batch = self._collect_epoch(self.dataset, ("users", "positive_items", "negative_items"))
+        dev = self.embedding_user.weight.device
+        users, pos, neg = (t.to(dev).long().contiguous() for t in (users, pos, neg))
+        partials = self._run_epoch(users, pos, neg, batch)
+        step_losses = partials.sum(dim=1).double().cpu()  # ONE device->host sync per epoch
+        mean_loss = float(step_losses.sum().item() / len(step_losses))
+        if pbar:
+            pbar.set_description(f"loss {mean_loss:.5f}")
+        return (mean_loss,)
+
+    def forward(self, users, items):
+        all_users, all_items = self.computer()
+        out = torch.empty(users.numel(), device=all_users.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rk_pair_scores(
+            self.latent_dim, _lib.ptr(all_users), _lib.ptr(all_items), None, None, 0.0, _lib.ptr(users.long().contiguous()),
+            _lib.ptr(items.long().contiguous()), users.numel(), _lib.ptr(out), _lib.stream_ptr()), "rk_pair_scores")
+        return out
+
+    # ------------------------------------------------------------------ batched evaluation hook
+    def scoring_tables(self):
+        """(user_rows[U,d], item_rows[I,d], user_bias|None, item_bias|None, mean) for rk_score_topk."""
+        all_users, all_items = self.computer()
+        return all_users, all_items, None, None, 0.0
+
+    def input_describe(self):
+        return {
+            "train_step": {
+                "users": (torch.int64, (VarDim(comment="batch"))),
+                "positive_items": (torch.int64, (VarDim(comment="batch"))),
+                "negative_items": (torch.int64, (VarDim(comment="batch"))),
+            },
+            "forward": {"users": (torch.int64, (VarDim(comment="batch"))), "items": (torch.int64, (VarDim(comment="batch")))},
+        }
+
+    def output_describe(self):
+        return {
+            "train_step": {"loss": (float, [])},
+            "forward": {"unnormalized_scores": (torch.float32, [VarDim(comment="batch")])},
+        }

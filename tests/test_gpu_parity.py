@@ -1,0 +1,251 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs and against the golden fixtures captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests import _golden as G
+from tests._stub import LGN_KEYS, PW_KEYS, ReplayDataset
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+TABLE_RTOL = 1e-4
+
+
+def _rand_csr(rng, n, avg, long_rows=()):
+    deg = rng.poisson(avg, n).astype(np.int64)
+    for r, k in long_rows:
+        deg[r] = k
+    deg = np.minimum(deg, n)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in deg]).astype(np.int32)
+    val = rng.random(len(col), dtype=np.float32)
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256, 48, 100])
+def test_spmm_matches_oracle(gpu_device, d):
+    from recad_amd.graph import CsrGraph
+    rng = np.random.default_rng(d)
+    n = 3000
+    rowptr, col, val = _rand_csr(rng, n, 12, long_rows=[(5, 2900), (77, 700), (1500, 513), (9, 0)])
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    coo = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, col]).astype(np.int64)), torch.from_numpy(val), (n, n)).coalesce()
+    g = CsrGraph.from_torch_coo(coo, gpu_device)
+    assert np.array_equal(g.rowptr.cpu().numpy(), rowptr) and np.array_equal(g.col.cpu().numpy(), col)
+    assert g.n_long_rows == 3
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    add = rng.standard_normal((n, d), dtype=np.float32)
+    y = g.spmm(torch.from_numpy(x).to(gpu_device), torch.from_numpy(add).to(gpu_device)).cpu().numpy()
+    ref = orc.spmm(rowptr, col, val, x) + add
+    assert G.relerr(y, ref) < 2e-6
+    y2 = g.spmm(torch.from_numpy(x).to(gpu_device)).cpu().numpy()
+    y3 = g.spmm(torch.from_numpy(x).to(gpu_device)).cpu().numpy()
+    assert np.array_equal(y2, y3), "SpMM must be bit-reproducible run to run"
+
+
+LGN = ["lightgcn_dev_d64", "lightgcn_dev_d128_l2_tg", "lightgcn_game_d64", "lightgcn_game_d64_tg"]
+
+
+def _make_lgn(g, device, steps=None):
+    from recad_amd import model
+    ds = ReplayDataset(g, LGN_KEYS, device=device, steps=steps)
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=int(g["dim"]), lightGCN_n_layers=int(g["layers"])).I(dataset=ds)
+    u, i = G.lightgcn_init(g)
+    m.embedding_user.weight.data.copy_(torch.from_numpy(u))
+    m.embedding_item.weight.data.copy_(torch.from_numpy(i))
+    return m.to(device), ds
+
+
+@pytest.mark.parametrize("name", LGN)
+def test_lightgcn_propagate_golden(gpu_device, name):
+    g = G.load(name)
+    m, _ = _make_lgn(g, gpu_device)
+    lu, li = m.computer()
+    light = torch.cat([lu, li]).cpu().numpy()
+    assert G.relerr(light[:: int(g["row_stride"])], g["light0"]) < 1e-6
+
+
+@pytest.mark.parametrize("graph_steps", [0, 4])
+@pytest.mark.parametrize("name", LGN)
+def test_lightgcn_train_golden(gpu_device, name, graph_steps):
+    g = G.load(name)
+    rs = int(g["row_stride"])
+    # step-1 gradients (no update)
+    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    b = next(ds.generate_batch())
+    part = m._run_epoch(b["users"], b["positive_items"], b["negative_items"], len(b["users"]), apply_update=False, want_grad=True)
+    grad = m._ws["grad"].cpu().numpy()
+    U = int(g["n_users"])
+    assert G.relerr(grad[:U][::rs], g["grad1_user"]) < 1e-5
+    assert G.relerr(grad[U:][::rs], g["grad1_item"]) < 1e-5
+    assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
+    # one step, then the rest, through the public train_step
+    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    m.graph_steps = graph_steps
+    (l0,) = m.train_step(progress_bar=None)
+    assert abs(l0 - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy()[::rs], g["after1_user"]) < 1e-5
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy()[::rs], g["after1_item"]) < 1e-5
+    n_steps = len(g["batch_len"])
+    if n_steps > 1:
+        # remaining steps in ONE epoch call when the recorded batches are equal-sized (same epoch)
+        lens = g["batch_len"][1:]
+        full = int(lens[0])
+        groups, cur = [], []
+        for s in range(1, n_steps):
+            cur.append(s)
+            if int(g["batch_len"][s]) != full:
+                groups.append(cur)
+                cur = []
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            ds.steps = grp
+            users, pos, neg = (torch.cat([torch.from_numpy(g["batches"][s, k, : int(g["batch_len"][s])].astype(np.int64))
+                                          for s in grp]).to(gpu_device) for k in range(3))
+            part = m._run_epoch(users, pos, neg, full)
+            losses = part.sum(1).double().cpu().numpy()
+            for s, l in zip(grp, losses):
+                assert abs(l - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, l, g["losses"][s])
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy()[::rs], g["final_user"]) < TABLE_RTOL
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy()[::rs], g["final_item"]) < TABLE_RTOL
+    assert int(m.optimizer.state[m.embedding_user.weight]["step"].item()) == n_steps
+
+
+def test_lightgcn_forward_matches_oracle(gpu_device):
+    g = G.load("lightgcn_game_d64_tg")
+    m, _ = _make_lgn(g, gpu_device)
+    rng = np.random.default_rng(3)
+    users = rng.integers(0, int(g["n_users"]), 5000)
+    items = rng.integers(0, int(g["n_items"]), 5000)
+    out = m(torch.from_numpy(users).to(gpu_device), torch.from_numpy(items).to(gpu_device)).cpu().numpy()
+    csr = orc.coo_to_csr(int(g["n_users"]) + int(g["n_items"]), g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    light = orc.lightgcn_propagate(csr, u0, i0, int(g["layers"]))
+    ref = orc.pair_scores(light[: int(g["n_users"])], light[int(g["n_users"]):], users, items)
+    assert np.allclose(out, ref, rtol=1e-5, atol=1e-7)
+
+
+def _eval_against_golden(g, m, device):
+    from recad_amd.evaluate import eligible_users, full_catalog_topk, hr_rows
+    users = eligible_users(g["train_ptr"], g["train_idx"], g["target_ids"])
+    assert np.array_equal(users, g["eval_users"])
+    res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=100, chunk=1000)
+    rows = hr_rows(users, res, g["topks"])
+    ref = g["eval_rows"]
+    assert rows.shape == ref.shape and np.array_equal(rows[:, 0], ref[:, 0])
+    assert np.allclose(rows[:, 1], ref[:, 1], rtol=1e-5, atol=1e-6)
+    tie_free = g["top_min_gap"] > G.TIE_RTOL
+    assert np.array_equal(rows[tie_free, 2:], ref[tie_free, 2:])
+    for k in range(len(g["topks"])):  # HR@K within 1e-4 relative (north_star)
+        assert abs(rows[:, 2 + k].mean() - ref[:, 2 + k].mean()) <= 1e-4 * max(ref[:, 2 + k].mean(), 1e-12) + 1.0 / len(rows)
+    es = int(g["eval_stride"])
+    mine = [(res["top_ids"][r], res["top_scores"][r]) for r in range(0, len(users), es)]
+    exact = G.compare_topk_lists(mine, g["top_ids"], g["top_scores"])
+    assert exact >= 0.97 * len(mine), exact
+    return res, users
+
+
+@pytest.mark.parametrize("name", ["lightgcn_dev_d64", "lightgcn_game_d64_tg"])
+def test_lightgcn_eval_golden(gpu_device, name):
+    g = G.load(name)
+    m, ds = _make_lgn(g, gpu_device)
+    # train over the recorded batches exactly as the golden run did (one train_step per batch)
+    for s in range(len(g["batch_len"])):
+        ds.steps = [s]
+        m.train_step()
+    _eval_against_golden(g, m, gpu_device)
+
+
+@pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False)])
+def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
+    """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
+    so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first)."""
+    from recad_amd import _lib
+    rng = np.random.default_rng(d)
+    nb, I, K = 150, 1000 + d, 100
+    urows = rng.standard_normal((nb, d), dtype=np.float32)
+    itab = rng.standard_normal((I, d), dtype=np.float32)
+    itab[17] = itab[400]  # exact ties
+    itab[18] = itab[400]
+    ub = rng.standard_normal(nb, dtype=np.float32) if with_bias else None
+    ib = rng.standard_normal(I, dtype=np.float32) if with_bias else None
+    if with_bias:
+        ib[17] = ib[18] = ib[400]
+    seen_lists = [np.sort(rng.choice(I, size=rng.integers(0, 60), replace=False)).astype(np.int32) for _ in range(nb)]
+    seen_lists[3] = np.sort(rng.choice(I, size=I - 40, replace=False)).astype(np.int32)  # fewer than K unseen
+    seen_ptr = np.zeros(nb + 1, dtype=np.int32)
+    seen_ptr[1:] = np.cumsum([len(s) for s in seen_lists])
+    seen_idx = np.concatenate(seen_lists).astype(np.int32)
+    targets = np.array([0, 5, 400], dtype=np.int32)
+    dev = gpu_device
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=dev).contiguous() if a is not None else None
+    top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev)
+    top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
+    ts = torch.empty(nb, 3, dtype=torch.float32, device=dev)
+    tr = torch.empty(nb, 3, dtype=torch.int32, device=dev)
+    scratch = torch.empty(nb * I, dtype=torch.float32, device=dev)
+    tu, ti, tub, tib = t(urows, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
+    ids = torch.arange(nb, dtype=torch.int32, device=dev)
+    sp, si, tg = t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(targets, torch.int32)
+    _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(ids), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.25 if with_bias else 0.0,
+                                        _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 3,
+                                        _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+    ref_scores = orc.score_rows(urows, itab, ub, ib, 0.25 if with_bias else 0.0)
+    got_scores = scratch.view(nb, I).cpu().numpy()
+    for b in range(nb):
+        unseen = np.ones(I, dtype=bool)
+        unseen[seen_lists[b]] = False
+        assert np.array_equal(got_scores[b][unseen], ref_scores[b][unseen]), f"row {b}: MFMA != fmaf chain"
+        rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen_lists[b], K, targets)
+        assert np.array_equal(top_ids[b].cpu().numpy(), rid), b
+        assert np.array_equal(top_sc[b].cpu().numpy(), rsc), b
+        assert np.array_equal(ts[b].cpu().numpy(), rts) and np.array_equal(tr[b].cpu().numpy(), rtr), b
+
+
+def test_norm_adj_on_device(gpu_device):
+    from recad_amd.graph import CsrGraph
+    g = G.load("lightgcn_game_d64_tg")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    idx = np.concatenate([np.sort(g["train_idx"][g["train_ptr"][u]:g["train_ptr"][u + 1]]) for u in range(U)]).astype(np.int32)
+    cg = CsrGraph.from_user_item_csr(U, I, g["train_ptr"], idx, gpu_device)
+    rp, c, v = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    assert np.array_equal(cg.rowptr.cpu().numpy(), rp) and np.array_equal(cg.col.cpu().numpy(), c)
+    assert np.allclose(cg.val.cpu().numpy(), v, rtol=4e-7, atol=0)
+    orp, oc, ov = orc.build_norm_adj(U, I, g["train_ptr"], idx)
+    assert np.allclose(cg.val.cpu().numpy(), ov, rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("name", ["mf_dev_e64", "mf_game_e64"])
+def test_mf_train_and_eval_golden(gpu_device, name):
+    from recad_amd import model
+    g = G.load(name)
+    rs = int(g["row_stride"])
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    m = model.from_config("victim", "mf", embedding_size=int(g["dim"])).I(dataset=ds)
+    for p, a in zip((m.user_emb, m.item_emb, m.user_bias, m.item_bias), G.mf_init(g)):
+        p.weight.data.copy_(torch.from_numpy(a))
+    m = m.to(gpu_device)
+    assert abs(float(m.mean.item()) - float(g["mean"])) == 0
+    b = next(ds.generate_batch())
+    part = m._run_epoch(b["users"], b["items"], b["labels"], len(b["users"]), apply_update=False)
+    assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
+    U, I, d = m.num_users, m.num_items, m.dim
+    gr = m._mom[2].cpu().numpy()
+    assert G.relerr(gr[: U * d].reshape(U, d)[::rs], g["grad1_user_emb"]) < 1e-5
+    assert G.relerr(gr[U * d:(U + I) * d].reshape(I, d)[::rs], g["grad1_item_emb"]) < 1e-5
+    assert G.relerr(gr[(U + I) * d:(U + I) * d + U][::rs], g["grad1_user_bias"].reshape(-1)) < 1e-5
+    m._mom[2].zero_()
+    for s in range(len(g["batch_len"])):
+        ds.steps = [s]
+        (loss,) = m.train_step()
+        assert abs(loss - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, loss, g["losses"][s])
+        if s == 0:
+            assert G.relerr(m.user_emb.weight.detach().cpu().numpy()[::rs], g["after1_user_emb"]) < 1e-5
+    for nm, p in (("user_emb", m.user_emb), ("item_emb", m.item_emb), ("user_bias", m.user_bias), ("item_bias", m.item_bias)):
+        assert G.relerr(p.weight.detach().cpu().numpy()[::rs], g["final_" + nm]) < TABLE_RTOL, nm
+    _eval_against_golden(g, m, gpu_device)
