@@ -10,7 +10,7 @@ import random
 import numpy as np
 import torch
 
-from . import default, model, utils, victim  # noqa: F401
+from . import dataset, default, model, utils, victim, workflow  # noqa: F401
 from .default import SEED
 
 random.seed(SEED)
