@@ -43,11 +43,16 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
                   const float *coo_val, int32_t *rowptr /*[n_rows+1]*/, int32_t *col /*[nnz]*/,
                   float *val /*[nnz]*/, void *stream);
 
-/* Degree-descending row schedule for rk_spmm_csr (load balance for power-law rows).
- * Synchronous (reads rowptr back once per graph build).  row_perm: device int32[n_rows].
- * n_long_rows: rows (a prefix of row_perm) that get a whole workgroup each. */
-int rk_csr_schedule(int32_t n_rows, const int32_t *rowptr, int32_t *row_perm, int32_t *n_long_rows,
-                    void *stream);
+/* Work schedule for rk_spmm_csr (load balance for power-law rows): every row is cut into
+ * segments of <= 64 nonzeros, whole rows are packed into workgroups of 16 segments (first-fit
+ * decreasing), rows with more than 1024 nonzeros get a workgroup of their own.  Built on the
+ * host once per graph (reads rowptr back: synchronous).  Two calls: _build returns the number
+ * of workgroups, _upload writes the per-wave descriptors int32[n_blocks*16*4] to the device. */
+typedef struct rk_schedule *rk_schedule_t;
+int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void *stream, rk_schedule_t *out,
+                          int32_t *n_blocks);
+int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
+int rk_csr_schedule_destroy(rk_schedule_t sched);
 
 /* D^-1/2 A D^-1/2 of the bipartite user-item graph straight into CSR, on device.
  * Replaces ImplicitData.getSparseGraph, recad/dataset/implicit.py:243-298 (scipy dok/lil).
@@ -57,11 +62,10 @@ int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t *r_ptr, co
                       int32_t *rowptr, int32_t *col, float *val, int32_t *tmp, void *stream);
 
 /* Y = A.X (+ add).  Replaces torch.sparse.mm(g, all_emb), recad/model/victim/lightgcn.py:107.
- * X is given as two row blocks (rows < x_split in x_lo, the rest in x_hi) so the user and
- * item tables need no torch.cat (lightgcn.py:88).  add (nullable) has the same row count as Y. */
+ * X, add (nullable), Y: device float[n_rows*dim], row-major; n_rows*dim*4 < 4 GiB. */
 int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                const int32_t *row_perm, int32_t n_long_rows, int32_t dim, const float *x_lo,
-                const float *x_hi, int32_t x_split, const float *add, float *y, void *stream);
+                const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
+                const float *add, float *y, void *stream);
 
 /* ---------------------------------------------------------------- LightGCN --------- */
 typedef struct rk_lightgcn_desc {
@@ -71,9 +75,12 @@ typedef struct rk_lightgcn_desc {
     /* normalised adjacency, CSR over N = n_users + n_items nodes (device) */
     const int32_t *rowptr, *col;
     const float *val;
-    const int32_t *row_perm;
-    int32_t n_long_rows, reserved1;
-    /* parameters and Adam moments, row-major fp32 (device); updated in place */
+    const int32_t *wave_desc;                 /* from rk_csr_schedule_upload */
+    int32_t n_blocks, reserved1;
+    /* parameters and Adam moments, row-major fp32 (device); updated in place.  The item
+     * block must directly follow the user block (item_emb == user_emb + n_users*dim, same for
+     * m/v): E0 = [users; items] is then ONE [N,dim] matrix and torch.cat (lightgcn.py:88) is
+     * a no-op. */
     float *user_emb, *item_emb;               /* embedding_user/.item.weight, lightgcn.py:40-45 */
     float *m_user, *v_user, *m_item, *v_item; /* exp_avg / exp_avg_sq of torch.optim.Adam */
     /* workspace, each float[N*dim] (device) */

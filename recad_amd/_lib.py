@@ -31,8 +31,8 @@ class LightGCNDesc(C.Structure):
         ("n_users", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("n_layers", C.c_int32),
         ("lam", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("reserved0", C.c_int32),
-        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("row_perm", C.c_void_p),
-        ("n_long_rows", C.c_int32), ("reserved1", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("wave_desc", C.c_void_p),
+        ("n_blocks", C.c_int32), ("reserved1", C.c_int32),
         ("user_emb", C.c_void_p), ("item_emb", C.c_void_p),
         ("m_user", C.c_void_p), ("v_user", C.c_void_p), ("m_item", C.c_void_p), ("v_item", C.c_void_p),
         ("buf_a", C.c_void_p), ("buf_b", C.c_void_p), ("light", C.c_void_p), ("gprop", C.c_void_p), ("gego", C.c_void_p),
@@ -49,9 +49,11 @@ _SIGNATURES = {
     "rk_last_error": [],
     "rk_device_info": [C.c_char_p, _I32, C.POINTER(_I32)],
     "rk_coo_to_csr": [_I32, _I64, _P, _P, _P, _P, _P, _P, _P],
-    "rk_csr_schedule": [_I32, _P, _P, C.POINTER(_I32), _P],
+    "rk_csr_schedule_build": [_I32, _P, _P, C.POINTER(_P), C.POINTER(_I32)],
+    "rk_csr_schedule_upload": [_P, _P, _P],
+    "rk_csr_schedule_destroy": [_P],
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
-    "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P],
+    "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
     "rk_lightgcn_propagate": [_P, _P],

@@ -27,7 +27,7 @@ __global__ void state_init_kernel(int *state, int step_base, int adam_t, long lo
 struct BprArgs {
     int U, d, L;
     float lam;
-    const float *light, *user_emb, *item_emb;
+    const float *light, *emb;  // emb = [users; items] contiguous
     float *gprop, *gego;
     const int64_t *users, *pos, *neg;
     float *loss_partials;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     for (int b = wave_id; b < nb; b += n_waves) {
         const long long u = a.users[off + b], p = a.pos[off + b], n = a.neg[off + b];
         const float *lu = a.light + (size_t)u * d, *lp = a.light + (size_t)(a.U + p) * d, *ln = a.light + (size_t)(a.U + n) * d;
-        const float *eu = a.user_emb + (size_t)u * d, *ep = a.item_emb + (size_t)p * d, *en = a.item_emb + (size_t)n * d;
+        const float *eu = a.emb + (size_t)u * d, *ep = a.emb + (size_t)(a.U + p) * d, *en = a.emb + (size_t)(a.U + n) * d;
         float ps = 0.f, ns = 0.f, r = 0.f;
         for (int k = lane; k < d; k += 64) {
             const float xu = lu[k];
@@ -131,11 +131,17 @@ static int check_desc(const rk_lightgcn_desc &d)
 {
     if (d.n_users <= 0 || d.n_items <= 0 || d.dim <= 0 || d.n_layers < 0) RK_FAIL(RK_EINVAL, "lightgcn: bad sizes");
     if (d.dim > 512) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 512 unsupported", d.dim);
-    if (!d.rowptr || !d.col || !d.val || !d.row_perm) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
+    if (!d.rowptr || !d.col || !d.val || !d.wave_desc || d.n_blocks <= 0) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
     if (!d.user_emb || !d.item_emb || !d.m_user || !d.v_user || !d.m_item || !d.v_item)
         RK_FAIL(RK_EINVAL, "lightgcn: parameter/moment pointers missing");
     if (!d.buf_a || !d.buf_b || !d.light || !d.gprop || !d.gego || !d.state || !d.coef)
         RK_FAIL(RK_EINVAL, "lightgcn: workspace pointers missing");
+    const size_t ud = (size_t)d.n_users * d.dim;
+    if (d.item_emb != d.user_emb + ud || d.m_item != d.m_user + ud || d.v_item != d.v_user + ud)
+        RK_FAIL(RK_EINVAL, "lightgcn: the item table/moments must directly follow the user table/moments in memory "
+                           "(one [U+I, dim] allocation; the kernels address E0 with a single base)");
+    if (((size_t)d.n_users + d.n_items) * d.dim * sizeof(float) >= (1ULL << 32))
+        RK_FAIL(RK_EINVAL, "lightgcn: (U+I)*dim*4 must be < 4 GiB (32-bit gather offsets)");
     return RK_OK;
 }
 
@@ -164,12 +170,11 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
     SpmmArgs a;
     memset(&a, 0, sizeof(a));
     a.n_rows = d.n_users + d.n_items;
-    a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.perm = d.row_perm; a.n_long = d.n_long_rows;
+    a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.wave_desc = reinterpret_cast<const int4 *>(d.wave_desc); a.n_blocks = d.n_blocks;
     a.d = d.dim;
     return a;
 }
 
-static void set_x(SpmmArgs &a, const float *x, int n_rows) { a.x_lo = x; a.x_hi = x; a.x_split = n_rows; }
 
 // forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
 static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s)
@@ -185,11 +190,9 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s)
     float *bufs[2] = {d.buf_a, d.buf_b};
     for (int l = 1; l <= L; ++l) {
         SpmmArgs a = base_args(d);
-        if (l == 1) { a.x_lo = d.user_emb; a.x_hi = d.item_emb; a.x_split = d.n_users; }
-        else set_x(a, bufs[l & 1], N);
+        a.x = (l == 1) ? d.user_emb : bufs[l & 1];
         a.e.y = (l < L) ? bufs[(l + 1) & 1] : nullptr;
-        if (l == 1) { a.e.sum_lo = d.user_emb; a.e.sum_hi = d.item_emb; a.e.sum_split = d.n_users; }
-        else { a.e.sum_lo = d.light; a.e.sum_hi = d.light; a.e.sum_split = N; }
+        a.e.sum_in = (l == 1) ? d.user_emb : d.light;
         a.e.sum_out = d.light;
         a.e.sum_scale = (l == L) ? inv : 1.0f;
         RK_HIP(spmm_launch(a, s));
@@ -205,8 +208,7 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
     auto fill_adam = [&](SpmmEpi &e) {
         if (apply_update) {
             e.adam = 1;
-            e.p_lo = d.user_emb; e.p_hi = d.item_emb; e.m_lo = d.m_user; e.m_hi = d.m_item; e.v_lo = d.v_user; e.v_hi = d.v_item;
-            e.p_split = d.n_users;
+            e.p = d.user_emb; e.m = d.m_user; e.v = d.v_user;
             e.coef = d.coef + 2 * k;
             e.b1 = d.beta1; e.b2 = d.beta2; e.eps = d.eps;
         }
@@ -217,10 +219,9 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
     if (L == 0) RK_FAIL(RK_EINVAL, "lightgcn: n_layers == 0 training is not supported by the fused path");
     for (int j = 1; j <= L; ++j) {
         SpmmArgs a = base_args(d);
-        set_x(a, j == 1 ? d.gprop : bufs[j & 1], N);
+        a.x = (j == 1) ? d.gprop : bufs[j & 1];
         const bool last = (j == L);
-        const float *add = last ? d.gego : d.gprop;
-        a.e.add_lo = add; a.e.add_hi = add; a.e.add_split = N;
+        a.e.add = last ? d.gego : d.gprop;
         if (last) {
             a.e.zero1 = d.gego;
             a.e.zero2 = (L >= 2) ? d.gprop : nullptr;
@@ -241,7 +242,7 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     if (rc) return rc;
     BprArgs b;
     b.U = d.n_users; b.d = d.dim; b.L = d.n_layers; b.lam = d.lambda;
-    b.light = d.light; b.user_emb = d.user_emb; b.item_emb = d.item_emb;
+    b.light = d.light; b.emb = d.user_emb;
     b.gprop = d.gprop; b.gego = d.gego;
     b.users = users; b.pos = pos; b.neg = neg;
     b.loss_partials = loss_partials;

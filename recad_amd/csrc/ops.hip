@@ -58,32 +58,94 @@ RK_EXPORT int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row,
     return RK_OK;
 }
 
-// Rows longer than this get a whole 16-wave workgroup in rk_spmm_csr (>= 32 nonzeros per wave).
-static constexpr int kLongRow = 512;
+// ---- SpMM work schedule (see spmm.h)
+struct rk_schedule {
+    std::vector<int32_t> desc;  // int4 per wave: {row, e_begin, e_end, n_segments if leader else 0}
+    int32_t n_blocks = 0;
+};
 
-RK_EXPORT int rk_csr_schedule(int32_t n_rows, const int32_t *rowptr, int32_t *row_perm, int32_t *n_long_rows, void *stream)
+RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void *stream, rk_schedule_t *out, int32_t *n_blocks)
 {
-    if (n_rows <= 0 || !rowptr || !row_perm || !n_long_rows) RK_FAIL(RK_EINVAL, "rk_csr_schedule: bad arguments");
+    if (n_rows <= 0 || !rowptr || !out || !n_blocks) RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    std::vector<int32_t> rp((size_t)n_rows + 1), perm((size_t)n_rows);
+    std::vector<int32_t> rp((size_t)n_rows + 1);
     RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
     RK_HIP(hipStreamSynchronize(s));
-    std::iota(perm.begin(), perm.end(), 0);
-    // counting sort by degree, descending, stable in row id => deterministic schedule
+    // rows by degree, descending, stable in row id (counting sort) => deterministic schedule
     int32_t maxdeg = 0;
     for (int32_t r = 0; r < n_rows; ++r) maxdeg = std::max(maxdeg, rp[r + 1] - rp[r]);
-    std::vector<int32_t> cnt((size_t)maxdeg + 2, 0);
+    std::vector<int32_t> cnt((size_t)maxdeg + 2, 0), order((size_t)n_rows);
     for (int32_t r = 0; r < n_rows; ++r) cnt[(size_t)(maxdeg - (rp[r + 1] - rp[r])) + 1]++;
     for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-    int32_t nl = 0;
-    for (int32_t r = 0; r < n_rows; ++r) {
-        const int32_t deg = rp[r + 1] - rp[r];
-        perm[(size_t)cnt[(size_t)(maxdeg - deg)]++] = r;
-        if (deg > kLongRow) ++nl;
+    for (int32_t r = 0; r < n_rows; ++r) order[(size_t)cnt[(size_t)(maxdeg - (rp[r + 1] - rp[r]))]++] = r;
+
+    const int kSpmmWaves = spmm_waves();
+    static const int seg_nnz = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : kSegNnz;
+    rk_schedule *sc = new rk_schedule();
+    std::vector<int32_t> &d = sc->desc;
+    auto new_block = [&]() {
+        const size_t base = d.size();
+        d.resize(base + (size_t)kSpmmWaves * 4, 0);
+        for (int w = 0; w < kSpmmWaves; ++w) d[base + (size_t)w * 4] = -1;
+        return base;
+    };
+    // open workgroups by free wave count: free_list[k] = blocks with exactly k free waves
+    std::vector<std::vector<size_t>> free_list((size_t)kSpmmWaves + 1);
+    for (int32_t oi = 0; oi < n_rows; ++oi) {
+        const int32_t r = order[(size_t)oi];
+        const int32_t b = rp[r], e = rp[r + 1], nnz = e - b;
+        int32_t nseg = std::max(1, (nnz + seg_nnz - 1) / seg_nnz);
+        if (nseg > kSpmmWaves) {  // long row: own workgroup, waves loop over ceil(nnz/16) nonzeros each
+            const size_t base = new_block();
+            int32_t chunk = (nnz + kSpmmWaves - 1) / kSpmmWaves;
+            chunk = (chunk + 3) & ~3;
+            for (int w = 0; w < kSpmmWaves; ++w) {
+                const int32_t eb = std::min(e, b + w * chunk), ee = std::min(e, eb + chunk);
+                d[base + (size_t)w * 4 + 0] = r;
+                d[base + (size_t)w * 4 + 1] = eb;
+                d[base + (size_t)w * 4 + 2] = ee;
+                d[base + (size_t)w * 4 + 3] = (w == 0) ? kSpmmWaves : 0;
+            }
+            continue;
+        }
+        // best fit: the open workgroup with the fewest free waves that still fits
+        size_t base = (size_t)-1;
+        int used = 0;
+        for (int k = nseg; k <= kSpmmWaves && base == (size_t)-1; ++k)
+            if (!free_list[(size_t)k].empty()) {
+                base = free_list[(size_t)k].back();
+                free_list[(size_t)k].pop_back();
+                used = kSpmmWaves - k;
+            }
+        if (base == (size_t)-1) { base = new_block(); used = 0; }
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            const size_t o = base + (size_t)(used + sgi) * 4;
+            d[o + 0] = r;
+            d[o + 1] = std::min(e, b + sgi * seg_nnz);
+            d[o + 2] = std::min(e, b + (sgi + 1) * seg_nnz);
+            d[o + 3] = (sgi == 0) ? nseg : 0;
+        }
+        const int left = kSpmmWaves - used - nseg;
+        if (left > 0) free_list[(size_t)left].push_back(base);
     }
-    RK_HIP(hipMemcpyAsync(row_perm, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+    sc->n_blocks = (int32_t)(d.size() / ((size_t)kSpmmWaves * 4));
+    *out = sc;
+    *n_blocks = sc->n_blocks;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream)
+{
+    if (!sched || !wave_desc) RK_FAIL(RK_EINVAL, "rk_csr_schedule_upload: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    RK_HIP(hipMemcpyAsync(wave_desc, sched->desc.data(), sizeof(int32_t) * sched->desc.size(), hipMemcpyHostToDevice, s));
     RK_HIP(hipStreamSynchronize(s));
-    *n_long_rows = nl;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_csr_schedule_destroy(rk_schedule_t sched)
+{
+    delete sched;
     return RK_OK;
 }
 
@@ -236,16 +298,17 @@ RK_EXPORT int rk_pair_scores(int32_t dim, const float *utab, const float *itab, 
 }
 
 RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                          const int32_t *row_perm, int32_t n_long_rows, int32_t dim, const float *x_lo,
-                          const float *x_hi, int32_t x_split, const float *add, float *y, void *stream)
+                          const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
+                          const float *add, float *y, void *stream)
 {
-    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !row_perm || !x_lo || !y)
+    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !y)
         RK_FAIL(RK_EINVAL, "rk_spmm_csr: bad arguments");
     SpmmArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.perm = row_perm; a.n_long = n_long_rows; a.d = dim;
-    a.x_lo = x_lo; a.x_hi = x_hi ? x_hi : x_lo; a.x_split = x_hi ? x_split : n_rows;
-    if (add) { a.e.add_lo = add; a.e.add_hi = add; a.e.add_split = n_rows; }
+    a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.wave_desc = reinterpret_cast<const int4 *>(wave_desc); a.n_blocks = n_blocks; a.d = dim;
+    if ((size_t)n_rows * dim * sizeof(float) >= (1ULL << 32)) RK_FAIL(RK_EINVAL, "rk_spmm_csr: n_rows*dim*4 must be < 4 GiB");
+    a.x = x;
+    a.e.add = add;
     a.e.y = y;
     RK_HIP(spmm_launch(a, (hipStream_t)stream));
     return RK_OK;

@@ -2,32 +2,33 @@
 // gradient buffers, dense Adam).  Replaces torch.sparse.mm at
 // recad/model/victim/lightgcn.py:107 and its autograd twin.
 //
-// Mapping (DESIGN.md "SpMM"): 1024-thread workgroups = 16 waves.  Rows are visited in a
-// degree-descending schedule (row_perm).  The first n_long rows get a whole workgroup each
-// (16 waves split the row's nonzeros, combine through LDS in fixed order); every other
-// workgroup takes 16 consecutive schedule entries, one row per wave, so the waves of a
-// workgroup carry similar work.  Inside a wave a row of D floats is covered by G = D/4
-// lanes with one 16-byte load each, so one global_load_dwordx4 gathers 64/G different
-// X rows; the column/value stream is read coalesced (64 entries per wave) and broadcast
-// with ds_bpermute.  Summation order is fixed by the schedule => bit-reproducible.
+// Mapping (DESIGN.md "SpMM"): 1024-thread workgroups = 16 waves.  A host-built schedule
+// (rk_csr_schedule_*) cuts every row into segments of <= 64 nonzeros and packs segments of
+// whole rows into workgroups of 16 (first-fit decreasing), one segment per wave, so every
+// wave has one short dependent chain: 64 column/value entries read coalesced, broadcast with
+// ds_bpermute, and up to 16 independent 16-byte gathers in flight.  Segments of one row sit
+// in consecutive waves; they combine through LDS in fixed order and the row's first wave runs
+// the epilogue.  Rows longer than 1024 nonzeros get a workgroup of their own and its waves
+// loop.  Inside a wave a row of D floats is covered by G = D/4 lanes with one 16-byte load
+// each, so one global_load_dwordx4 gathers 64/G different X rows.  Summation order is fixed
+// by the schedule => bit-reproducible.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 struct SpmmEpi {
     // v = acc (+ add[r])
-    const float *add_lo, *add_hi;
-    int add_split;
+    const float *add;
     float *y;  // nullable: y[r] = v
     // sum_out[r] = (sum_in[r] + v) * sum_scale   (nullable sum_out)
-    const float *sum_lo, *sum_hi;
-    int sum_split;
+    const float *sum_in;
     float *sum_out;
     float sum_scale;
     float *zero1, *zero2;  // nullable: rows set to 0 after the addend was read
     // Adam on p[r] with gradient v
     int adam;
-    float *p_lo, *p_hi, *m_lo, *m_hi, *v_lo, *v_hi;
-    int p_split;
+    float *p, *m, *v;
     const float *coef;  // {step_size, bc2s}
     float b1, b2, eps;
     int *state;  // bump words ST_STEP_BASE / ST_ADAM_T by `bump` (last kernel of a chunk)
@@ -38,26 +39,23 @@ struct SpmmArgs {
     int n_rows;
     const int *rowptr, *col;
     const float *val;
-    const int *perm;
-    int n_long;
+    const int4 *wave_desc;  // per wave: {row, e_begin, e_end, n_segments if row leader else 0}
+    int n_blocks;
     int d;
-    const float *x_lo, *x_hi;
-    int x_split;
+    const float *x;  // [n_rows, d] row-major; n_rows*d*4 < 4 GiB (32-bit byte offsets)
+    int dbg;
     SpmmEpi e;
 };
 
-static constexpr int kSpmmWaves = 16;
-static constexpr int kSpmmThreads = kSpmmWaves * kWave;
+static constexpr int kSpmmWavesMax = 16;
+// waves per workgroup (schedule and launch must agree); RK_SPMM_WAVES overrides for tuning
+inline int spmm_waves()
+{
+    static const int w = getenv("RK_SPMM_WAVES") ? atoi(getenv("RK_SPMM_WAVES")) : 8;
+    return (w == 4 || w == 8 || w == 16) ? w : 8;
+}
 
-__host__ inline int spmm_grid(int n_rows, int n_long) { return n_long + (n_rows - n_long + kSpmmWaves - 1) / kSpmmWaves; }
-
-template <int VEC>
-struct Acc;
-template <>
-struct Acc<4> {
-    float4 v;
-    __device__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
-};
+static constexpr int kSegNnz = 64;  // default nonzeros per schedule segment (RK_SEG_NNZ overrides, tuning only)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc)
 {
@@ -66,11 +64,33 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc)
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+template <int D, int UN>
+__device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n, int t0, const float *__restrict__ x,
+                                               int grp, int sub)
+{
+    constexpr int NG = 64 / (D / 4);
+    float4 xv[UN];
+    float av[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        const int src = (t0 + j) * NG + grp;
+        int cc = __shfl(c, src & 63, 64);
+        float aa = __shfl(a, src & 63, 64);
+        const bool ok = src < n;
+        cc = ok ? cc : 0;
+        av[j] = ok ? aa : 0.f;
+        xv[j] = *reinterpret_cast<const float4 *>(x + (unsigned)(cc * D + sub * 4));
+    }
+#pragma unroll
+    for (int j = 0; j < UN; ++j) acc = f4_fma(av[j], xv[j], acc);
+    return acc;
+}
+
 // Partial sum of row segment [eb, ee) for the D/4 lanes that share `sub`; after the
 // cross-group reduction every lane holds the total for its float4 slot.
-template <int D>
+template <int D, int UNMAX>
 __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, const float *__restrict__ val, int eb, int ee,
-                                               const float *x_lo, const float *x_hi, int split, int lane)
+                                               const float *__restrict__ x, int lane)
 {
     constexpr int G = D / 4, NG = 64 / G;
     const int grp = lane / G, sub = lane % G;
@@ -85,22 +105,12 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
         c_next = 0; a_next = 0.f;
         if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = val[base + 64 + lane]; }
         const int iters = (n + NG - 1) / NG;
-        for (int t = 0; t < iters; t += 4) {
-            float4 x[4];
-            float av[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int src = (t + j) * NG + grp;
-                int cc = __shfl(c, src & 63, 64);
-                float aa = __shfl(a, src & 63, 64);
-                const bool ok = src < n;
-                cc = ok ? cc : 0;
-                av[j] = ok ? aa : 0.f;
-                x[j] = *reinterpret_cast<const float4 *>(row2(x_lo, x_hi, split, cc, D) + sub * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = f4_fma(av[j], x[j], acc);
-        }
+        int t = 0;
+        for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
+        const int rem = iters - t;
+        if (UNMAX > 8 && rem > 8) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
+        else if (rem > 4) acc = gather_round<D, 8>(acc, c, a, n, t, x, grp, sub);
+        else if (rem > 0) acc = gather_round<D, 4>(acc, c, a, n, t, x, grp, sub);
     }
 #pragma unroll
     for (int o = G; o < 64; o <<= 1) {
@@ -111,28 +121,23 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
 }
 
 template <int D>
-__device__ __forceinline__ void spmm_epilogue(const SpmmEpi &e, int r, int sub, float4 v)
+__device__ __forceinline__ void spmm_epilogue(const SpmmEpi &e, int r, int sub, float4 v, float4 addv, float4 sumv)
 {
-    const size_t off = (size_t)sub * 4;
-    if (e.add_lo) {
-        float *ap = const_cast<float *>(row2(e.add_lo, e.add_hi, e.add_split, r, D)) + off;
-        v = f4_add(v, *reinterpret_cast<const float4 *>(ap));
-    }
-    if (e.zero1) *reinterpret_cast<float4 *>(e.zero1 + (size_t)r * D + off) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.zero2) *reinterpret_cast<float4 *>(e.zero2 + (size_t)r * D + off) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.y) *reinterpret_cast<float4 *>(e.y + (size_t)r * D + off) = v;
+    const size_t off = (size_t)r * D + (size_t)sub * 4;
+    if (e.add) v = f4_add(v, addv);
+    if (e.zero1) *reinterpret_cast<float4 *>(e.zero1 + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.zero2) *reinterpret_cast<float4 *>(e.zero2 + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.y) *reinterpret_cast<float4 *>(e.y + off) = v;
     if (e.sum_out) {
-        float4 s = *reinterpret_cast<const float4 *>(row2(e.sum_lo, e.sum_hi, e.sum_split, r, D) + off);
-        s = f4_add(s, v);
+        float4 s = f4_add(sumv, v);
         s.x *= e.sum_scale; s.y *= e.sum_scale; s.z *= e.sum_scale; s.w *= e.sum_scale;
-        *reinterpret_cast<float4 *>(e.sum_out + (size_t)r * D + off) = s;
+        *reinterpret_cast<float4 *>(e.sum_out + off) = s;
     }
     if (e.adam) {
         const float step_size = e.coef[0], bc2s = e.coef[1];
         const float w1 = (float)(1.0 - (double)e.b1), w2 = (float)(1.0 - (double)e.b2);
-        float4 *pp = reinterpret_cast<float4 *>(row2(e.p_lo, e.p_hi, e.p_split, r, D) + off);
-        float4 *mp = reinterpret_cast<float4 *>(row2(e.m_lo, e.m_hi, e.p_split, r, D) + off);
-        float4 *vp = reinterpret_cast<float4 *>(row2(e.v_lo, e.v_hi, e.p_split, r, D) + off);
+        float4 *pp = reinterpret_cast<float4 *>(e.p + off), *mp = reinterpret_cast<float4 *>(e.m + off);
+        float4 *vp = reinterpret_cast<float4 *>(e.v + off);
         float4 p = *pp, m = *mp, vv = *vp;
         adam_elem(p.x, m.x, vv.x, v.x, w1, e.b2, w2, step_size, bc2s, e.eps);
         adam_elem(p.y, m.y, vv.y, v.y, w1, e.b2, w2, step_size, bc2s, e.eps);
@@ -142,90 +147,65 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmEpi &e, int r, int sub, 
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(kSpmmThreads) void spmm_csr_kernel(const SpmmArgs a)
+template <int D, int UNMAX, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmArgs a)
 {
     constexpr int G = D / 4;
-    __shared__ float4 part[kSpmmWaves][G];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    if (a.e.bump && b == 0 && threadIdx.x == 0) {
+    __shared__ float4 part[WAVES][G];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
-    if (b < a.n_long) {
-        const int r = a.perm[b];
-        const int rb = a.rowptr[r], re = a.rowptr[r + 1];
-        int chunk = (re - rb + kSpmmWaves - 1) / kSpmmWaves;
-        chunk = (chunk + 3) & ~3;
-        const int eb = min(re, rb + w * chunk), ee = min(re, eb + chunk);
-        float4 acc = spmm_segment<D>(a.col, a.val, eb, ee, a.x_lo, a.x_hi, a.x_split, lane);
-        if (lane < G) part[w][lane] = acc;
-        __syncthreads();
-        if (w == 0 && lane < G) {
-            float4 t = part[0][lane];
-#pragma unroll
-            for (int k = 1; k < kSpmmWaves; ++k) t = f4_add(t, part[k][lane]);
-            spmm_epilogue<D>(a.e, r, lane, t);
-        }
-    } else {
-        const int idx = a.n_long + (b - a.n_long) * kSpmmWaves + w;
-        if (idx >= a.n_rows) return;
-        const int r = a.perm[idx];
-        float4 acc = spmm_segment<D>(a.col, a.val, a.rowptr[r], a.rowptr[r + 1], a.x_lo, a.x_hi, a.x_split, lane);
-        if (lane < G) spmm_epilogue<D>(a.e, r, lane, acc);
+    const int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
+    const bool lead = ds.w > 0 && lane < G;
+    // epilogue operands do not depend on the gather: fetch them first so their latency hides
+    float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
+    const size_t eoff = (size_t)max(ds.x, 0) * D + (size_t)(lane % G) * 4;
+    if (lead && a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+    if (lead && a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ds.z > ds.y && !(a.dbg & 1)) acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane);
+    if (lane < G) part[w][lane] = acc;
+    __syncthreads();
+    if (lead && !(a.dbg & 2)) {
+        for (int k = 1; k < ds.w; ++k) acc = f4_add(acc, part[w + k][lane]);
+        spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
     }
 }
 
 // Any d (<= 512): one X row per wave step, lanes stride over the row.  Same schedule and
 // epilogue semantics; used for dims without a vector instantiation.
 static constexpr int kGenMaxC = 8;
-static __global__ __launch_bounds__(kSpmmThreads) void spmm_csr_generic_kernel(const SpmmArgs a)
+static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const SpmmArgs a)
 {
-    __shared__ float part[kSpmmWaves][kGenMaxC * 64];
+    __shared__ float part[kSpmmWavesMax][kGenMaxC * 64];
+    const int kSpmmWaves = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.x, d = a.d;
-    if (a.e.bump && b == 0 && threadIdx.x == 0) {
+    const int d = a.d;
+    if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
-    int r, eb, ee;
-    const bool is_long = b < a.n_long;
-    if (is_long) {
-        r = a.perm[b];
-        const int rb = a.rowptr[r], re = a.rowptr[r + 1];
-        const int chunk = (re - rb + kSpmmWaves - 1) / kSpmmWaves;
-        eb = min(re, rb + w * chunk);
-        ee = min(re, eb + chunk);
-    } else {
-        const int idx = a.n_long + (b - a.n_long) * kSpmmWaves + w;
-        if (idx >= a.n_rows) return;
-        r = a.perm[idx];
-        eb = a.rowptr[r];
-        ee = a.rowptr[r + 1];
-    }
+    const int4 ds = a.wave_desc[(size_t)blockIdx.x * kSpmmWaves + w];
+    const int r = ds.x;
     float acc[kGenMaxC];
 #pragma unroll
     for (int k = 0; k < kGenMaxC; ++k) acc[k] = 0.f;
-    for (int e = eb; e < ee; ++e) {
-        const float *x = row2(a.x_lo, a.x_hi, a.x_split, a.col[e], d);
+    for (int e = ds.y; e < ds.z; ++e) {
+        const float *x = a.x + (size_t)a.col[e] * d;
         const float av = a.val[e];
 #pragma unroll
         for (int k = 0; k < kGenMaxC; ++k)
             if (k * 64 + lane < d) acc[k] += av * x[k * 64 + lane];
     }
-    if (is_long) {
 #pragma unroll
-        for (int k = 0; k < kGenMaxC; ++k) part[w][k * 64 + lane] = acc[k];
-        __syncthreads();
-        if (w != 0) return;
+    for (int k = 0; k < kGenMaxC; ++k) part[w][k * 64 + lane] = acc[k];
+    __syncthreads();
+    if (ds.w <= 0) return;
 #pragma unroll
-        for (int k = 0; k < kGenMaxC; ++k) {
-            float t = part[0][k * 64 + lane];
-            for (int ww = 1; ww < kSpmmWaves; ++ww) t += part[ww][k * 64 + lane];
-            acc[k] = t;
-        }
-    }
+    for (int k = 0; k < kGenMaxC; ++k)
+        for (int ww = 1; ww < ds.w; ++ww) acc[k] += part[w + ww][k * 64 + lane];
     const SpmmEpi &e = a.e;
     const float w1 = (float)(1.0 - (double)e.b1), w2 = (float)(1.0 - (double)e.b2);
 #pragma unroll
@@ -233,18 +213,16 @@ static __global__ __launch_bounds__(kSpmmThreads) void spmm_csr_generic_kernel(c
         const int c = k * 64 + lane;
         if (c >= d) continue;
         float v = acc[k];
-        if (e.add_lo) v += row2(e.add_lo, e.add_hi, e.add_split, r, d)[c];
-        if (e.zero1) e.zero1[(size_t)r * d + c] = 0.f;
-        if (e.zero2) e.zero2[(size_t)r * d + c] = 0.f;
-        if (e.y) e.y[(size_t)r * d + c] = v;
-        if (e.sum_out) e.sum_out[(size_t)r * d + c] = (row2(e.sum_lo, e.sum_hi, e.sum_split, r, d)[c] + v) * e.sum_scale;
+        const size_t o = (size_t)r * d + c;
+        if (e.add) v += e.add[o];
+        if (e.zero1) e.zero1[o] = 0.f;
+        if (e.zero2) e.zero2[o] = 0.f;
+        if (e.y) e.y[o] = v;
+        if (e.sum_out) e.sum_out[o] = (e.sum_in[o] + v) * e.sum_scale;
         if (e.adam) {
-            float *pp = row2(e.p_lo, e.p_hi, e.p_split, r, d) + c;
-            float *mp = row2(e.m_lo, e.m_hi, e.p_split, r, d) + c;
-            float *vp = row2(e.v_lo, e.v_hi, e.p_split, r, d) + c;
-            float p = *pp, m = *mp, vv = *vp;
+            float p = e.p[o], m = e.m[o], vv = e.v[o];
             adam_elem(p, m, vv, v, w1, e.b2, w2, e.coef[0], e.coef[1], e.eps);
-            *pp = p; *mp = m; *vp = vv;
+            e.p[o] = p; e.m[o] = m; e.v[o] = vv;
         }
     }
 }
@@ -253,13 +231,24 @@ static __global__ __launch_bounds__(kSpmmThreads) void spmm_csr_generic_kernel(c
 inline hipError_t spmm_launch(const SpmmArgs &a, hipStream_t s)
 {
     if (a.n_rows <= 0) return hipSuccess;
-    const dim3 grid(spmm_grid(a.n_rows, a.n_long)), block(kSpmmThreads);
+    const int W = spmm_waves();
+    const dim3 grid(a.n_blocks), block(W * 64);
+    static const int variant = getenv("RK_SPMM_VARIANT") ? atoi(getenv("RK_SPMM_VARIANT")) : 0;
+    static const int dbg = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
+    const_cast<SpmmArgs &>(a).dbg = dbg;
+#define RK_SPMM_CASE(D, UN, WV, MW) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW>), grid, block, 0, s, a)
+#define RK_SPMM_D(D)                                                                         \
+    if (W == 16) { if (variant == 1) RK_SPMM_CASE(D, 16, 16, 4); else RK_SPMM_CASE(D, 8, 16, 8); } \
+    else if (W == 8) { if (variant == 1) RK_SPMM_CASE(D, 8, 8, 8); else if (variant == 2) RK_SPMM_CASE(D, 16, 8, 4); else RK_SPMM_CASE(D, 8, 8, 6); } \
+    else { if (variant == 1) RK_SPMM_CASE(D, 8, 4, 8); else RK_SPMM_CASE(D, 8, 4, 6); }
     switch (a.d) {
-        case 32: hipLaunchKernelGGL(spmm_csr_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(spmm_csr_kernel<64>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(spmm_csr_kernel<128>, grid, block, 0, s, a); break;
-        case 256: hipLaunchKernelGGL(spmm_csr_kernel<256>, grid, block, 0, s, a); break;
+        case 32: RK_SPMM_D(32) break;
+        case 64: RK_SPMM_D(64) break;
+        case 128: RK_SPMM_D(128) break;
+        case 256: RK_SPMM_D(256) break;
         default: hipLaunchKernelGGL(spmm_csr_generic_kernel, grid, block, 0, s, a); break;
     }
+#undef RK_SPMM_D
+#undef RK_SPMM_CASE
     return hipGetLastError();
 }

@@ -8,11 +8,11 @@ from . import _lib
 
 class CsrGraph:
     """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the
-    degree-descending row schedule rk_spmm_csr uses.  Immutable after construction."""
+    per-wave work schedule rk_spmm_csr uses.  Immutable after construction."""
 
-    def __init__(self, n_rows, rowptr, col, val, row_perm, n_long_rows):
+    def __init__(self, n_rows, rowptr, col, val, wave_desc, n_blocks):
         self.n_rows, self.rowptr, self.col, self.val = n_rows, rowptr, col, val
-        self.row_perm, self.n_long_rows = row_perm, n_long_rows
+        self.wave_desc, self.n_blocks = wave_desc, n_blocks
 
     @property
     def nnz(self):
@@ -29,15 +29,19 @@ class CsrGraph:
         if self.rowptr.device == device:
             return self
         return CsrGraph(self.n_rows, self.rowptr.to(device), self.col.to(device), self.val.to(device),
-                        self.row_perm.to(device), self.n_long_rows)
+                        self.wave_desc.to(device), self.n_blocks)
 
     @staticmethod
     def _schedule(n_rows, rowptr):
-        perm = torch.empty(n_rows, device=rowptr.device, dtype=torch.int32)
-        n_long = C.c_int32(0)
-        _lib.check(_lib.lib().rk_csr_schedule(n_rows, _lib.ptr(rowptr), _lib.ptr(perm), C.byref(n_long),
-                                              _lib.stream_ptr()), "rk_csr_schedule")
-        return perm, int(n_long.value)
+        sched, n_blocks = C.c_void_p(), C.c_int32(0)
+        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), _lib.stream_ptr(), C.byref(sched),
+                                                    C.byref(n_blocks)), "rk_csr_schedule_build")
+        try:
+            desc = torch.empty(int(n_blocks.value) * 16 * 4, device=rowptr.device, dtype=torch.int32)  # >= waves*4 per block
+            _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
+        finally:
+            _lib.lib().rk_csr_schedule_destroy(sched)
+        return desc, int(n_blocks.value)
 
     @classmethod
     def from_torch_coo(cls, coo, device):
@@ -55,8 +59,8 @@ class CsrGraph:
         val = torch.empty(max(nnz, 1), device=device, dtype=torch.float32)[:nnz]
         _lib.check(_lib.lib().rk_coo_to_csr(n, nnz, _lib.ptr(row), _lib.ptr(col64), _lib.ptr(v), _lib.ptr(rowptr),
                                             _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()), "rk_coo_to_csr")
-        perm, n_long = cls._schedule(n, rowptr)
-        return cls(n, rowptr, col, val, perm, n_long)
+        desc, n_blocks = cls._schedule(n, rowptr)
+        return cls(n, rowptr, col, val, desc, n_blocks)
 
     @classmethod
     def from_user_item_csr(cls, n_users, n_items, r_ptr, r_idx, device):
@@ -74,8 +78,8 @@ class CsrGraph:
         _lib.check(_lib.lib().rk_build_norm_adj(n_users, n_items, _lib.ptr(r_ptr), _lib.ptr(r_idx), _lib.ptr(rowptr),
                                                 _lib.ptr(col), _lib.ptr(val), _lib.ptr(tmp), _lib.stream_ptr()),
                    "rk_build_norm_adj")
-        perm, n_long = cls._schedule(N, rowptr)
-        return cls(N, rowptr, col, val, perm, n_long)
+        desc, n_blocks = cls._schedule(N, rowptr)
+        return cls(N, rowptr, col, val, desc, n_blocks)
 
     def to_torch_coo(self):
         """The graph in the reference's own format (a coalesced torch sparse COO tensor)."""
@@ -89,6 +93,6 @@ class CsrGraph:
         x = x.contiguous()
         y = torch.empty_like(x)
         _lib.check(_lib.lib().rk_spmm_csr(self.n_rows, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val),
-                                          _lib.ptr(self.row_perm), self.n_long_rows, x.shape[1], _lib.ptr(x), None, 0,
+                                          _lib.ptr(self.wave_desc), self.n_blocks, x.shape[1], _lib.ptr(x),
                                           _lib.ptr(add), _lib.ptr(y), _lib.stream_ptr()), "rk_spmm_csr")
         return y

@@ -66,10 +66,34 @@ class LightGCN(BaseVictim):
             st["step"] = torch.zeros((), dtype=torch.float32)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        for k in ("exp_avg", "exp_avg_sq"):
-            if st[k].device != p.device:
-                st[k] = st[k].to(p.device)
         return st
+
+    def _fuse_tables(self):
+        """The kernels address E0 = [users; items] (and the Adam moments) through ONE base
+        pointer, i.e. torch.cat (lightgcn.py:88) costs nothing.  Re-home the two Parameters'
+        storage (and their moments) into one [N,d] allocation whenever they are not adjacent
+        (fresh model, after .to(), after load_state_dict into new tensors).  Values and
+        Parameter identities are preserved, so optimizers/state_dicts keep working."""
+        wu, wi = self.embedding_user.weight, self.embedding_item.weight
+        su, si = self._adam_state(wu), self._adam_state(wi)
+        U, d = self.num_users, self.latent_dim
+
+        def adjacent(a, b):
+            return (a.device == b.device and a.is_contiguous() and b.is_contiguous()
+                    and b.data_ptr() == a.data_ptr() + U * d * 4)
+
+        def fuse(a, b):
+            flat = torch.empty(self.num_users + self.num_items, d, device=wu.device, dtype=torch.float32)
+            flat[:U].copy_(a)
+            flat[U:].copy_(b)
+            return flat[:U], flat[U:]
+
+        if not adjacent(wu.data, wi.data):
+            wu.data, wi.data = fuse(wu.data, wi.data)
+        for k in ("exp_avg", "exp_avg_sq"):
+            if not adjacent(su[k], si[k]) or su[k].device != wu.device:
+                su[k], si[k] = fuse(su[k].to(wu.device), si[k].to(wu.device))
+        return wu, wi, su, si
 
     def _csr(self, device):
         if not isinstance(self.Graph, CsrGraph):
@@ -78,11 +102,10 @@ class LightGCN(BaseVictim):
 
     def _ensure_handle(self, want_grad=False):
         _lib.require_gpu()
-        wu, wi = self.embedding_user.weight, self.embedding_item.weight
-        dev = wu.device
+        dev = self.embedding_user.weight.device
         if dev.type != "cuda":
             raise _lib.HipCallError("LightGCN parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
-        su, si = self._adam_state(wu), self._adam_state(wi)
+        wu, wi, su, si = self._fuse_tables()
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad))
         if self._handle is not None and self._handle_key == key:
             return self._handle
@@ -99,8 +122,8 @@ class LightGCN(BaseVictim):
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
             lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
             eps=float(grp.get("eps", 1e-8)),
-            rowptr=_lib.ptr(g.rowptr), col=_lib.ptr(g.col), val=_lib.ptr(g.val), row_perm=_lib.ptr(g.row_perm),
-            n_long_rows=g.n_long_rows,
+            rowptr=_lib.ptr(g.rowptr), col=_lib.ptr(g.col), val=_lib.ptr(g.val), wave_desc=_lib.ptr(g.wave_desc),
+            n_blocks=g.n_blocks,
             user_emb=_lib.ptr(wu.data), item_emb=_lib.ptr(wi.data),
             m_user=_lib.ptr(su["exp_avg"]), v_user=_lib.ptr(su["exp_avg_sq"]),
             m_item=_lib.ptr(si["exp_avg"]), v_item=_lib.ptr(si["exp_avg_sq"]),
