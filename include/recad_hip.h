@@ -145,6 +145,44 @@ int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, float *user
                       int32_t batch, int32_t adam_t0, float lr, float beta1, float beta2, float eps,
                       float *loss_partials, int32_t apply_update, void *stream);
 
+/* Pass 2 of rk_score_topk on a ready score matrix scores[nb, n_items] (modified in place:
+ * seen items are overwritten with -inf).  Used for victims whose scores are not a dot product. */
+int rk_topk_rows(float *scores, int32_t nb, int32_t n_items, const int32_t *user_ids, const int32_t *seen_ptr,
+                 const int32_t *seen_idx, int32_t K, int32_t *top_ids, float *top_scores,
+                 const int32_t *targets, int32_t n_targets, float *target_score, int32_t *target_rank,
+                 void *stream);
+
+/* ---------------------------------------------------------------- NCF -------------- */
+#define RK_NCF_MAX_LAYERS 8
+#define RK_NCF_MAX_TENSORS 24
+/* NeuMF-end (recad/model/victim/ncf.py:9-58).  E = factor * 2^(n_layers-1) is the MLP embedding
+ * width; tower layer l is Linear(in_l -> in_l/2) + ReLU with in_l = factor * 2^(n_layers-l)
+ * (ncf.py:41-47); W[l] is nn.Linear's [out, in] row-major weight.  Tensor order of grad/m/v:
+ * ug, ig, um, im, W[0..L-1], b[0..L-1], pw, pb. */
+typedef struct rk_ncf_desc {
+    int32_t n_users, n_items, factor, n_layers;
+    float lr, beta1, beta2, eps;
+    float *ug, *ig, *um, *im;                  /* embed_{user,item}_{GMF,MLP}.weight */
+    float *W[RK_NCF_MAX_LAYERS], *b[RK_NCF_MAX_LAYERS];
+    float *pw, *pb;                            /* predict_layer.weight [2*factor] (GMF part first), .bias [1] */
+    float *grad[RK_NCF_MAX_TENSORS], *m[RK_NCF_MAX_TENSORS], *v[RK_NCF_MAX_TENSORS];
+    float *acts, *dacts;                       /* each float[max_batch * sum_{l=0..L} in_l] */
+    float *d0;                                 /* float[max_batch] */
+    int32_t max_batch, reserved;
+} rk_ncf_desc;
+
+/* NCF.forward (ncf.py:112-131) for n pairs -> out[n].  Pairs are (users[b], items[b]), or -- when
+ * user_ids != NULL -- the full catalog of each listed user: pair q = (user_ids[q / n_items_catalog],
+ * q % n_items_catalog), which is how the evaluation fills a [users, items] score matrix. */
+int rk_ncf_forward(const rk_ncf_desc *desc, const int64_t *users, const int64_t *items,
+                   const int32_t *user_ids, int32_t n_items_catalog, int64_t n, float *out, void *stream);
+
+/* One epoch of NCF.train_step (ncf.py:133-153): forward, BCE-with-logits, backward through the
+ * tower (fp32 MFMA GEMMs), embedding scatter-add, dense Adam on every tensor. */
+int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, const int64_t *items,
+                       const int64_t *labels, int64_t n, int32_t batch, int32_t adam_t0,
+                       float *loss_partials, int32_t apply_update, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,20 @@ class LightGCNDesc(C.Structure):
     ]
 
 
+class NCFDesc(C.Structure):
+    """rk_ncf_desc (include/recad_hip.h)."""
+
+    _fields_ = [
+        ("n_users", C.c_int32), ("n_items", C.c_int32), ("factor", C.c_int32), ("n_layers", C.c_int32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("ug", C.c_void_p), ("ig", C.c_void_p), ("um", C.c_void_p), ("im", C.c_void_p),
+        ("W", C.c_void_p * 8), ("b", C.c_void_p * 8), ("pw", C.c_void_p), ("pb", C.c_void_p),
+        ("grad", C.c_void_p * 24), ("m", C.c_void_p * 24), ("v", C.c_void_p * 24),
+        ("acts", C.c_void_p), ("dacts", C.c_void_p), ("d0", C.c_void_p),
+        ("max_batch", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 _lib = None
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
@@ -61,6 +75,9 @@ _SIGNATURES = {
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rk_topk_rows": [_P, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P],
+    "rk_ncf_forward": [C.POINTER(NCFDesc), _P, _P, _P, _I32, _I64, _P, _P],
+    "rk_ncf_train_epoch": [C.POINTER(NCFDesc), _P, _P, _P, _I64, _I32, _I32, _P, _I32, _P],
     "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,
                           _F, _P, _I32, _P],
 }

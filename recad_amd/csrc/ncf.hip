@@ -1,0 +1,410 @@
+// NCF (NeuMF-end) victim hot path on gfx950 (recad/model/victim/ncf.py:112-153): embedding
+// gathers, the MLP tower as exact-fp32 MFMA GEMMs (forward, dX and dW), predict layer +
+// BCE-with-logits, embedding-gradient scatter-add and one multi-tensor dense Adam launch.
+#include <algorithm>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- strided fp32 MFMA GEMM
+// C[m,n] = sum_k A(m,k) * B(n,k)  (+ bias[n]) (relu) (masked by mask[m,n] > 0)
+// A(m,k) = A[m*a_rs + k*a_cs], B(n,k) = B[n*b_rs + k*b_cs]; k-ordered fmaf chain (MFMA f32).
+struct GemmArgs {
+    int M, N, K;
+    const float *A; long long a_rs, a_cs;
+    const float *B; long long b_rs, b_cs;
+    float *C; int ldc;
+    const float *bias;
+    const float *mask; int ldmask;
+    int relu;
+};
+
+static constexpr int kGT = 128, kGK = 32, kGLd = kGK + 1;
+
+__device__ __forceinline__ void stage_strided(float (*dst)[kGLd], const float *__restrict__ src, int n_rows, int n_k, int r0,
+                                              int k0, long long rs, long long cs)
+{
+    if (cs == 1) {  // k contiguous: consecutive threads walk k
+        for (int idx = threadIdx.x; idx < kGT * kGK; idx += 256) {
+            const int r = idx / kGK, c = idx % kGK;
+            const int gr = r0 + r, gc = k0 + c;
+            dst[r][c] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + gc] : 0.f;
+        }
+    } else {  // rows contiguous: consecutive threads walk rows
+        for (int idx = threadIdx.x; idx < kGT * kGK; idx += 256) {
+            const int c = idx / kGT, r = idx % kGT;
+            const int gr = r0 + r, gc = k0 + c;
+            dst[r][c] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + (long long)gc * cs] : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g)
+{
+    __shared__ float As[kGT][kGLd];
+    __shared__ float Bs[kGT][kGLd];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int k0 = 0; k0 < g.K; k0 += kGK) {
+        stage_strided(As, g.A, g.M, g.K, m0, k0, g.a_rs, g.a_cs);
+        stage_strided(Bs, g.B, g.N, g.K, n0, k0, g.b_rs, g.b_cs);
+        __syncthreads();
+        const int kc = min(kGK, g.K - k0);
+        for (int kk = 0; kk < kc; kk += 2) {
+            const float a0 = As[wr * 64 + lr][kk + lk], a1 = As[wr * 64 + 32 + lr][kk + lk];
+            const float b0 = Bs[wc * 64 + lr][kk + lk], b1 = Bs[wc * 64 + 32 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + j * 32 + lr;
+                if (m < g.M && n < g.N) {
+                    float s = acc[i][j][r];
+                    if (g.bias) s += g.bias[n];
+                    if (g.relu) s = s > 0.f ? s : 0.f;
+                    if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                    g.C[(size_t)m * g.ldc + n] = s;
+                }
+            }
+}
+
+static int gemm(hipStream_t s, int M, int N, int K, const float *A, long long a_rs, long long a_cs, const float *B,
+                long long b_rs, long long b_cs, float *C, int ldc, const float *bias, int relu, const float *mask, int ldmask)
+{
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
+    g.C = C; g.ldc = ldc; g.bias = bias; g.relu = relu; g.mask = mask; g.ldmask = ldmask;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + kGT - 1) / kGT, (M + kGT - 1) / kGT), dim3(256), 0, s, g);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------- element kernels
+// pair b of this chunk: explicit (users[b], items[b]) or full-catalog (user_ids[b / I], b % I)
+struct PairSrc {
+    const int64_t *users, *items;
+    const int32_t *user_ids;
+    int n_items;
+    long long off;
+};
+__device__ __forceinline__ void pair_at(const PairSrc &p, long long b, long long &u, long long &i)
+{
+    if (p.user_ids) { const long long q = p.off + b; u = p.user_ids[q / p.n_items]; i = q % p.n_items; }
+    else { u = p.users[p.off + b]; i = p.items[p.off + b]; }
+}
+
+// X0[b] = [um[u] | im[i]]   (ncf.py:119-121)
+__global__ void ncf_gather_kernel(PairSrc p, int nb, int E, const float *__restrict__ um, const float *__restrict__ im,
+                                  float *__restrict__ x0)
+{
+    const int lane = threadIdx.x & 63;
+    for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += (long long)gridDim.x * (blockDim.x >> 6)) {
+        long long u, i;
+        pair_at(p, b, u, i);
+        const float *su = um + (size_t)u * E, *si = im + (size_t)i * E;
+        float *d = x0 + (size_t)b * 2 * E;
+        for (int k = lane * 4; k < E; k += 256) {
+            *reinterpret_cast<float4 *>(d + k) = *reinterpret_cast<const float4 *>(su + k);
+            *reinterpret_cast<float4 *>(d + E + k) = *reinterpret_cast<const float4 *>(si + k);
+        }
+    }
+}
+
+// logit = pw . [ug*ig | xL] + pb (ncf.py:114-116,123-131); optional BCE loss + d0 = (sigmoid - y)/nb
+__global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug,
+                                                          const float *__restrict__ ig, const float *__restrict__ xl,
+                                                          const float *__restrict__ pw, const float *__restrict__ pb,
+                                                          float *__restrict__ logits, const int64_t *labels, float *d0,
+                                                          float *loss_partials)
+{
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float invB = 1.f / (float)nb;
+    float lsum = 0.f;
+    for (int b = blockIdx.x * 4 + w; b < nb; b += gridDim.x * 4) {
+        long long u, i;
+        pair_at(p, b, u, i);
+        const float *pu = ug + (size_t)u * f, *pi = ig + (size_t)i * f, *px = xl + (size_t)b * f;
+        float s = 0.f;
+        for (int k = lane; k < f; k += 64) s += pw[k] * (pu[k] * pi[k]) + pw[f + k] * px[k];
+        s = wave_sum(s) + pb[0];
+        if (lane == 0) {
+            if (logits) logits[p.off + b] = s;
+            if (labels) {
+                const float y = (float)labels[p.off + b];
+                lsum += fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));
+                d0[b] = (1.f / (1.f + expf(-s)) - y) * invB;
+            }
+        }
+    }
+    if (loss_partials) {
+        if (lane == 0) red[w] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * invB;
+    }
+}
+
+// backward of the predict layer: dXL[b,k] = d0[b]*pw[f+k]; GMF table grads by atomics
+__global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug, const float *__restrict__ ig,
+                                       const float *__restrict__ pw, const float *__restrict__ d0, float *__restrict__ dxl,
+                                       float *g_ug, float *g_ig)
+{
+    const int lane = threadIdx.x & 63;
+    for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += (long long)gridDim.x * (blockDim.x >> 6)) {
+        long long u, i;
+        pair_at(p, b, u, i);
+        const float dd = d0[b];
+        for (int k = lane; k < f; k += 64) {
+            dxl[(size_t)b * f + k] = dd * pw[f + k];
+            unsafeAtomicAdd(g_ug + (size_t)u * f + k, dd * pw[k] * ig[(size_t)i * f + k]);
+            unsafeAtomicAdd(g_ig + (size_t)i * f + k, dd * pw[k] * ug[(size_t)u * f + k]);
+        }
+    }
+}
+
+// gpw[k] = sum_b d0[b] * z[b,k], z = [ug*ig | xL]; gpb = sum_b d0[b].  One thread per k: fixed order.
+__global__ void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug, const float *__restrict__ ig,
+                                         const float *__restrict__ xl, const float *__restrict__ d0, float *gpw, float *gpb)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 2 * f) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        float z;
+        if (k == 2 * f) z = 1.f;
+        else if (k < f) { long long u, i; pair_at(p, b, u, i); z = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
+        else z = xl[(size_t)b * f + (k - f)];
+        s += d0[b] * z;
+    }
+    if (k == 2 * f) gpb[0] += s; else gpw[k] += s;
+}
+
+// db[n] += sum_m dY[m,n]  (one thread per column, fixed order)
+__global__ void colsum_kernel(int M, int N, const float *__restrict__ dY, float *db)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n];
+    db[n] += s;
+}
+
+// g_um[u] += dX0[b, :E], g_im[i] += dX0[b, E:]
+__global__ void ncf_scatter_kernel(PairSrc p, int nb, int E, const float *__restrict__ dx0, float *g_um, float *g_im)
+{
+    const int lane = threadIdx.x & 63;
+    for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += (long long)gridDim.x * (blockDim.x >> 6)) {
+        long long u, i;
+        pair_at(p, b, u, i);
+        const float *s = dx0 + (size_t)b * 2 * E;
+        for (int k = lane; k < E; k += 64) {
+            unsafeAtomicAdd(g_um + (size_t)u * E + k, s[k]);
+            unsafeAtomicAdd(g_im + (size_t)i * E + k, s[E + k]);
+        }
+    }
+}
+
+__global__ void relu_mask_kernel(long long n, float *dy, const float *y)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+// dense Adam over every tensor in one launch; gradients are re-zeroed after use
+struct MultiAdam {
+    int n_tensors;
+    float *p[RK_NCF_MAX_TENSORS], *g[RK_NCF_MAX_TENSORS], *m[RK_NCF_MAX_TENSORS], *v[RK_NCF_MAX_TENSORS];
+    long long n[RK_NCF_MAX_TENSORS];
+    float step_size, bc2s, b1, b2, eps;
+};
+__global__ void multi_adam_kernel(const MultiAdam a)
+{
+    const int t = blockIdx.y;
+    const float w1 = (float)(1.0 - (double)a.b1), w2 = (float)(1.0 - (double)a.b2);
+    float *p = a.p[t], *g = a.g[t], *m = a.m[t], *v = a.v[t];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[t]; i += (long long)gridDim.x * blockDim.x) {
+        const float gg = g[i];
+        g[i] = 0.f;
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, mm, vv, gg, w1, a.b2, w2, a.step_size, a.bc2s, a.eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// ---------------------------------------------------------------- host orchestration
+static int check_ncf(const rk_ncf_desc &d)
+{
+    if (d.n_users <= 0 || d.n_items <= 0 || d.factor <= 0 || d.n_layers < 1 || d.n_layers > RK_NCF_MAX_LAYERS)
+        RK_FAIL(RK_EINVAL, "ncf: bad sizes");
+    if ((d.factor << (d.n_layers - 1)) % 4) RK_FAIL(RK_EINVAL, "ncf: factor*2^(L-1) must be a multiple of 4");
+    if (!d.ug || !d.ig || !d.um || !d.im || !d.pw || !d.pb || !d.acts || !d.dacts || !d.d0 || d.max_batch <= 0)
+        RK_FAIL(RK_EINVAL, "ncf: null pointer");
+    for (int l = 0; l < d.n_layers; ++l)
+        if (!d.W[l] || !d.b[l]) RK_FAIL(RK_EINVAL, "ncf: tower pointer missing");
+    return RK_OK;
+}
+
+static inline int in_of(const rk_ncf_desc &d, int l) { return d.factor << (d.n_layers - l); }  // input width of layer l
+static size_t act_off(const rk_ncf_desc &d, int l, int nbmax)
+{
+    size_t o = 0;
+    for (int k = 0; k < l; ++k) o += (size_t)in_of(d, k) * nbmax;
+    return o;
+}
+
+// forward for one chunk of nb pairs; acts[l] = input of layer l, acts[L] = tower output [nb, f]
+static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, hipStream_t s)
+{
+    const int L = d.n_layers, E = d.factor << (L - 1);
+    float *x0 = d.acts;
+    hipLaunchKernelGGL(ncf_gather_kernel, dim3(std::min(2048, (nb + 3) / 4)), dim3(256), 0, s, p, nb, E, d.um, d.im, x0);
+    RK_CHECK_LAUNCH();
+    for (int l = 0; l < L; ++l) {
+        const int in = in_of(d, l), out = in / 2;
+        int rc = gemm(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
+                      d.acts + act_off(d, l + 1, d.max_batch), out, d.b[l], 1, nullptr, 0);
+        if (rc) return rc;
+    }
+    return RK_OK;
+}
+
+RK_EXPORT int rk_ncf_forward(const rk_ncf_desc *desc, const int64_t *users, const int64_t *items,
+                             const int32_t *user_ids, int32_t n_items_catalog, int64_t n, float *out, void *stream)
+{
+    if (!desc || !out || n < 0) RK_FAIL(RK_EINVAL, "rk_ncf_forward: bad arguments");
+    if (!user_ids && (!users || !items)) RK_FAIL(RK_EINVAL, "rk_ncf_forward: give (users, items) or user_ids");
+    int rc = check_ncf(*desc);
+    if (rc) return rc;
+    const rk_ncf_desc &d = *desc;
+    hipStream_t s = (hipStream_t)stream;
+    for (long long off = 0; off < n; off += d.max_batch) {
+        const int nb = (int)std::min<long long>(d.max_batch, n - off);
+        PairSrc p{users, items, user_ids, n_items_catalog, off};
+        rc = ncf_forward_chunk(d, p, nb, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, s, p, nb, d.factor, d.ug, d.ig,
+                           d.acts + act_off(d, d.n_layers, d.max_batch), d.pw, d.pb, out, (const int64_t *)nullptr,
+                           (float *)nullptr, (float *)nullptr);
+        RK_CHECK_LAUNCH();
+    }
+    return RK_OK;
+}
+
+RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, const int64_t *items,
+                                 const int64_t *labels, int64_t n, int32_t batch, int32_t adam_t0,
+                                 float *loss_partials, int32_t apply_update, void *stream)
+{
+    if (!desc || !users || !items || !labels || !loss_partials || n <= 0 || batch <= 0)
+        RK_FAIL(RK_EINVAL, "rk_ncf_train_epoch: bad arguments");
+    int rc = check_ncf(*desc);
+    if (rc) return rc;
+    const rk_ncf_desc &d = *desc;
+    if (batch > d.max_batch) RK_FAIL(RK_EINVAL, "rk_ncf_train_epoch: batch %d > desc.max_batch %d", batch, d.max_batch);
+    const int L = d.n_layers, f = d.factor, E = f << (L - 1), T = 4 + 2 * L + 2;
+    for (int t = 0; t < T; ++t)
+        if (!d.grad[t] || !d.m[t] || !d.v[t]) RK_FAIL(RK_EINVAL, "ncf: grad/moment pointer %d missing", t);
+    hipStream_t s = (hipStream_t)stream;
+    // tensor order: ug, ig, um, im, W0.., b0.., pw, pb
+    float *P[RK_NCF_MAX_TENSORS];
+    long long NN[RK_NCF_MAX_TENSORS];
+    P[0] = d.ug; NN[0] = (long long)d.n_users * f;
+    P[1] = d.ig; NN[1] = (long long)d.n_items * f;
+    P[2] = d.um; NN[2] = (long long)d.n_users * E;
+    P[3] = d.im; NN[3] = (long long)d.n_items * E;
+    for (int l = 0; l < L; ++l) {
+        const int in = in_of(d, l);
+        P[4 + l] = d.W[l]; NN[4 + l] = (long long)in * (in / 2);
+        P[4 + L + l] = d.b[l]; NN[4 + L + l] = in / 2;
+    }
+    P[4 + 2 * L] = d.pw; NN[4 + 2 * L] = 2 * f;
+    P[5 + 2 * L] = d.pb; NN[5 + 2 * L] = 1;
+    for (int t = 0; t < T; ++t) RK_HIP(hipMemsetAsync(d.grad[t], 0, sizeof(float) * (size_t)NN[t], s));
+    const int n_steps = (int)((n + batch - 1) / batch);
+    RK_HIP(hipMemsetAsync(loss_partials, 0, sizeof(float) * (size_t)n_steps * RK_LOSS_PARTIALS, s));
+    const int wgrid = [](int nb) { return std::min(2048, (nb + 3) / 4); }(batch);
+    for (int step = 0; step < n_steps; ++step) {
+        const long long off = (long long)step * batch;
+        const int nb = (int)std::min<long long>(batch, n - off);
+        PairSrc p{users, items, nullptr, 0, off};
+        rc = ncf_forward_chunk(d, p, nb, s);
+        if (rc) return rc;
+        float *xl = d.acts + act_off(d, L, d.max_batch), *dxl = d.dacts + act_off(d, L, d.max_batch);
+        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(RK_LOSS_PARTIALS, (nb + 3) / 4)), dim3(256), 0, s, p, nb, f, d.ug, d.ig,
+                           xl, d.pw, d.pb, (float *)nullptr, labels, d.d0, loss_partials + (size_t)step * RK_LOSS_PARTIALS);
+        RK_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
+        RK_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64), dim3(64), 0, s, p, nb, f, d.ug, d.ig, xl, d.d0,
+                           d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
+        RK_CHECK_LAUNCH();
+        // tower backward.  dY of the top layer is masked by its own ReLU here; for the layers below
+        // the mask (x > 0, x = the previous layer's ReLU output) is applied in the dX GEMM's epilogue.
+        for (int l = L - 1; l >= 0; --l) {
+            const int in = in_of(d, l), out = in / 2;
+            float *x = d.acts + act_off(d, l, d.max_batch), *y = d.acts + act_off(d, l + 1, d.max_batch);
+            float *dy = d.dacts + act_off(d, l + 1, d.max_batch), *dx = d.dacts + act_off(d, l, d.max_batch);
+            if (l == L - 1) {
+                hipLaunchKernelGGL(relu_mask_kernel, dim3(std::min(1024, (nb * out + 255) / 256)), dim3(256), 0, s,
+                                   (long long)nb * out, dy, y);
+                RK_CHECK_LAUNCH();
+            }
+            // dW[out,in] += dY^T X : A(m=o,k=b) = dy[b*out+o], B(n=i,k=b) = x[b*in+i]
+            rc = gemm(s, out, in, nb, dy, 1, out, x, 1, in, d.grad[4 + l], in, nullptr, 0, nullptr, 0);
+            if (rc) return rc;
+            hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(64), 0, s, nb, out, dy, d.grad[4 + L + l]);
+            RK_CHECK_LAUNCH();
+            // dX[nb,in] = dY W, masked by (x > 0) for l >= 1 (x is the previous layer's ReLU output)
+            rc = gemm(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, in, nullptr, 0, l >= 1 ? x : nullptr, in);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(ncf_scatter_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, E, d.dacts, d.grad[2], d.grad[3]);
+        RK_CHECK_LAUNCH();
+        if (!apply_update) break;
+        const AdamCoef c = adam_coef(adam_t0 + step + 1, d.lr, d.beta1, d.beta2);
+        MultiAdam a;
+        a.n_tensors = T;
+        long long maxn = 0;
+        for (int t = 0; t < T; ++t) { a.p[t] = P[t]; a.g[t] = d.grad[t]; a.m[t] = d.m[t]; a.v[t] = d.v[t]; a.n[t] = NN[t]; maxn = std::max(maxn, NN[t]); }
+        a.step_size = c.step_size; a.bc2s = c.bc2s; a.b1 = d.beta1; a.b2 = d.beta2; a.eps = d.eps;
+        hipLaunchKernelGGL(multi_adam_kernel, dim3((int)std::min<long long>((maxn + 255) / 256, 1024), T), dim3(256), 0, s, a);
+        RK_CHECK_LAUNCH();
+    }
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------- top-K over a ready score matrix
+extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *user_ids, const int *seen_ptr,
+                                 const int *seen_idx, int K, int *top_ids, float *top_scores, const int *targets,
+                                 int n_targets, float *target_score, int *target_rank, hipStream_t s);
+
+RK_EXPORT int rk_topk_rows(float *scores, int32_t nb, int32_t n_items, const int32_t *user_ids, const int32_t *seen_ptr,
+                           const int32_t *seen_idx, int32_t K, int32_t *top_ids, float *top_scores,
+                           const int32_t *targets, int32_t n_targets, float *target_score, int32_t *target_rank,
+                           void *stream)
+{
+    if (nb <= 0) return RK_OK;
+    if (!scores || n_items <= 0 || !user_ids || !seen_ptr || !seen_idx || !top_ids || !top_scores)
+        RK_FAIL(RK_EINVAL, "rk_topk_rows: bad arguments");
+    return rk_topk_rows_impl(scores, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
+                             target_score, target_rank, (hipStream_t)stream);
+}

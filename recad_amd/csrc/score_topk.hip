@@ -203,6 +203,19 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ scor
     }
 }
 
+extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *user_ids, const int *seen_ptr,
+                                 const int *seen_idx, int K, int *top_ids, float *top_scores, const int *targets,
+                                 int n_targets, float *target_score, int *target_rank, hipStream_t s)
+{
+    if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
+    if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
+        RK_FAIL(RK_EINVAL, "top-K: bad targets");
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(256), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K, top_ids,
+                       top_scores, targets, n_targets, target_score, target_rank);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
 RK_EXPORT int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const int32_t *user_ids, const float *itab,
                             int32_t n_items, const float *ubias_rows, const float *ibias, float mean,
                             const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
@@ -212,16 +225,11 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const i
     if (nb <= 0) return RK_OK;
     if (dim <= 0 || n_items <= 0 || !urows || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
         RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
-    if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "rk_score_topk: K must be in [1,%d]", kMaxK);
-    if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
-        RK_FAIL(RK_EINVAL, "rk_score_topk: bad targets");
     if ((ubias_rows == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((n_items + kTile - 1) / kTile, (nb + kTile - 1) / kTile);
     hipLaunchKernelGGL(score_gemm_kernel, grid, dim3(256), 0, s, dim, urows, nb, itab, n_items, ubias_rows, ibias, mean, scratch);
     RK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(256), 0, s, scratch, n_items, user_ids, seen_ptr, seen_idx, K, top_ids,
-                       top_scores, targets, n_targets, target_score, target_rank);
-    RK_CHECK_LAUNCH();
-    return RK_OK;
+    return rk_topk_rows_impl(scratch, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
+                             target_score, target_rank, s);
 }

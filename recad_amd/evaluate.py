@@ -17,10 +17,15 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     Returns dict of host numpy arrays: top_ids[n,K], top_scores[n,K], target_score[n,T], target_rank[n,T].
     """
     _lib.require_gpu()
-    utab, itab, ubias, ibias, mean = victim.scoring_tables()
-    dev = itab.device
-    itab = itab.contiguous()
-    n_items, d = itab.shape
+    dot = hasattr(victim, "scoring_tables")
+    if dot:
+        utab, itab, ubias, ibias, mean = victim.scoring_tables()
+        dev = itab.device
+        itab = itab.contiguous()
+        n_items, d = itab.shape
+    else:  # score_matrix(user_ids, out) victims (NCF): scores are not a dot product
+        dev = next(victim.parameters()).device
+        n_items = victim.num_items
     user_ids_t = torch.as_tensor(np.asarray(user_ids), dtype=torch.int32, device=dev).contiguous()
     seen_ptr_t = torch.as_tensor(np.asarray(seen_ptr), dtype=torch.int32, device=dev).contiguous()
     seen_idx_t = torch.as_tensor(np.asarray(seen_idx), dtype=torch.int32, device=dev).contiguous()
@@ -37,6 +42,13 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         ids = user_ids_t[s:e]
+        if not dot:
+            victim.score_matrix(ids, scratch[: (e - s) * n_items])
+            _lib.check(_lib.lib().rk_topk_rows(
+                _lib.ptr(scratch), e - s, n_items, _lib.ptr(ids), _lib.ptr(seen_ptr_t), _lib.ptr(seen_idx_t), K,
+                _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]), _lib.ptr(targets_t), T, _lib.ptr(tscore[s:e]),
+                _lib.ptr(trank[s:e]), _lib.stream_ptr()), "rk_topk_rows")
+            continue
         urows = utab.index_select(0, ids.long()).contiguous()
         ub_rows = ubias.index_select(0, ids.long()).contiguous() if ubias is not None else None
         _lib.check(_lib.lib().rk_score_topk(

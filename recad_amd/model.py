@@ -2,7 +2,7 @@
 for the victims this build implements."""
 from . import victim
 
-factories = {"victim": {"lightgcn": victim.LightGCN, "mf": victim.MF}}
+factories = {"victim": {"lightgcn": victim.LightGCN, "mf": victim.MF, "ncf": victim.NCF}}
 
 
 def from_config(scope, name, **kwargs):

@@ -1,0 +1,157 @@
+"""NCF (NeuMF-end) victim on MI355X: same interface as recad/model/victim/ncf.py, hot path in HIP
+(recad_amd/csrc/ncf.hip: fp32-MFMA tower GEMMs, fused predict/BCE, multi-tensor Adam)."""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..utils import VarDim, pick_optim
+from .base import BaseVictim
+
+
+class NCF(BaseVictim):
+    victim_name = "ncf"
+
+    def _build(self, factor_num, num_layers, dropout, model, GMF_model, MLP_model, **config):
+        self.dataset = config["dataset"]
+        self.config = config
+        info = self.dataset.info_describe()
+        user_num, item_num = info["n_users"], info["n_items"]
+        if model != "NeuMF-end":
+            raise ValueError("the HIP NCF path implements model='NeuMF-end' (the reference default) only")
+        if dropout:
+            raise ValueError("dropout is not supported by the HIP path (reference default is 0)")
+        if not 1 <= num_layers <= 8:
+            raise ValueError("num_layers must be in [1, 8]")
+        self.dropout, self.model, self.GMF_model, self.MLP_model = dropout, model, GMF_model, MLP_model
+        self.factor_num, self.num_layers = factor_num, num_layers
+        self.num_users, self.num_items = user_num, item_num
+        E = factor_num * (2 ** (num_layers - 1))
+        # construction and initialisation in the reference's order (ncf.py:33-58,60-77) so that a
+        # seeded run starts from the same weights
+        self.embed_user_GMF = nn.Embedding(user_num, factor_num)
+        self.embed_item_GMF = nn.Embedding(item_num, factor_num)
+        self.embed_user_MLP = nn.Embedding(user_num, E)
+        self.embed_item_MLP = nn.Embedding(item_num, E)
+        mods = []
+        for i in range(num_layers):
+            width = factor_num * (2 ** (num_layers - i))
+            mods += [nn.Dropout(p=dropout), nn.Linear(width, width // 2), nn.ReLU()]
+        self.MLP_layers = nn.Sequential(*mods)
+        self.predict_layer = nn.Linear(factor_num * 2, 1)
+        for emb in (self.embed_user_GMF, self.embed_user_MLP, self.embed_item_GMF, self.embed_item_MLP):
+            nn.init.normal_(emb.weight, std=0.01)
+        for m in self.MLP_layers:
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+        nn.init.kaiming_uniform_(self.predict_layer.weight, a=1, nonlinearity="sigmoid")
+        for m in self.modules():
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+        self.optimizer = pick_optim(config["optim"])(self.parameters(), lr=config["lr"])
+        self.loss_func = nn.BCEWithLogitsLoss()
+        self._E = E
+        self._ws = None
+        self._t = 0
+        self.max_batch = 4096
+
+    # ------------------------------------------------------------------ C-ABI descriptor
+    def _tensors(self):
+        lin = [m for m in self.MLP_layers if isinstance(m, nn.Linear)]
+        return ([self.embed_user_GMF.weight, self.embed_item_GMF.weight, self.embed_user_MLP.weight, self.embed_item_MLP.weight]
+                + [m.weight for m in lin] + [m.bias for m in lin] + [self.predict_layer.weight, self.predict_layer.bias])
+
+    def _desc(self, batch):
+        ts = self._tensors()
+        dev = ts[0].device
+        if dev.type != "cuda":
+            raise _lib.HipCallError("NCF parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
+        if not isinstance(self.optimizer, torch.optim.Adam):
+            raise NotImplementedError("the HIP NCF path fuses torch.optim.Adam (default options)")
+        L, f = self.num_layers, self.factor_num
+        mb = max(int(batch), self.max_batch)
+        key = (tuple(t.data_ptr() for t in ts), mb)
+        if self._ws is None or self._ws["key"] != key:
+            widths = sum(f * 2 ** (L - l) for l in range(L + 1))
+            old = self._ws
+            ws = {"key": key,
+                  "grad": [torch.zeros_like(t) for t in ts],
+                  "m": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["m"]],
+                  "v": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["v"]],
+                  "acts": torch.empty(mb * widths, device=dev), "dacts": torch.empty(mb * widths, device=dev),
+                  "d0": torch.empty(mb, device=dev), "max_batch": mb}
+            self._ws = ws
+        ws = self._ws
+        grp = self.optimizer.param_groups[0]
+        b1, b2 = grp.get("betas", (0.9, 0.999))
+        d = _lib.NCFDesc(n_users=self.num_users, n_items=self.num_items, factor=f, n_layers=L, lr=float(grp["lr"]),
+                         beta1=float(b1), beta2=float(b2), eps=float(grp.get("eps", 1e-8)),
+                         ug=_lib.ptr(ts[0].data), ig=_lib.ptr(ts[1].data), um=_lib.ptr(ts[2].data), im=_lib.ptr(ts[3].data),
+                         pw=_lib.ptr(ts[-2].data), pb=_lib.ptr(ts[-1].data), acts=_lib.ptr(ws["acts"]), dacts=_lib.ptr(ws["dacts"]),
+                         d0=_lib.ptr(ws["d0"]), max_batch=ws["max_batch"])
+        for l in range(L):
+            d.W[l] = ts[4 + l].data.data_ptr()
+            d.b[l] = ts[4 + L + l].data.data_ptr()
+        for k in range(len(ts)):
+            d.grad[k] = ws["grad"][k].data_ptr()
+            d.m[k] = ws["m"][k].data_ptr()
+            d.v[k] = ws["v"][k].data_ptr()
+        return d
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, user, item):
+        d = self._desc(0)
+        out = torch.empty(user.numel(), device=self.predict_layer.weight.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rk_ncf_forward(C.byref(d), _lib.ptr(user.long().contiguous()), _lib.ptr(item.long().contiguous()),
+                                             None, 0, user.numel(), _lib.ptr(out), _lib.stream_ptr()), "rk_ncf_forward")
+        return out.view(-1)
+
+    def _run_epoch(self, users, items, labels, batch, apply_update=True):
+        d = self._desc(batch)
+        n = users.numel()
+        n_steps = (n + batch - 1) // batch
+        lp = torch.empty(n_steps * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rk_ncf_train_epoch(C.byref(d), _lib.ptr(users), _lib.ptr(items), _lib.ptr(labels), n, batch,
+                                                 self._t, _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()),
+                   "rk_ncf_train_epoch")
+        if apply_update:
+            self._t += n_steps
+        return lp.view(n_steps, _lib.RK_LOSS_PARTIALS)
+
+    def train_step(self, **config):
+        """One epoch of pointwise BCE training (ncf.py:133-153) -> (mean step loss,)."""
+        self.train()
+        pbar = config.get("progress_bar", None)
+        (users, items, labels), batch = self._collect_epoch(self.dataset, ("users", "items", "labels"))
+        dev = self.predict_layer.weight.device
+        users, items, labels = (t.to(dev).long().contiguous() for t in (users, items, labels))
+        partials = self._run_epoch(users, items, labels, batch)
+        step_losses = partials.sum(dim=1).double().cpu()
+        mean_loss = float(step_losses.sum().item() / len(step_losses))
+        if pbar:
+            pbar.set_description(f"loss: {mean_loss:.5f}")
+        return (mean_loss,)
+
+    def score_matrix(self, user_ids, out):
+        """out[len(user_ids), n_items] <- forward over the full catalog of each user (evaluation)."""
+        d = self._desc(0)
+        _lib.check(_lib.lib().rk_ncf_forward(C.byref(d), None, None, _lib.ptr(user_ids), self.num_items,
+                                             user_ids.numel() * self.num_items, _lib.ptr(out), _lib.stream_ptr()),
+                   "rk_ncf_forward")
+
+    def input_describe(self):
+        return {
+            "train_step": {
+                "users": (torch.int64, (VarDim(comment="batch"))),
+                "items": (torch.int64, (VarDim(comment="batch"))),
+                "labels": (torch.int64, (VarDim(comment="batch"))),
+            },
+            "forward": {"users": (torch.int64, (VarDim(comment="batch"))), "items": (torch.int64, (VarDim(comment="batch")))},
+        }
+
+    def output_describe(self):
+        return {
+            "train_step": {"loss": (float, [])},
+            "forward": {"unnormalized_scores": (torch.float32, [VarDim(comment="batch")])},
+        }

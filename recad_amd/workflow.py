@@ -92,7 +92,7 @@ class Normal:
     # ------------------------------------------------------------------ evaluate (normal.py:57-160)
     def _rows(self, model, dataset, users, targets, topks):
         ptr, idx = dataset.train_csr_sorted()
-        if hasattr(model, "scoring_tables"):
+        if hasattr(model, "scoring_tables") or hasattr(model, "score_matrix"):
             res = full_catalog_topk(model, users, ptr, idx, targets, K=max(100, max(topks)))
             return hr_rows(users, res, topks), res
         # foreign victim: the reference's own per-user forward loop

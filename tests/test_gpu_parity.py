@@ -279,3 +279,53 @@ def test_workflow_end_to_end_on_device(gpu_device):
                                ds.n_items, ptr.astype(np.int32), idx, [0], [10, 20, 50, 100], users=users)
         for i, k in enumerate([10, 20, 50, 100]):
             assert abs(rows[:, 2 + i].mean() - res[f"HR@{k}"]) < 1e-12, (name, k)
+
+
+@pytest.mark.parametrize("name", ["ncf_dev_f8_l3", "ncf_game_f32_l5"])
+def test_ncf_train_golden(gpu_device, name):
+    from recad_amd import model
+    g = G.load(name)
+    f, L = int(g["factor"]), int(g["layers"])
+    rs, dstr = int(g["row_stride"]), int(g["dense_stride"])
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    m = model.from_config("victim", "ncf", factor_num=f, num_layers=L).I(dataset=ds)
+    (ug, ig, um, im), W, b, pw, pb = G.ncf_init(g)
+    for p, a in zip((m.embed_user_GMF, m.embed_item_GMF, m.embed_user_MLP, m.embed_item_MLP), (ug, ig, um, im)):
+        p.weight.data.copy_(torch.from_numpy(a))
+    lin = [x for x in m.MLP_layers if isinstance(x, torch.nn.Linear)]
+    for l, x in enumerate(lin):
+        x.weight.data.copy_(torch.from_numpy(W[l]))
+    m.predict_layer.weight.data.copy_(torch.from_numpy(pw))
+    m = m.to(gpu_device)
+    n0 = int(g["batch_len"][0])
+    b0 = next(ds.generate_batch())
+    pred0 = m(b0["users"], b0["items"]).cpu().numpy()
+    assert np.allclose(pred0, g["pred0"], rtol=1e-5, atol=1e-7)
+    names = ["embed_user_GMF.weight", "embed_item_GMF.weight", "embed_user_MLP.weight", "embed_item_MLP.weight"]
+    names += [f"MLP_layers.{3 * l + 1}.weight" for l in range(L)] + [f"MLP_layers.{3 * l + 1}.bias" for l in range(L)]
+    names += ["predict_layer.weight", "predict_layer.bias"]
+
+    def pick(n, a):
+        a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+        return a[::rs] if n.startswith("embed_") else a.reshape(-1)[::dstr]
+
+    part = m._run_epoch(b0["users"], b0["items"], b0["labels"], n0, apply_update=False)
+    assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
+    for nme, gr in zip(names, m._ws["grad"]):
+        assert G.relerr(pick(nme, gr), g["grad1_" + nme].reshape(pick(nme, gr).shape)) < 2e-5, nme
+    for gr in m._ws["grad"]:
+        gr.zero_()
+    params = dict(m.named_parameters())
+    for s in range(len(g["batch_len"])):
+        ds.steps = [s]
+        (loss,) = m.train_step()
+        assert abs(loss - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, loss, g["losses"][s])
+        if s == 0:
+            for nme in names:
+                assert G.relerr(pick(nme, params[nme]), g["after1_" + nme].reshape(pick(nme, params[nme]).shape)) < 2e-5, nme
+    steps = len(g["batch_len"])
+    for nme in names:
+        ok, info = G.adam_close(pick(nme, params[nme]), g["final_" + nme], 1e-3, steps)
+        assert ok, (nme, info)
+    if name == "ncf_dev_f8_l3":
+        _eval_against_golden(g, m, gpu_device)
