@@ -67,6 +67,33 @@ int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const
                 const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
                 const float *add, float *y, void *stream);
 
+/* rk_spmm_csr with every fused epilogue the LightGCN step uses, for callers that compose a step
+ * themselves (the row-sharded multi-GPU trainer runs collectives between the launches).  Row r of
+ * the CSR slab addresses row r of add/y/sum_in/sum_out/zero1/zero2/adam_*; x has x_rows rows.
+ *   v = A.x (+ add);  y = v;  sum_out = (sum_in + v) * sum_scale;  zero1 = zero2 = 0;
+ *   adam_t > 0: torch.optim.Adam step t on adam_p/m/v with gradient v (coef_scratch: device float[2]). */
+typedef struct rk_spmm_epilogue {
+    const float *add;
+    float *y;
+    const float *sum_in;
+    float *sum_out;
+    float sum_scale;
+    int32_t adam_t;
+    float *zero1, *zero2;
+    float *adam_p, *adam_m, *adam_v, *coef_scratch;
+    float lr, beta1, beta2, eps;
+} rk_spmm_epilogue;
+int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
+                   const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x, int64_t x_rows,
+                   const rk_spmm_epilogue *epi, void *stream);
+
+/* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
+ * index light/emb/gprop/gego directly (item rows already offset).  gprop += dL/dlight / (L+1),
+ * gego += that + the L2-reg gradient; loss_partials: device float[RK_LOSS_PARTIALS]. */
+int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb,
+                float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
+                const int64_t *rows_n, int32_t nb, float *loss_partials, void *stream);
+
 /* ---------------------------------------------------------------- LightGCN --------- */
 typedef struct rk_lightgcn_desc {
     int32_t n_users, n_items, dim, n_layers;

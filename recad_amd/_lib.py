@@ -40,6 +40,17 @@ class LightGCNDesc(C.Structure):
     ]
 
 
+class SpmmEpilogue(C.Structure):
+    """rk_spmm_epilogue (include/recad_hip.h)."""
+
+    _fields_ = [
+        ("add", C.c_void_p), ("y", C.c_void_p), ("sum_in", C.c_void_p), ("sum_out", C.c_void_p),
+        ("sum_scale", C.c_float), ("adam_t", C.c_int32), ("zero1", C.c_void_p), ("zero2", C.c_void_p),
+        ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("coef_scratch", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+    ]
+
+
 class NCFDesc(C.Structure):
     """rk_ncf_desc (include/recad_hip.h)."""
 
@@ -68,6 +79,8 @@ _SIGNATURES = {
     "rk_csr_schedule_destroy": [_P],
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
+    "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
+    "rk_bpr_rows": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
     "rk_lightgcn_propagate": [_P, _P],

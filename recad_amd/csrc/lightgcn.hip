@@ -35,6 +35,7 @@ struct BprArgs {
     float *coef;  // coef[2k], coef[2k+1] for step k of the chunk
     int k;
     float lr, b1, b2;
+    int nb_direct;  // state == nullptr: one batch of nb_direct triplets starting at users[0]
 };
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -46,12 +47,16 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
 {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int step = a.state[ST_STEP_BASE] + a.k;
-    const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
-    const int B = a.state[ST_BATCH];
-    const long long off = (long long)step * B;
-    const int nb = (int)max(0LL, min((long long)B, ntrip - off));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int step = 0, nb = a.nb_direct;
+    long long off = 0;
+    if (a.state) {
+        step = a.state[ST_STEP_BASE] + a.k;
+        const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
+        const int B = a.state[ST_BATCH];
+        off = (long long)step * B;
+        nb = (int)max(0LL, min((long long)B, ntrip - off));
+    }
+    if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
         const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
         a.coef[2 * a.k] = c.step_size;
         a.coef[2 * a.k + 1] = c.bc2s;
@@ -248,6 +253,7 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     b.loss_partials = loss_partials;
     b.state = d.state; b.coef = d.coef; b.k = k;
     b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
+    b.nb_direct = 0;
     hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
     RK_CHECK_LAUNCH();
     return launch_backward(d, k, apply_update, bump, s);
@@ -307,5 +313,58 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
         int rc = launch_step(d, users, pos, neg, loss_partials, 0, apply_update, 1, s);
         if (rc) return rc;
     }
+    return RK_OK;
+}
+
+
+// ---------------------------------------------------------------- op-level entry points
+// (the row-sharded multi-GPU trainer composes a step from these between its collectives)
+__global__ void set_coef_kernel(float *coef, float step_size, float bc2s)
+{
+    coef[0] = step_size;
+    coef[1] = bc2s;
+}
+
+RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
+                             const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x, int64_t x_rows,
+                             const rk_spmm_epilogue *epi, void *stream)
+{
+    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !epi)
+        RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: bad arguments");
+    if ((size_t)x_rows * dim * sizeof(float) >= (1ULL << 32)) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: x_rows*dim*4 must be < 4 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    SpmmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val;
+    a.wave_desc = reinterpret_cast<const int4 *>(wave_desc); a.n_blocks = n_blocks; a.d = dim; a.x = x;
+    a.e.add = epi->add; a.e.y = epi->y; a.e.sum_in = epi->sum_in; a.e.sum_out = epi->sum_out; a.e.sum_scale = epi->sum_scale;
+    a.e.zero1 = epi->zero1; a.e.zero2 = epi->zero2;
+    if (epi->sum_out && !epi->sum_in) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: sum_out needs sum_in");
+    if (epi->adam_t > 0) {
+        if (!epi->adam_p || !epi->adam_m || !epi->adam_v || !epi->coef_scratch) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: Adam pointers missing");
+        const AdamCoef c = adam_coef(epi->adam_t, epi->lr, epi->beta1, epi->beta2);
+        hipLaunchKernelGGL(set_coef_kernel, dim3(1), dim3(1), 0, s, epi->coef_scratch, c.step_size, c.bc2s);
+        RK_CHECK_LAUNCH();
+        a.e.adam = 1; a.e.p = epi->adam_p; a.e.m = epi->adam_m; a.e.v = epi->adam_v; a.e.coef = epi->coef_scratch;
+        a.e.b1 = epi->beta1; a.e.b2 = epi->beta2; a.e.eps = epi->eps;
+    }
+    RK_HIP(spmm_launch(a, s));
+    return RK_OK;
+}
+
+RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb,
+                          float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
+                          const int64_t *rows_n, int32_t nb, float *loss_partials, void *stream)
+{
+    if (dim <= 0 || n_layers < 0 || !light || !emb || !gprop || !gego || !rows_u || !rows_p || !rows_n || nb <= 0 || !loss_partials)
+        RK_FAIL(RK_EINVAL, "rk_bpr_rows: bad arguments");
+    BprArgs b;
+    memset(&b, 0, sizeof(b));
+    b.U = 0; b.d = dim; b.L = n_layers; b.lam = lambda;
+    b.light = light; b.emb = emb; b.gprop = gprop; b.gego = gego;
+    b.users = rows_u; b.pos = rows_p; b.neg = rows_n;
+    b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb;
+    hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, (hipStream_t)stream, b);
+    RK_CHECK_LAUNCH();
     return RK_OK;
 }

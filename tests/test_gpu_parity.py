@@ -329,3 +329,24 @@ def test_ncf_train_golden(gpu_device, name):
         assert ok, (nme, info)
     if name == "ncf_dev_f8_l3":
         _eval_against_golden(g, m, gpu_device)
+
+
+@pytest.mark.parametrize("name", ["lightgcn_game_d64_tg", "lightgcn_dev_d128_l2_tg"])
+def test_sharded_trainer_single_rank_hip(gpu_device, name):
+    """The row-sharded trainer with the real HIP ops (rk_spmm_csr_ex / rk_bpr_rows), world = 1:
+    same losses and tables as the goldens (the multi-rank logic is covered on CPU with gloo)."""
+    from recad_amd.sharded import ShardedLightGCN
+    g = G.load(name)
+    U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device))
+    for s in range(len(g["batch_len"])):
+        n = int(g["batch_len"][s])
+        u, p, ng = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)).to(gpu_device) for k in range(3))
+        loss = float(tr.train_epoch(u, p, ng, n)[0])
+        assert abs(loss - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, loss, g["losses"][s])
+    users, items = tr.tables()
+    rs = int(g["row_stride"])
+    assert G.relerr(users.cpu().numpy()[::rs], g["final_user"]) < TABLE_RTOL
+    assert G.relerr(items.cpu().numpy()[::rs], g["final_item"]) < TABLE_RTOL
