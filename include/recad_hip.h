@@ -47,10 +47,12 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
  * segments of <= 64 nonzeros, whole rows are packed into workgroups of 16 segments (first-fit
  * decreasing), rows with more than 1024 nonzeros get a workgroup of their own.  Built on the
  * host once per graph (reads rowptr back: synchronous).  Two calls: _build returns the number
- * of workgroups, _upload writes the per-wave descriptors int32[n_blocks*16*4] to the device. */
+ * of workgroups, _upload writes the per-wave descriptors int32[n_blocks*16*4] to the device.
+ * class_split > 0 (= n_users for the bipartite adjacency): rows < split and rows >= split are
+ * scheduled separately and interleaved 4:4 over the 8 XCDs so each XCD L2 holds one table. */
 typedef struct rk_schedule *rk_schedule_t;
-int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void *stream, rk_schedule_t *out,
-                          int32_t *n_blocks);
+int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, void *stream,
+                          rk_schedule_t *out, int32_t *n_blocks);
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);
 

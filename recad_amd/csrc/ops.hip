@@ -64,9 +64,11 @@ struct rk_schedule {
     int32_t n_blocks = 0;
 };
 
-RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void *stream, rk_schedule_t *out, int32_t *n_blocks)
+RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, void *stream,
+                                    rk_schedule_t *out, int32_t *n_blocks)
 {
-    if (n_rows <= 0 || !rowptr || !out || !n_blocks) RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
+    if (n_rows <= 0 || !rowptr || !out || !n_blocks || class_split < 0 || class_split > n_rows)
+        RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     std::vector<int32_t> rp((size_t)n_rows + 1);
     RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
@@ -82,7 +84,13 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void 
     const int kSpmmWaves = spmm_waves();
     static const int seg_nnz = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : kSegNnz;
     rk_schedule *sc = new rk_schedule();
-    std::vector<int32_t> &d = sc->desc;
+    // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  With
+    // class_split > 0 the rows < split (users) and >= split (items) are scheduled into separate
+    // workgroup lists that are then interleaved 4:4 per group of 8, so an XCD's L2 only ever
+    // fetches ONE of the two embedding tables (speed only; any placement is correct).
+    std::vector<int32_t> cls[2];
+    for (int pass = 0; pass < 2; ++pass) {
+    std::vector<int32_t> &d = cls[pass];
     auto new_block = [&]() {
         const size_t base = d.size();
         d.resize(base + (size_t)kSpmmWaves * 4, 0);
@@ -93,6 +101,7 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void 
     std::vector<std::vector<size_t>> free_list((size_t)kSpmmWaves + 1);
     for (int32_t oi = 0; oi < n_rows; ++oi) {
         const int32_t r = order[(size_t)oi];
+        if ((class_split > 0 && r >= class_split) != (pass == 1)) continue;
         const int32_t b = rp[r], e = rp[r + 1], nnz = e - b;
         int32_t nseg = std::max(1, (nnz + seg_nnz - 1) / seg_nnz);
         if (nseg > kSpmmWaves) {  // long row: own workgroup, waves loop over ceil(nnz/16) nonzeros each
@@ -128,7 +137,22 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, void 
         const int left = kSpmmWaves - used - nseg;
         if (left > 0) free_list[(size_t)left].push_back(base);
     }
-    sc->n_blocks = (int32_t)(d.size() / ((size_t)kSpmmWaves * 4));
+    }
+    const size_t bw = (size_t)kSpmmWaves * 4;
+    const size_t nb0 = cls[0].size() / bw, nb1 = cls[1].size() / bw;
+    std::vector<int32_t> &d = sc->desc;
+    d.reserve(cls[0].size() + cls[1].size());
+    size_t i0 = 0, i1 = 0;
+    for (size_t b = 0; i0 < nb0 || i1 < nb1; ++b) {
+        bool want1 = (b % 8) >= 4;
+        if (want1 && i1 >= nb1) want1 = false;
+        if (!want1 && i0 >= nb0) want1 = true;
+        const std::vector<int32_t> &src = want1 ? cls[1] : cls[0];
+        size_t &idx = want1 ? i1 : i0;
+        d.insert(d.end(), src.begin() + (long)(idx * bw), src.begin() + (long)((idx + 1) * bw));
+        ++idx;
+    }
+    sc->n_blocks = (int32_t)(d.size() / bw);
     *out = sc;
     *n_blocks = sc->n_blocks;
     return RK_OK;

@@ -32,9 +32,9 @@ class CsrGraph:
                         self.wave_desc.to(device), self.n_blocks)
 
     @staticmethod
-    def _schedule(n_rows, rowptr):
+    def _schedule(n_rows, rowptr, class_split=0):
         sched, n_blocks = C.c_void_p(), C.c_int32(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), _lib.stream_ptr(), C.byref(sched),
+        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, _lib.stream_ptr(), C.byref(sched),
                                                     C.byref(n_blocks)), "rk_csr_schedule_build")
         try:
             desc = torch.empty(int(n_blocks.value) * 16 * 4, device=rowptr.device, dtype=torch.int32)  # >= waves*4 per block
@@ -44,7 +44,7 @@ class CsrGraph:
         return desc, int(n_blocks.value)
 
     @classmethod
-    def from_torch_coo(cls, coo, device):
+    def from_torch_coo(cls, coo, device, class_split=0):
         """From the reference's graph tensor: coalesced sparse COO, int64 indices, fp32 values
         (recad/dataset/implicit.py:295-296,320-326)."""
         _lib.require_gpu()
@@ -59,7 +59,7 @@ class CsrGraph:
         val = torch.empty(max(nnz, 1), device=device, dtype=torch.float32)[:nnz]
         _lib.check(_lib.lib().rk_coo_to_csr(n, nnz, _lib.ptr(row), _lib.ptr(col64), _lib.ptr(v), _lib.ptr(rowptr),
                                             _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()), "rk_coo_to_csr")
-        desc, n_blocks = cls._schedule(n, rowptr)
+        desc, n_blocks = cls._schedule(n, rowptr, class_split)
         return cls(n, rowptr, col, val, desc, n_blocks)
 
     @classmethod
@@ -78,7 +78,7 @@ class CsrGraph:
         _lib.check(_lib.lib().rk_build_norm_adj(n_users, n_items, _lib.ptr(r_ptr), _lib.ptr(r_idx), _lib.ptr(rowptr),
                                                 _lib.ptr(col), _lib.ptr(val), _lib.ptr(tmp), _lib.stream_ptr()),
                    "rk_build_norm_adj")
-        desc, n_blocks = cls._schedule(N, rowptr)
+        desc, n_blocks = cls._schedule(N, rowptr, n_users)
         return cls(N, rowptr, col, val, desc, n_blocks)
 
     def to_torch_coo(self):

@@ -37,7 +37,7 @@ class HipOps:
     def make_slab(self, rowptr, col, val, device):
         rp = torch.as_tensor(rowptr, dtype=torch.int32, device=device).contiguous()
         sched, n_blocks = C.c_void_p(), C.c_int32(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(len(rowptr) - 1, _lib.ptr(rp), _lib.stream_ptr(), C.byref(sched),
+        _lib.check(_lib.lib().rk_csr_schedule_build(len(rowptr) - 1, _lib.ptr(rp), 0, _lib.stream_ptr(), C.byref(sched),
                                                     C.byref(n_blocks)), "rk_csr_schedule_build")
         try:
             desc = torch.empty(int(n_blocks.value) * 64, device=device, dtype=torch.int32)

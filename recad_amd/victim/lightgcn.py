@@ -97,7 +97,7 @@ class LightGCN(BaseVictim):
 
     def _csr(self, device):
         if not isinstance(self.Graph, CsrGraph):
-            self.Graph = CsrGraph.from_torch_coo(self.Graph, device)
+            self.Graph = CsrGraph.from_torch_coo(self.Graph, device, class_split=self.num_users)
         return self.Graph.to(device)
 
     def _ensure_handle(self, want_grad=False):
