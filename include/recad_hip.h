@@ -59,7 +59,8 @@ int rk_csr_schedule_destroy(rk_schedule_t sched);
 /* D^-1/2 A D^-1/2 of the bipartite user-item graph straight into CSR, on device.
  * Replaces ImplicitData.getSparseGraph, recad/dataset/implicit.py:243-298 (scipy dok/lil).
  * r_ptr/r_idx: user->item CSR (device, item ids sorted ascending within a user).
- * Outputs: rowptr[U+I+1], col[2E], val[2E] (device).  Uses `tmp` int32[I+1] device scratch. */
+ * Outputs: rowptr[U+I+1], col[2E], val[2E] (device).  `tmp`: int32[I+1] device scratch; the
+ * transpose uses a radix sort of the edge keys with stream-ordered temporaries (hipMallocAsync). */
 int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t *r_ptr, const int32_t *r_idx,
                       int32_t *rowptr, int32_t *col, float *val, int32_t *tmp, void *stream);
 
@@ -173,6 +174,22 @@ int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, float *user
                       const int64_t *users, const int64_t *items, const int64_t *labels, int64_t n,
                       int32_t batch, int32_t adam_t0, float lr, float beta1, float beta2, float eps,
                       float *loss_partials, int32_t apply_update, void *stream);
+
+/* ---------------------------------------------------------------- samplers ---------- */
+/* BPR triplets with the semantics of pairwise_sample, recad/dataset/implicit.py:50-74: n_draws
+ * uniform user draws with replacement; a user without positives yields valid=0 (the reference
+ * skips the draw); positive uniform over the user's list; negative uniform over the items NOT in
+ * it.  pos_ptr/pos_idx: user->sorted item ids (device int32).  Counter-based RNG of `seed`. */
+int rk_bpr_sample(int32_t n_users, int32_t n_items, const int32_t *pos_ptr, const int32_t *pos_idx,
+                  int64_t n_draws, uint64_t seed, int64_t *users, int64_t *pos, int64_t *neg, int32_t *valid,
+                  void *stream);
+
+/* (user, item, label) rows of pointwise_sample, recad/dataset/implicit.py:77-91: each train edge
+ * once with label 1, followed by negative_ratio rows with label 0 whose item is uniform (with
+ * replacement) over the user's non-interacted items.  Outputs: int64[n_edges*(negative_ratio+1)]. */
+int rk_pointwise_sample(int32_t n_users, int32_t n_items, const int32_t *train_ptr, const int32_t *train_idx,
+                        int64_t n_edges, int32_t negative_ratio, uint64_t seed, int64_t *users, int64_t *items,
+                        int64_t *labels, void *stream);
 
 /* Pass 2 of rk_score_topk on a ready score matrix scores[nb, n_items] (modified in place:
  * seen items are overwritten with -inf).  Used for victims whose scores are not a dot product. */

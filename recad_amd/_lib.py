@@ -88,6 +88,8 @@ _SIGNATURES = {
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rk_bpr_sample": [_I32, _I32, _P, _P, _I64, C.c_uint64, _P, _P, _P, _P, _P],
+    "rk_pointwise_sample": [_I32, _I32, _P, _P, _I64, _I32, C.c_uint64, _P, _P, _P, _P],
     "rk_topk_rows": [_P, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P],
     "rk_ncf_forward": [C.POINTER(NCFDesc), _P, _P, _P, _I32, _I64, _P, _P],
     "rk_ncf_train_epoch": [C.POINTER(NCFDesc), _P, _P, _P, _I64, _I32, _I32, _P, _I32, _P],

@@ -4,6 +4,8 @@
 #include <numeric>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "spmm.h"
 
 RK_EXPORT int rk_abi_version(void) { return RK_ABI_VERSION; }
@@ -229,37 +231,23 @@ __global__ void adj_user_rows_kernel(int U, const int *__restrict__ rptr, const 
     }
 }
 
-// One thread per (user,item) edge finds its slot in the item row by counting smaller users:
-// deterministic without sorting: slot = #edges of item i with user < u.  Done via binary
-// search over users is not possible without the transpose, so use a per-item cursor filled
-// in user order by a single pass per item block (items are few, users visited in order).
-__global__ void adj_item_rows_kernel(int U, int I, const int *__restrict__ rptr, const int *__restrict__ ridx,
+// item rows = transpose of the user rows: radix-sort the edge keys (item << 32 | user); edge e of
+// the sorted list is entry e of the item block (users ascending inside an item => deterministic).
+__global__ void adj_edge_keys_kernel(int U, const int *__restrict__ rptr, const int *__restrict__ ridx, unsigned long long *__restrict__ keys)
+{
+    const int u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= U) return;
+    for (int k = rptr[u] + lane; k < rptr[u + 1]; k += 64) keys[k] = ((unsigned long long)(unsigned)ridx[k] << 32) | (unsigned)u;
+}
+
+__global__ void adj_item_rows_kernel(int U, long long E, const unsigned long long *__restrict__ keys, const int *__restrict__ rptr,
                                      const int *__restrict__ rowptr, int *__restrict__ col, float *__restrict__ val)
 {
-    // one wave per item: scan all users' lists for this item would be O(E*I); instead each
-    // wave owns an item and binary-searches every user's sorted list -- O(U log deg) per item.
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= I) return;
-    const int out0 = rowptr[U + i];
-    const float di = dinv_f(rowptr[U + i + 1] - out0);
-    int written = 0;
-    for (int base = 0; base < U; base += 64) {
-        const int u = base + lane;
-        bool has = false;
-        int deg = 0;
-        if (u < U) {
-            int lo = rptr[u], hi = rptr[u + 1];
-            deg = hi - lo;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ridx[mid] < i) lo = mid + 1; else hi = mid; }
-            has = lo < rptr[u + 1] && ridx[lo] == i;
-        }
-        const unsigned long long m = __ballot(has);
-        if (has) {
-            const int pos = out0 + written + __popcll(m & ((1ULL << lane) - 1ULL));
-            col[pos] = u;
-            val[pos] = (di * 1.0f) * dinv_f(deg);
-        }
-        written += __popcll(m);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[e];
+        const int i = (int)(k >> 32), u = (int)(k & 0xffffffffULL);
+        col[E + e] = u;
+        val[E + e] = (dinv_f(rowptr[U + i + 1] - rowptr[U + i]) * 1.0f) * dinv_f(rptr[u + 1] - rptr[u]);
     }
 }
 
@@ -282,8 +270,26 @@ RK_EXPORT int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t 
     RK_CHECK_LAUNCH();
     hipLaunchKernelGGL(adj_user_rows_kernel, dim3((n_users + 3) / 4), dim3(256), 0, s, n_users, r_ptr, r_idx, rowptr, col, val);
     RK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(adj_item_rows_kernel, dim3((n_items + 3) / 4), dim3(256), 0, s, n_users, n_items, r_ptr, r_idx, rowptr, col, val);
-    RK_CHECK_LAUNCH();
+    if (E > 0) {
+        unsigned long long *keys = nullptr, *sorted = nullptr;
+        void *tmp_sort = nullptr;
+        size_t tmp_bytes = 0;
+        int end_bit = 32;
+        while (end_bit < 64 && (1LL << (end_bit - 32)) < (long long)n_items) ++end_bit;
+        RK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys, sorted, (int)E, 0, end_bit, s));
+        RK_HIP(hipMallocAsync((void **)&keys, sizeof(unsigned long long) * (size_t)E, s));
+        RK_HIP(hipMallocAsync((void **)&sorted, sizeof(unsigned long long) * (size_t)E, s));
+        RK_HIP(hipMallocAsync(&tmp_sort, tmp_bytes, s));
+        hipLaunchKernelGGL(adj_edge_keys_kernel, dim3((n_users + 3) / 4), dim3(256), 0, s, n_users, r_ptr, r_idx, keys);
+        RK_CHECK_LAUNCH();
+        RK_HIP(hipcub::DeviceRadixSort::SortKeys(tmp_sort, tmp_bytes, keys, sorted, (int)E, 0, end_bit, s));
+        const int grid = (int)std::min<long long>(((long long)E + 255) / 256, 8192);
+        hipLaunchKernelGGL(adj_item_rows_kernel, dim3(grid), dim3(256), 0, s, n_users, (long long)E, sorted, r_ptr, rowptr, col, val);
+        RK_CHECK_LAUNCH();
+        RK_HIP(hipFreeAsync(keys, s));
+        RK_HIP(hipFreeAsync(sorted, s));
+        RK_HIP(hipFreeAsync(tmp_sort, s));
+    }
     return RK_OK;
 }
 

@@ -295,10 +295,48 @@ class ImplicitData:
         labels = np.concatenate([np.ones(len(pu), dtype=np.int64), np.zeros(len(nu), dtype=np.int64)])
         return users, items, labels
 
+    def _device_epoch(self):
+        """Samplers on the GPU (rk_bpr_sample / rk_pointwise_sample); shuffling by torch.randperm."""
+        from . import _lib
+        dev = torch.device(self.config["device"])
+        seed = int(self._rng.integers(0, 2 ** 62))
+        pairwise = self.config["sample"] == "pairwise"
+        key = "_dev_net" if pairwise else "_dev_train"
+        if not hasattr(self, key):
+            ptr, idx = self._net if pairwise else self.train_csr_sorted()
+            setattr(self, key, (torch.as_tensor(ptr, dtype=torch.int32).to(dev), torch.as_tensor(idx, dtype=torch.int32).to(dev)))
+        ptr, idx = getattr(self, key)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed & 0x7FFFFFFF)
+        if pairwise:
+            n = self.traindataSize
+            u, p, ng = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
+            valid = torch.empty(n, dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().rk_bpr_sample(self.n_users, self.n_items, _lib.ptr(ptr), _lib.ptr(idx), n, seed, _lib.ptr(u),
+                                                _lib.ptr(p), _lib.ptr(ng), _lib.ptr(valid), _lib.stream_ptr()), "rk_bpr_sample")
+            keep = valid.bool()
+            cols = [t[keep] for t in (u, p, ng)]
+            names, bs = ("users", "positive_items", "negative_items"), self.config["pairwise_batch_size"]
+        else:
+            ratio = self.config["negative_ratio"]
+            E = idx.numel()
+            n = E * (ratio + 1)
+            cols = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3)]
+            _lib.check(_lib.lib().rk_pointwise_sample(self.n_users, self.n_items, _lib.ptr(ptr), _lib.ptr(idx), E, ratio, seed,
+                                                      _lib.ptr(cols[0]), _lib.ptr(cols[1]), _lib.ptr(cols[2]), _lib.stream_ptr()),
+                       "rk_pointwise_sample")
+            names, bs = ("users", "items", "labels"), self.config["pointwise_batch_size"]
+        perm = torch.randperm(cols[0].numel(), device=dev, generator=gen)
+        out = {k: c[perm].contiguous() for k, c in zip(names, cols)}
+        out["batch_size"] = bs
+        return out
+
     def generate_epoch(self):
         """One shuffled epoch as three int64 device tensors (+ batch size): the fast path the
         HIP victims consume; generate_batch() slices the same tensors."""
         dev = self.config["device"]
+        if self.config["sampler"] == "device" and self.config["sample"] in ("pairwise", "pointwise"):
+            return self._device_epoch()
         if self.config["sample"] == "pairwise":
             cols, names, bs = self.pairwise_sample(), ("users", "positive_items", "negative_items"), self.config["pairwise_batch_size"]
         elif self.config["sample"] == "pointwise":

@@ -350,3 +350,50 @@ def test_sharded_trainer_single_rank_hip(gpu_device, name):
     rs = int(g["row_stride"])
     assert G.relerr(users.cpu().numpy()[::rs], g["final_user"]) < TABLE_RTOL
     assert G.relerr(items.cpu().numpy()[::rs], g["final_item"]) < TABLE_RTOL
+
+
+def test_device_samplers(gpu_device):
+    """rk_bpr_sample / rk_pointwise_sample: the reference samplers' semantics (implicit.py:50-91),
+    checked exactly (membership) and distributionally (uniformity), reproducible per seed."""
+    from recad_amd import dataset, synth
+    d = synth.make("tiny")
+    mk = lambda **kw: dataset.from_config("implicit", "tiny", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                                          need_graph=False, device=gpu_device, graph_source="train", sampler="device", **kw)
+    ds = mk(seed=3)
+    ep = ds.generate_epoch()
+    u, p, n = (ep[k].cpu().numpy() for k in LGN_KEYS)
+    keys = set(ds._net_keys.tolist())
+    assert 0.95 * ds.traindataSize < len(u) <= ds.traindataSize
+    assert all((a * ds.n_items + b) in keys for a, b in zip(u, p))
+    assert not any((a * ds.n_items + b) in keys for a, b in zip(u, n))
+    cnt = np.bincount(u, minlength=ds.n_users)
+    assert cnt.std() < 3 * np.sqrt(cnt.mean()) + 1 and cnt.min() > 0          # uniform users, with replacement
+    negc = np.bincount(n, minlength=ds.n_items)
+    assert negc.min() > 0                                                      # every item reachable as negative
+    # positives uniform within a user's list: the busiest user sees (almost) all of its items
+    uu = int(np.argmax(np.diff(ds._net[0])))
+    mine = set(p[u == uu].tolist())
+    assert mine <= set(ds._net[1][ds._net[0][uu]:ds._net[0][uu + 1]].tolist()) and len(mine) > 3
+    ep2 = mk(seed=3).generate_epoch()
+    assert all(torch.equal(ep[k], ep2[k]) for k in LGN_KEYS), "same seed => same epoch"
+    assert not torch.equal(ep["users"], mk(seed=4).generate_epoch()["users"])
+    # pointwise
+    dsp = mk(seed=5, sample="pointwise")
+    ep = dsp.generate_epoch()
+    u, i, l = (ep[k].cpu().numpy() for k in PW_KEYS)
+    tp, ti = dsp.train_csr_sorted()
+    tk = set((np.repeat(np.arange(dsp.n_users), np.diff(tp)) * dsp.n_items + ti).tolist())
+    assert len(u) == 5 * dsp.traindataSize and l.sum() == dsp.traindataSize
+    assert all(((a * dsp.n_items + b) in tk) == (c == 1) for a, b, c in zip(u, i, l))
+    pos_pairs = sorted((a * dsp.n_items + b) for a, b, c in zip(u, i, l) if c == 1)
+    assert pos_pairs == sorted(tk)                                             # every train edge exactly once
+    negs = i[(u == uu) & (l == 0)]
+    free = dsp.n_items - np.diff(tp)[uu]
+    assert len(np.unique(negs)) > 0.6 * min(len(negs), free)
+    # and the model trains on them end to end
+    from recad_amd import model
+    m = model.from_config("victim", "mf", embedding_size=16).I(dataset=dsp).to(gpu_device)
+    l0 = m.train_step()[0]
+    for _ in range(3):
+        l1 = m.train_step()[0]
+    assert np.isfinite(l1) and l1 < l0
