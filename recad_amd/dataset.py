@@ -335,7 +335,10 @@ class ImplicitData:
         """One shuffled epoch as three int64 device tensors (+ batch size): the fast path the
         HIP victims consume; generate_batch() slices the same tensors."""
         dev = self.config["device"]
-        if self.config["sampler"] == "device" and self.config["sample"] in ("pairwise", "pointwise"):
+        smp = self.config["sampler"]
+        if smp == "auto":
+            smp = "device" if torch.device(dev).type == "cuda" else "numpy"
+        if smp == "device" and self.config["sample"] in ("pairwise", "pointwise"):
             return self._device_epoch()
         if self.config["sample"] == "pairwise":
             cols, names, bs = self.pairwise_sample(), ("users", "positive_items", "negative_items"), self.config["pairwise_batch_size"]

@@ -40,7 +40,7 @@ DATASET_IMPLICIT = {
     "device": DEVICE, "if_cache": False, "cache_dir": os.path.join(".", "generated"),
     # build-specific (no reference counterpart):
     "graph_source": "reference",  # "reference" = adjacency/positives from the LAST split read (test); "train"
-    "sampler": "numpy",           # "numpy" (vectorised host) | "device" (HIP)
+    "sampler": "auto",            # "numpy" (vectorised host) | "device" (HIP) | "auto" = device when on a GPU
 }
 
 WORKFLOW = {

@@ -397,3 +397,65 @@ def test_device_samplers(gpu_device):
     for _ in range(3):
         l1 = m.train_step()[0]
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_full_size_properties_ml1m(gpu_device):
+    """BASELINE.json config[1] at FULL size (ml1m-shaped 5950x3702, 469K edges, d=64, L=3): the
+    oracle is too slow to replay an epoch, so check size-independent properties, plus exact
+    oracle comparisons on samples."""
+    from recad_amd import dataset, model, synth
+    from recad_amd.evaluate import eligible_users, full_catalog_topk
+    d = synth.make("ml1m")
+    ds = dataset.from_config("implicit", "ml1m", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                             device=gpu_device, graph_source="train", seed=7)
+    g = ds.graph_csr()
+    N = g.n_rows
+    assert g.nnz == 2 * ds.traindataSize
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((N, 64), dtype=np.float32)).to(gpu_device)
+    y = torch.from_numpy(rng.standard_normal((N, 64), dtype=np.float32)).to(gpu_device)
+    ax, ay = g.spmm(x), g.spmm(y)
+    # linearity and symmetry of the normalised adjacency
+    assert G.relerr(g.spmm(x + 2 * y).cpu().numpy(), (ax + 2 * ay).cpu().numpy()) < 1e-5
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * ay.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    # exact rows against the oracle (same CSR, fixed per-row order may differ: tolerance)
+    rp, c, v = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
+    ref = orc.spmm(rp, c, v, x.cpu().numpy())
+    assert G.relerr(ax.cpu().numpy(), ref) < 2e-6
+    # spectral bound: ||D^-1/2 A D^-1/2|| <= 1
+    assert float(ax.norm()) <= float(x.norm()) * (1 + 1e-5)
+    # one epoch of training lowers the loss; two identical runs agree to rounding
+    def run():
+        torch.manual_seed(2023)
+        ds_ = ds.reset(seed=7)
+        m = model.from_config("victim", "lightgcn", latent_dim_rec=64).I(dataset=ds_).to(gpu_device)
+        return m, [m.train_step()[0] for _ in range(3)]
+    m, l1 = run()
+    _, l2 = run()
+    assert l1[2] < l1[1] < l1[0] and np.allclose(l1, l2, rtol=1e-5)
+    # evaluation: sorted, unique, unseen, rank consistent with membership, bit-exact vs oracle on samples
+    ptr, idx = ds.train_csr_sorted()
+    users = eligible_users(ptr, idx, [0])
+    res = full_catalog_topk(m, users, ptr, idx, [0, 17], K=100)
+    ts, ti = res["top_scores"], res["top_ids"]
+    assert (np.diff(ts, axis=1) <= 0).all() and (ti >= 0).all()
+    assert all(len(set(r)) == 100 for r in ti[::97])
+    for r in range(0, len(users), 211):
+        u = users[r]
+        seen = set(idx[ptr[u]:ptr[u + 1]].tolist())
+        assert not (seen & set(ti[r].tolist()))
+        for t, tg in enumerate([0, 17]):
+            if tg not in seen:
+                assert (res["target_rank"][r, t] < 100) == (tg in ti[r]), (u, tg)
+    utab, itab, _, _, _ = m.scoring_tables()
+    utab, itab = utab.cpu().numpy(), itab.cpu().numpy()
+    for r in range(0, len(users), 401):
+        u = users[r]
+        s = orc.score_rows(utab[u:u + 1], itab)[0]
+        ids, sc, tsc, trk = orc.topk_row(s, idx[ptr[u]:ptr[u + 1]], 100, np.array([0, 17], dtype=np.int32))
+        assert np.array_equal(ids, ti[r]) and np.array_equal(sc, ts[r])
+        assert np.array_equal(trk, res["target_rank"][r])
+    # idempotence: evaluating twice gives identical lists
+    res2 = full_catalog_topk(m, users, ptr, idx, [0, 17], K=100)
+    assert np.array_equal(res2["top_ids"], ti)
