@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=458)   # one ml1m epoch = ceil(468649/1024)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "yelp", "tiny"])
+    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "yelp", "tiny", "c4s", "config4"])
     ap.add_argument("--graph", default="train", choices=["train", "reference"],
                     help="adjacency from the train edges (BASELINE '~470K edges') or the reference's as-is test-edge graph")
     ap.add_argument("--dim", type=int, default=64)
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--graph-steps", type=int, default=8, help="train steps per hipGraph replay (0 = plain launches)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
     ap.add_argument("--parallel", default="replicas", choices=["replicas", "rows"],
                     help="N>1: one victim replica per GPU (weak) or node rows sharded over the GPUs with RCCL all-gathers (strong)")
     return ap.parse_args()
@@ -194,10 +195,12 @@ def main():
     ptr, idx = ds.train_csr_sorted()
     targets = np.array([0], dtype=np.int32)
     ev_users = eligible_users(ptr, idx, targets)
+    if args.eval_users:
+        ev_users = ev_users[: args.eval_users]
     full_catalog_topk(victim, ev_users[:256], ptr, idx, targets)  # warm
     barrier()
     t1 = time.perf_counter()
-    res = full_catalog_topk(victim, ev_users, ptr, idx, targets, K=100, chunk=8192)
+    res = full_catalog_topk(victim, ev_users, ptr, idx, targets, K=100, chunk=max(256, min(8192, (1 << 31) // max(ds.n_items, 1))))
     torch.cuda.synchronize()
     ev_el = time.perf_counter() - t1
     hr50 = float((res["target_rank"][:, 0] < 50).mean())

@@ -8,6 +8,8 @@ SHAPES = {
     "ml1m": (5950, 3702, 468649, 49390, 49494, 0),      # readme.md:168-176 of the reference
     "yelp": (54632, 34474, 1600000, 170000, 170000, 1),  # data/readme.md:62; edge counts assumed
     "tiny": (300, 200, 6000, 600, 600, 3),
+    "c4s": (250000, 125000, 25000000, 100000, 100000, 2),        # config 4 scaled down 4x per side
+    "config4": (1000000, 500000, 100000000, 100000, 100000, 2),  # BASELINE.json config 4
 }
 
 
