@@ -1,0 +1,226 @@
+// Exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32): C[m,n] = sum_k A(m,k) * B(n,k) with a
+// fused epilogue.  Used by the full-catalog scoring (recad/workflow/normal.py:57-93 semantics) and
+// the NCF tower (recad/model/victim/ncf.py:41-53,122).
+//
+// * 128x128 tile per 4-wave workgroup, each wave 64x64 = 2x2 accumulators of 32x32.
+// * k-chunks of 32 staged in padded LDS (row stride 33 floats: the ds_read_b32 of an MFMA operand
+//   is conflict-free); the next chunk's global loads are issued (16-byte loads when the layout
+//   allows) before the current chunk's 64 MFMAs and written to LDS afterwards (register
+//   prefetch; 33 KiB of LDS => 3 workgroups per CU overlap each other's barriers and epilogues).
+// * MFMA f32 is a k-ordered fmaf chain and chunks are visited in order, so a result is
+//   bit-identical to  s = fmaf(a[k], b[k], s), k = 0..K-1  (the oracle's orc_score_rows).
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    int M, N, K;
+    const float *A; long long a_rs, a_cs;  // A(m,k) = A[m*a_rs + k*a_cs]
+    const float *B; long long b_rs, b_cs;  // B(n,k) = B[n*b_rs + k*b_cs]
+    float *C; int ldc;
+    const float *col_bias;                 // + col_bias[n]
+    const float *row_bias;                 // scoring: ((s + row_bias[m]) + col_bias[n]) + const_add
+    float const_add;
+    int relu;
+    const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
+};
+
+static constexpr int kGT = 128, kGK = 32, kGLd = kGK + 1;
+static constexpr int kGemmLdsBytes = 2 * 2 * kGT * kGLd * (int)sizeof(float);  // 2 buffers x (A,B)
+
+// Tile rows [r0, r0+128) x k [k0, k0+32) of a strided matrix -> 16 floats per thread.
+// mode 0: scalar, bounds-checked.  mode 1: k contiguous (cs==1), float4 along k.
+// mode 2: rows contiguous (rs==1), float4 along rows.
+struct TileRegs { float v[16]; };
+
+__device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, int r0, int k0, long long rs, long long cs)
+{
+    const bool full = (r0 + kGT <= n_rows) && (k0 + kGK <= n_k);
+    if (!full) return 0;
+    if (cs == 1 && (rs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 1;
+    if (rs == 1 && (cs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 2;
+    return 0;
+}
+
+__device__ __forceinline__ void tile_load(TileRegs &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
+                                          int k0, long long rs, long long cs)
+{
+    const int tid = threadIdx.x;
+    if (mode == 1) {  // 8 float4 per row of 32 k: thread -> (row = p*32 + tid/8, k4 = tid%8)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
+            const float4 x = *reinterpret_cast<const float4 *>(src + (long long)(r0 + r) * rs + (k0 + c));
+            t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
+        }
+    } else if (mode == 2) {  // 32 float4 per k column of 128 rows: thread -> (k = p*8 + tid/32, row4 = tid%32)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = p * 8 + (tid >> 5), r = (tid & 31) * 4;
+            const float4 x = *reinterpret_cast<const float4 *>(src + (long long)(k0 + c) * cs + (r0 + r));
+            t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int idx = p * 256 + tid;
+            const int r = idx / kGK, c = idx % kGK;
+            const int gr = r0 + r, gc = k0 + c;
+            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + (long long)gc * cs] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_store(const TileRegs &t, int mode, float (*dst)[kGLd])
+{
+    const int tid = threadIdx.x;
+    if (mode == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
+            dst[r][c] = t.v[p * 4]; dst[r][c + 1] = t.v[p * 4 + 1]; dst[r][c + 2] = t.v[p * 4 + 2]; dst[r][c + 3] = t.v[p * 4 + 3];
+        }
+    } else if (mode == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = p * 8 + (tid >> 5), r = (tid & 31) * 4;
+            dst[r][c] = t.v[p * 4]; dst[r + 1][c] = t.v[p * 4 + 1]; dst[r + 2][c] = t.v[p * 4 + 2]; dst[r + 3][c] = t.v[p * 4 + 3];
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int idx = p * 256 + tid;
+            dst[idx / kGK][idx % kGK] = t.v[p];
+        }
+    }
+}
+
+// position `id` of the tile order -> tile origin.  Order (speed only): strips of 8 tile-rows,
+// tile-row fastest, so consecutive tiles share the B tile and the strip's A tiles stay in L2.
+__device__ __forceinline__ void tile_origin(int id, int gx, int gy, int &m0, int &n0)
+{
+    const int strip = id / (8 * gx), rem = id % (8 * gx);
+    const int h = min(8, gy - strip * 8);
+    m0 = (strip * 8 + rem % h) * kGT;
+    n0 = (rem / h) * kGT;
+}
+
+template <int NBUF, int MINW>
+static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs g, const int tiles_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: [buffer 0: A | B][buffer 1: A | B]
+    auto tileA = [&](int buf) { return reinterpret_cast<float (*)[kGLd]>(smem + (size_t)buf * 2 * kGT * kGLd); };
+    auto tileB = [&](int buf) { return reinterpret_cast<float (*)[kGLd]>(smem + (size_t)buf * 2 * kGT * kGLd + kGT * kGLd); };
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int gx = (g.N + kGT - 1) / kGT, gy = (g.M + kGT - 1) / kGT, nwg = gx * gy;
+    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of the
+    // tile order (bijective remap), each workgroup a run of tiles_per_block consecutive tiles.
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb / 8, r = nb % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int t_begin = bid * tiles_per_block, t_end = min(nwg, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int n_chunks = (g.K + kGK - 1) / kGK;
+    const int total = (t_end - t_begin) * n_chunks;
+    TileRegs ta, tb;
+    int m0, n0;
+    tile_origin(t_begin, gx, gy, m0, n0);
+    int ma = tile_mode(g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs), mb = tile_mode(g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
+    tile_load(ta, ma, g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs);
+    tile_load(tb, mb, g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
+    tile_store(ta, ma, tileA(0));
+    tile_store(tb, mb, tileB(0));
+    __syncthreads();
+    // ONE software pipeline over all (tile, k-chunk) pairs of this workgroup: the next pair's global
+    // loads are in flight under the current chunk's MFMAs, and a finished tile's stores drain under
+    // the next tile's MFMAs.
+    for (int it = 0; it < total; ++it) {
+        const int cur = (NBUF == 2) ? (it & 1) : 0, c = it % n_chunks;
+        const bool more = it + 1 < total;
+        if (more) {
+            const int c1 = (it + 1) % n_chunks;
+            int m1, n1;
+            tile_origin(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
+            ma = tile_mode(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
+            mb = tile_mode(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
+            tile_load(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
+            tile_load(tb, mb, g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
+        }
+        const int kc = min(kGK, g.K - c * kGK);
+        float (*Ac)[kGLd] = tileA(cur);
+        float (*Bc)[kGLd] = tileB(cur);
+        for (int kk = 0; kk < kc; kk += 2) {
+            const float a0 = Ac[wr * 64 + lr][kk + lk], a1 = Ac[wr * 64 + 32 + lr][kk + lk];
+            const float b0 = Bc[wc * 64 + lr][kk + lk], b1 = Bc[wc * 64 + 32 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (c == n_chunks - 1) {  // tile finished: epilogue, then clear the accumulators
+            tile_origin(t_begin + it / n_chunks, gx, gy, m0, n0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + j * 32 + lr;
+                        if (m < g.M && n < g.N) {
+                            float s = acc[i][j][r];
+                            if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
+                            else if (g.col_bias) s += g.col_bias[n];
+                            if (g.relu) s = s > 0.f ? s : 0.f;
+                            if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                            g.C[(size_t)m * g.ldc + n] = s;
+                        }
+                        acc[i][j][r] = 0.f;
+                    }
+        }
+        if (NBUF == 1) __syncthreads();  // everyone is done reading the single buffer
+        if (more) {
+            tile_store(ta, ma, tileA(NBUF == 2 ? cur ^ 1 : 0));
+            tile_store(tb, mb, tileB(NBUF == 2 ? cur ^ 1 : 0));
+        }
+        __syncthreads();
+    }
+}
+
+// asynchronous launch; returns the hipError_t of the launch
+inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
+{
+    static bool attr_set = false;
+    static const int variant = getenv("RK_GEMM_VARIANT") ? atoi(getenv("RK_GEMM_VARIANT")) : 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<2, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nwg = ((g.N + kGT - 1) / kGT) * ((g.M + kGT - 1) / kGT);
+    // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
+    int tpb = (g.K <= 64) ? nwg / 1024 : 1;
+    tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+    const dim3 grid((nwg + tpb - 1) / tpb);
+    // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
+    // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
+    if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, dim3(256), kGemmLdsBytes, s, g, tpb);
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, 3>), grid, dim3(256), kGemmLdsBytes / 2, s, g, tpb);
+    return hipGetLastError();
+}

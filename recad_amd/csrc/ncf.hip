@@ -3,99 +3,16 @@
 // BCE-with-logits, embedding-gradient scatter-add and one multi-tensor dense Adam launch.
 #include <algorithm>
 
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// ---------------------------------------------------------------- strided fp32 MFMA GEMM
-// C[m,n] = sum_k A(m,k) * B(n,k)  (+ bias[n]) (relu) (masked by mask[m,n] > 0)
-// A(m,k) = A[m*a_rs + k*a_cs], B(n,k) = B[n*b_rs + k*b_cs]; k-ordered fmaf chain (MFMA f32).
-struct GemmArgs {
-    int M, N, K;
-    const float *A; long long a_rs, a_cs;
-    const float *B; long long b_rs, b_cs;
-    float *C; int ldc;
-    const float *bias;
-    const float *mask; int ldmask;
-    int relu;
-};
-
-static constexpr int kGT = 128, kGK = 32, kGLd = kGK + 1;
-
-__device__ __forceinline__ void stage_strided(float (*dst)[kGLd], const float *__restrict__ src, int n_rows, int n_k, int r0,
-                                              int k0, long long rs, long long cs)
-{
-    if (cs == 1) {  // k contiguous: consecutive threads walk k
-        for (int idx = threadIdx.x; idx < kGT * kGK; idx += 256) {
-            const int r = idx / kGK, c = idx % kGK;
-            const int gr = r0 + r, gc = k0 + c;
-            dst[r][c] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + gc] : 0.f;
-        }
-    } else {  // rows contiguous: consecutive threads walk rows
-        for (int idx = threadIdx.x; idx < kGT * kGK; idx += 256) {
-            const int c = idx / kGT, r = idx % kGT;
-            const int gr = r0 + r, gc = k0 + c;
-            dst[r][c] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + (long long)gc * cs] : 0.f;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g)
-{
-    __shared__ float As[kGT][kGLd];
-    __shared__ float Bs[kGT][kGLd];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lk = lane >> 5;
-    for (int k0 = 0; k0 < g.K; k0 += kGK) {
-        stage_strided(As, g.A, g.M, g.K, m0, k0, g.a_rs, g.a_cs);
-        stage_strided(Bs, g.B, g.N, g.K, n0, k0, g.b_rs, g.b_cs);
-        __syncthreads();
-        const int kc = min(kGK, g.K - k0);
-        for (int kk = 0; kk < kc; kk += 2) {
-            const float a0 = As[wr * 64 + lr][kk + lk], a1 = As[wr * 64 + 32 + lr][kk + lk];
-            const float b0 = Bs[wc * 64 + lr][kk + lk], b1 = Bs[wc * 64 + 32 + lr][kk + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + j * 32 + lr;
-                if (m < g.M && n < g.N) {
-                    float s = acc[i][j][r];
-                    if (g.bias) s += g.bias[n];
-                    if (g.relu) s = s > 0.f ? s : 0.f;
-                    if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
-                    g.C[(size_t)m * g.ldc + n] = s;
-                }
-            }
-}
+#include "gemm.h"
 
 static int gemm(hipStream_t s, int M, int N, int K, const float *A, long long a_rs, long long a_cs, const float *B,
                 long long b_rs, long long b_cs, float *C, int ldc, const float *bias, int relu, const float *mask, int ldmask)
 {
     GemmArgs g;
+    memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.K = K; g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
-    g.C = C; g.ldc = ldc; g.bias = bias; g.relu = relu; g.mask = mask; g.ldmask = ldmask;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + kGT - 1) / kGT, (M + kGT - 1) / kGT), dim3(256), 0, s, g);
-    RK_CHECK_LAUNCH();
+    g.C = C; g.ldc = ldc; g.col_bias = bias; g.relu = relu; g.mask = mask; g.ldmask = ldmask;
+    RK_HIP(gemm_f32_launch(g, s));
     return RK_OK;
 }
 

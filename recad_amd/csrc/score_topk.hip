@@ -6,72 +6,7 @@
 //           the K-th largest score, ordered collection, bitonic sort by (score desc, id asc).
 #include <algorithm>
 
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static constexpr int kTile = 128;  // users x items per workgroup
-static constexpr int kKC = 32;     // k-chunk staged in LDS (2 x 128 x 33 floats = 33 KiB)
-static constexpr int kLd = kKC + 1;
-
-// stage rows [r0, r0+128) x cols [k0, k0+64) of a row-major [n_rows, d] matrix, zero-filled
-__device__ __forceinline__ void stage_tile(float (*dst)[kLd], const float *__restrict__ src, int n_rows, int d, int r0, int k0)
-{
-    for (int idx = threadIdx.x; idx < kTile * kKC; idx += 256) {
-        const int r = idx / kKC, c = idx % kKC;
-        const int gr = r0 + r, gc = k0 + c;
-        dst[r][c] = (gr < n_rows && gc < d) ? src[(size_t)gr * d + gc] : 0.f;
-    }
-}
-
-__global__ __launch_bounds__(256) void score_gemm_kernel(int d, const float *__restrict__ urows, int nb,
-                                                         const float *__restrict__ itab, int n_items,
-                                                         const float *__restrict__ ubias_rows, const float *__restrict__ ibias,
-                                                         float mean, float *__restrict__ out)
-{
-    __shared__ float As[kTile][kLd];
-    __shared__ float Bs[kTile][kLd];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    const int u0 = blockIdx.y * kTile, i0 = blockIdx.x * kTile;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lk = lane >> 5;
-    for (int k0 = 0; k0 < d; k0 += kKC) {
-        stage_tile(As, urows, nb, d, u0, k0);
-        stage_tile(Bs, itab, n_items, d, i0, k0);
-        __syncthreads();
-        const int kc = min(kKC, d - k0);
-        for (int kk = 0; kk < kc; kk += 2) {
-            const float a0 = As[wr * 64 + lr][kk + lk], a1 = As[wr * 64 + 32 + lr][kk + lk];
-            const float b0 = Bs[wc * 64 + lr][kk + lk], b1 = Bs[wc * 64 + 32 + lr][kk + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int u = u0 + wr * 64 + i * 32 + row, it = i0 + wc * 64 + j * 32 + lr;
-                if (u < nb && it < n_items) {
-                    float s = acc[i][j][r];
-                    if (ibias) s = ((s + ubias_rows[u]) + ibias[it]) + mean;
-                    out[(size_t)u * n_items + it] = s;
-                }
-            }
-}
+#include "gemm.h"
 
 // ---------------------------------------------------------------- pass 2
 __device__ __forceinline__ unsigned score_key(float s)
@@ -85,6 +20,10 @@ __device__ __forceinline__ unsigned score_key(float s)
 
 static constexpr int kMaxK = 256;
 
+// LDS_ROW: the user's score row is staged once in (dynamic) LDS and every pass reads it from
+// there; the scores matrix is then left untouched.  Otherwise passes stream the row from global
+// memory / L2 and seen items are overwritten with -inf in place.
+template <bool LDS_ROW>
 __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ scores, int n_items, const int *__restrict__ user_ids,
                                                         const int *__restrict__ seen_ptr, const int *__restrict__ seen_idx, int K,
                                                         int *__restrict__ top_ids, float *__restrict__ top_scores,
@@ -96,11 +35,21 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ scor
     __shared__ int sh_i[8];
     __shared__ int wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float lds_row[];
     const int b = blockIdx.x;
-    float *row = scores + (size_t)b * n_items;
+    float *grow = scores + (size_t)b * n_items;
+    float *row = LDS_ROW ? lds_row : grow;
     const int u = user_ids[b];
     // target scores before masking (normal.py:83-85)
-    if (tid < n_targets) target_score[(size_t)b * n_targets + tid] = row[targets[tid]];
+    if (tid < n_targets) target_score[(size_t)b * n_targets + tid] = grow[targets[tid]];
+    if (LDS_ROW) {
+        if ((((uintptr_t)grow) & 15) == 0) {
+            for (int i = tid * 4; i + 3 < n_items; i += 1024) *reinterpret_cast<float4 *>(row + i) = *reinterpret_cast<const float4 *>(grow + i);
+            for (int i = (n_items & ~3) + tid; i < n_items; i += 256) row[i] = grow[i];
+        } else {
+            for (int i = tid; i < n_items; i += 256) row[i] = grow[i];
+        }
+    }
     __syncthreads();
     for (int k = seen_ptr[u] + tid; k < seen_ptr[u + 1]; k += 256) row[seen_idx[k]] = -INFINITY;
     __threadfence_block();
@@ -210,8 +159,22 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(256), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K, top_ids,
-                       top_scores, targets, n_targets, target_score, target_rank);
+    const size_t row_bytes = ((size_t)n_items * sizeof(float) + 15) & ~(size_t)15;
+    // LDS staging only pays while several workgroups still fit per CU (measured: a 138 KB row in LDS
+    // is 2.8x SLOWER than streaming it from L2 -- one 4-wave workgroup per CU); ml1m-size rows tie.
+    if (row_bytes <= 16 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            RK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_rows_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(nb), dim3(256), row_bytes, s, scores, n_items, user_ids, seen_ptr, seen_idx,
+                           K, top_ids, top_scores, targets, n_targets, target_score, target_rank);
+    } else {
+        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(nb), dim3(256), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K,
+                           top_ids, top_scores, targets, n_targets, target_score, target_rank);
+    }
     RK_CHECK_LAUNCH();
     return RK_OK;
 }
@@ -227,9 +190,14 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const i
         RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
     if ((ubias_rows == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((n_items + kTile - 1) / kTile, (nb + kTile - 1) / kTile);
-    hipLaunchKernelGGL(score_gemm_kernel, grid, dim3(256), 0, s, dim, urows, nb, itab, n_items, ubias_rows, ibias, mean, scratch);
-    RK_CHECK_LAUNCH();
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = nb; g.N = n_items; g.K = dim;
+    g.A = urows; g.a_rs = dim; g.a_cs = 1;
+    g.B = itab; g.b_rs = dim; g.b_cs = 1;
+    g.C = scratch; g.ldc = n_items;
+    g.row_bias = ubias_rows; g.col_bias = ibias; g.const_add = mean;
+    RK_HIP(gemm_f32_launch(g, s));
     return rk_topk_rows_impl(scratch, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
                              target_score, target_rank, s);
 }
