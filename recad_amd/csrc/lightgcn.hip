@@ -177,6 +177,10 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
     a.n_rows = d.n_users + d.n_items;
     a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.wave_desc = reinterpret_cast<const int4 *>(d.wave_desc); a.n_blocks = d.n_blocks;
     a.d = d.dim;
+    if (d.hot_H > 0 && d.col_tagged && d.hot_rows && d.pblocks) {
+        a.col_tagged = d.col_tagged; a.hot_rows = d.hot_rows; a.pblocks = d.pblocks;
+        a.hot_H = d.hot_H; a.nb_class0 = d.nb_class0; a.two_classes = d.two_classes;
+    }
     return a;
 }
 

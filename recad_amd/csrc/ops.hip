@@ -175,6 +175,78 @@ RK_EXPORT int rk_csr_schedule_destroy(rk_schedule_t sched)
     return RK_OK;
 }
 
+// ---- LDS hot-row tables for spmm_csr_hot_kernel (host-built once per graph and dim)
+RK_EXPORT int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                const int32_t *wave_desc, int32_t n_blocks, int32_t class_split, int32_t dim,
+                                int32_t *col_tagged, int32_t *hot_rows, int32_t *pblocks, int32_t *meta, void *stream)
+{
+    if (n_rows <= 0 || nnz < 0 || !rowptr || !col || !wave_desc || n_blocks <= 0 || dim <= 0 || !col_tagged || !hot_rows || !pblocks || !meta)
+        RK_FAIL(RK_EINVAL, "rk_spmm_hot_build: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int W = spmm_waves();
+    const int H = hot_rows_for_dim(dim);
+    std::vector<int32_t> rp((size_t)n_rows + 1), c((size_t)nnz), wd((size_t)n_blocks * W * 4);
+    RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
+    if (nnz) RK_HIP(hipMemcpyAsync(c.data(), col, sizeof(int32_t) * c.size(), hipMemcpyDeviceToHost, s));
+    RK_HIP(hipMemcpyAsync(wd.data(), wave_desc, sizeof(int32_t) * wd.size(), hipMemcpyDeviceToHost, s));
+    RK_HIP(hipStreamSynchronize(s));
+    const bool two = class_split > 0 && class_split < n_rows;
+    auto cls_of = [&](int r) { return (two && r >= class_split) ? 1 : 0; };
+    // column frequency per row class
+    std::vector<int32_t> freq[2] = {std::vector<int32_t>((size_t)n_rows, 0), std::vector<int32_t>(two ? (size_t)n_rows : 0, 0)};
+    for (int32_t r = 0; r < n_rows; ++r) {
+        std::vector<int32_t> &f = freq[cls_of(r)];
+        for (int32_t e = rp[r]; e < rp[r + 1]; ++e) f[(size_t)c[e]]++;
+    }
+    std::vector<int32_t> hot((size_t)2 * H, -1), slot[2];
+    long long hot_nnz = 0;
+    for (int k = 0; k < (two ? 2 : 1); ++k) {
+        std::vector<int32_t> ids;
+        for (int32_t n = 0; n < n_rows; ++n)
+            if (freq[k][(size_t)n] > 1) ids.push_back(n);  // a row gathered once gains nothing from LDS
+        const size_t take = std::min(ids.size(), (size_t)H);
+        std::partial_sort(ids.begin(), ids.begin() + (long)take, ids.end(), [&](int32_t x, int32_t y) {
+            return freq[k][(size_t)x] != freq[k][(size_t)y] ? freq[k][(size_t)x] > freq[k][(size_t)y] : x < y;
+        });
+        slot[k].assign((size_t)n_rows, -1);
+        for (size_t h = 0; h < take; ++h) {
+            hot[(size_t)k * H + h] = ids[h];
+            slot[k][(size_t)ids[h]] = (int32_t)h;
+            hot_nnz += freq[k][(size_t)ids[h]];
+        }
+    }
+    if (!two) for (int h = 0; h < H; ++h) hot[(size_t)H + h] = hot[(size_t)h];
+    std::vector<int32_t> tagged((size_t)nnz);
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const std::vector<int32_t> &sl = slot[cls_of(r)];
+        for (int32_t e = rp[r]; e < rp[r + 1]; ++e) {
+            const int32_t sidx = sl[(size_t)c[e]];
+            tagged[(size_t)e] = sidx >= 0 ? (int32_t)(0x80000000u | (uint32_t)sidx) : c[e];
+        }
+    }
+    // schedule workgroups by the class of their rows (a workgroup never mixes classes when class_split is used)
+    std::vector<int32_t> pb0, pb1;
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        int k = 0;
+        for (int w = 0; w < W; ++w) {
+            const int32_t r = wd[((size_t)b * W + w) * 4];
+            if (r >= 0) { k = cls_of(r); break; }
+        }
+        (k ? pb1 : pb0).push_back(b);
+    }
+    std::vector<int32_t> pbl(pb0);
+    pbl.insert(pbl.end(), pb1.begin(), pb1.end());
+    if (nnz) RK_HIP(hipMemcpyAsync(col_tagged, tagged.data(), sizeof(int32_t) * tagged.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipMemcpyAsync(hot_rows, hot.data(), sizeof(int32_t) * hot.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipMemcpyAsync(pblocks, pbl.data(), sizeof(int32_t) * pbl.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipStreamSynchronize(s));
+    meta[0] = H;
+    meta[1] = (int32_t)pb0.size();
+    meta[2] = two ? 1 : 0;
+    meta[3] = nnz ? (int32_t)(1000 * hot_nnz / nnz) : 0;  // permille of nonzeros served from LDS
+    return RK_OK;
+}
+
 // ---- D^-1/2 A D^-1/2 on device (implicit.py:259-277, fp32 like numpy>=2 computes it)
 __global__ void item_count_kernel(long long E, const int *__restrict__ ridx, int *__restrict__ icnt)
 {

@@ -10,9 +10,28 @@ class CsrGraph:
     """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the
     per-wave work schedule rk_spmm_csr uses.  Immutable after construction."""
 
-    def __init__(self, n_rows, rowptr, col, val, wave_desc, n_blocks):
+    def __init__(self, n_rows, rowptr, col, val, wave_desc, n_blocks, class_split=0):
         self.n_rows, self.rowptr, self.col, self.val = n_rows, rowptr, col, val
-        self.wave_desc, self.n_blocks = wave_desc, n_blocks
+        self.wave_desc, self.n_blocks, self.class_split = wave_desc, n_blocks, class_split
+        self._hot = {}
+
+    def hot_tables(self, dim, min_permille=150):
+        """LDS hot-row tables for the persistent SpMM (rk_spmm_hot_build), cached per dim.
+        Returns None when too few nonzeros would be served from LDS to pay for the staging."""
+        if dim not in self._hot:
+            nnz = self.col.numel()
+            H = 32768 // dim
+            tagged = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)
+            hot_rows = torch.empty(2 * H, dtype=torch.int32, device=self.device)
+            pblocks = torch.empty(self.n_blocks, dtype=torch.int32, device=self.device)
+            meta = (C.c_int32 * 4)()
+            _lib.check(_lib.lib().rk_spmm_hot_build(self.n_rows, nnz, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.wave_desc),
+                                                    self.n_blocks, self.class_split, dim, _lib.ptr(tagged), _lib.ptr(hot_rows),
+                                                    _lib.ptr(pblocks), meta, _lib.stream_ptr()), "rk_spmm_hot_build")
+            t = {"col_tagged": tagged, "hot_rows": hot_rows, "pblocks": pblocks, "H": int(meta[0]), "nb_class0": int(meta[1]),
+                 "two_classes": int(meta[2]), "permille": int(meta[3])}
+            self._hot[dim] = t if t["permille"] >= min_permille else None
+        return self._hot[dim]
 
     @property
     def nnz(self):
@@ -29,7 +48,7 @@ class CsrGraph:
         if self.rowptr.device == device:
             return self
         return CsrGraph(self.n_rows, self.rowptr.to(device), self.col.to(device), self.val.to(device),
-                        self.wave_desc.to(device), self.n_blocks)
+                        self.wave_desc.to(device), self.n_blocks, self.class_split)
 
     @staticmethod
     def _schedule(n_rows, rowptr, class_split=0):
@@ -60,7 +79,7 @@ class CsrGraph:
         _lib.check(_lib.lib().rk_coo_to_csr(n, nnz, _lib.ptr(row), _lib.ptr(col64), _lib.ptr(v), _lib.ptr(rowptr),
                                             _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()), "rk_coo_to_csr")
         desc, n_blocks = cls._schedule(n, rowptr, class_split)
-        return cls(n, rowptr, col, val, desc, n_blocks)
+        return cls(n, rowptr, col, val, desc, n_blocks, class_split)
 
     @classmethod
     def from_user_item_csr(cls, n_users, n_items, r_ptr, r_idx, device):
@@ -79,7 +98,7 @@ class CsrGraph:
                                                 _lib.ptr(col), _lib.ptr(val), _lib.ptr(tmp), _lib.stream_ptr()),
                    "rk_build_norm_adj")
         desc, n_blocks = cls._schedule(N, rowptr, n_users)
-        return cls(N, rowptr, col, val, desc, n_blocks)
+        return cls(N, rowptr, col, val, desc, n_blocks, n_users)
 
     def to_torch_coo(self):
         """The graph in the reference's own format (a coalesced torch sparse COO tensor)."""

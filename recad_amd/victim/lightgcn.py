@@ -54,6 +54,10 @@ class LightGCN(BaseVictim):
         self._handle_key = None
         self._ws = None
         self.graph_steps = 8  # steps per hipGraph replay; 0/1 = plain launches
+        # Experimental: persistent SpMM with the hottest X rows staged in LDS (spmm_csr_hot_kernel).
+        # Correct (parity-tested) but 2.5x SLOWER than the gather kernel at ml1m size (43.8 vs 17.4 us):
+        # one 16-wave workgroup per CU serialises its segments' latency chains.  Off by default.
+        self.use_lds_hot_rows = False
 
     # ------------------------------------------------------------------ C-ABI handle
     def _adam_is_default(self):
@@ -118,6 +122,8 @@ class LightGCN(BaseVictim):
         ws["coef"] = torch.zeros(2 * _lib.RK_MAX_GRAPH_STEPS, device=dev, dtype=torch.float32)
         grp = self.optimizer.param_groups[0]
         betas = grp.get("betas", (0.9, 0.999))
+        hot = g.hot_tables(d) if (self.use_lds_hot_rows and d in (32, 64, 128, 256)) else None
+        ws["hot"] = hot  # keeps the tables alive as long as the handle
         desc = _lib.LightGCNDesc(
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
             lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
@@ -129,7 +135,10 @@ class LightGCN(BaseVictim):
             m_item=_lib.ptr(si["exp_avg"]), v_item=_lib.ptr(si["exp_avg_sq"]),
             buf_a=_lib.ptr(ws["buf_a"]), buf_b=_lib.ptr(ws["buf_b"]), light=_lib.ptr(ws["light"]),
             gprop=_lib.ptr(ws["gprop"]), gego=_lib.ptr(ws["gego"]), grad=_lib.ptr(ws["grad"]),
-            state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]))
+            state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]),
+            col_tagged=_lib.ptr(hot["col_tagged"]) if hot else None, hot_rows=_lib.ptr(hot["hot_rows"]) if hot else None,
+            pblocks=_lib.ptr(hot["pblocks"]) if hot else None, hot_H=hot["H"] if hot else 0,
+            nb_class0=hot["nb_class0"] if hot else 0, two_classes=hot["two_classes"] if hot else 0)
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         self._handle, self._handle_key, self._ws = h, key, ws
