@@ -28,44 +28,48 @@ struct GemmArgs {
     const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
 };
 
-static constexpr int kGT = 128, kGK = 32, kGLd = kGK + 1;
-static constexpr int kGemmLdsBytes = 2 * 2 * kGT * kGLd * (int)sizeof(float);  // 2 buffers x (A,B)
+static constexpr int kGK = 32, kGLd = kGK + 1;
+template <int BT> constexpr int gemm_lds_bytes(int nbuf) { return nbuf * 2 * BT * kGLd * (int)sizeof(float); }
 
 // Tile rows [r0, r0+128) x k [k0, k0+32) of a strided matrix -> 16 floats per thread.
 // mode 0: scalar, bounds-checked.  mode 1: k contiguous (cs==1), float4 along k.
 // mode 2: rows contiguous (rs==1), float4 along rows.
-struct TileRegs { float v[16]; };
+template <int BT> struct TileRegs { float v[BT / 8]; };
 
+template <int BT>
 __device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, int r0, int k0, long long rs, long long cs)
 {
-    const bool full = (r0 + kGT <= n_rows) && (k0 + kGK <= n_k);
+    const bool full = (r0 + BT <= n_rows) && (k0 + kGK <= n_k);
     if (!full) return 0;
     if (cs == 1 && (rs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 1;
     if (rs == 1 && (cs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 2;
     return 0;
 }
 
-__device__ __forceinline__ void tile_load(TileRegs &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
+template <int BT>
+__device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
                                           int k0, long long rs, long long cs)
 {
     const int tid = threadIdx.x;
+    constexpr int NP = BT / 32;  // float4 loads per thread
     if (mode == 1) {  // 8 float4 per row of 32 k: thread -> (row = p*32 + tid/8, k4 = tid%8)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
             const float4 x = *reinterpret_cast<const float4 *>(src + (long long)(r0 + r) * rs + (k0 + c));
             t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
         }
-    } else if (mode == 2) {  // 32 float4 per k column of 128 rows: thread -> (k = p*8 + tid/32, row4 = tid%32)
+    } else if (mode == 2) {  // BT/4 float4 per k column of BT rows: thread -> (k = p*KP + tid/(BT/4), row4 = tid%(BT/4))
+        constexpr int RQ = BT / 4, KP = 256 / RQ;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = p * 8 + (tid >> 5), r = (tid & 31) * 4;
+        for (int p = 0; p < NP; ++p) {
+            const int c = p * KP + tid / RQ, r = (tid % RQ) * 4;
             const float4 x = *reinterpret_cast<const float4 *>(src + (long long)(k0 + c) * cs + (r0 + r));
             t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < BT / 8; ++p) {
             const int idx = p * 256 + tid;
             const int r = idx / kGK, c = idx % kGK;
             const int gr = r0 + r, gc = k0 + c;
@@ -74,24 +78,27 @@ __device__ __forceinline__ void tile_load(TileRegs &t, int mode, const float *__
     }
 }
 
-__device__ __forceinline__ void tile_store(const TileRegs &t, int mode, float (*dst)[kGLd])
+template <int BT>
+__device__ __forceinline__ void tile_store(const TileRegs<BT> &t, int mode, float (*dst)[kGLd])
 {
     const int tid = threadIdx.x;
+    constexpr int NP = BT / 32;
     if (mode == 1) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
             dst[r][c] = t.v[p * 4]; dst[r][c + 1] = t.v[p * 4 + 1]; dst[r][c + 2] = t.v[p * 4 + 2]; dst[r][c + 3] = t.v[p * 4 + 3];
         }
     } else if (mode == 2) {
+        constexpr int RQ = BT / 4, KP = 256 / RQ;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = p * 8 + (tid >> 5), r = (tid & 31) * 4;
+        for (int p = 0; p < NP; ++p) {
+            const int c = p * KP + tid / RQ, r = (tid % RQ) * 4;
             dst[r][c] = t.v[p * 4]; dst[r + 1][c] = t.v[p * 4 + 1]; dst[r + 2][c] = t.v[p * 4 + 2]; dst[r + 3][c] = t.v[p * 4 + 3];
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < BT / 8; ++p) {
             const int idx = p * 256 + tid;
             dst[idx / kGK][idx % kGK] = t.v[p];
         }
@@ -100,17 +107,21 @@ __device__ __forceinline__ void tile_store(const TileRegs &t, int mode, float (*
 
 // position `id` of the tile order -> tile origin.  Order (speed only): strips of 8 tile-rows,
 // tile-row fastest, so consecutive tiles share the B tile and the strip's A tiles stay in L2.
+template <int BT>
 __device__ __forceinline__ void tile_origin(int id, int gx, int gy, int &m0, int &n0)
 {
     const int strip = id / (8 * gx), rem = id % (8 * gx);
     const int h = min(8, gy - strip * 8);
-    m0 = (strip * 8 + rem % h) * kGT;
-    n0 = (rem / h) * kGT;
+    m0 = (strip * 8 + rem % h) * BT;
+    n0 = (rem / h) * BT;
 }
 
-template <int NBUF, int MINW>
+// BT = tile edge (128: each wave 2x2 accumulators of 32x32; 64: one accumulator per wave, for
+// skinny problems that would not fill the chip with 128-tiles).
+template <int BT, int NBUF, int MINW>
 static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs g, const int tiles_per_block)
 {
+    constexpr int kGT = BT, TA = BT / 64, WS = BT / 2;  // TA accumulators per wave and dim, WS = wave sub-tile edge
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: [buffer 0: A | B][buffer 1: A | B]
     auto tileA = [&](int buf) { return reinterpret_cast<float (*)[kGLd]>(smem + (size_t)buf * 2 * kGT * kGLd); };
@@ -127,20 +138,20 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     }
     const int t_begin = bid * tiles_per_block, t_end = min(nwg, t_begin + tiles_per_block);
     if (t_begin >= t_end) return;
-    f32x16 acc[2][2];
+    f32x16 acc[TA][TA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TA; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
     const int n_chunks = (g.K + kGK - 1) / kGK;
     const int total = (t_end - t_begin) * n_chunks;
-    TileRegs ta, tb;
+    TileRegs<BT> ta, tb;
     int m0, n0;
-    tile_origin(t_begin, gx, gy, m0, n0);
-    int ma = tile_mode(g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs), mb = tile_mode(g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
+    tile_origin<BT>(t_begin, gx, gy, m0, n0);
+    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs), mb = tile_mode<BT>(g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
     tile_load(ta, ma, g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs);
     tile_load(tb, mb, g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
     tile_store(ta, ma, tileA(0));
@@ -155,9 +166,9 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
         if (more) {
             const int c1 = (it + 1) % n_chunks;
             int m1, n1;
-            tile_origin(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
-            ma = tile_mode(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
-            mb = tile_mode(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
+            tile_origin<BT>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
+            ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
+            mb = tile_mode<BT>(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
             tile_load(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
             tile_load(tb, mb, g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
         }
@@ -165,23 +176,27 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
         float (*Ac)[kGLd] = tileA(cur);
         float (*Bc)[kGLd] = tileB(cur);
         for (int kk = 0; kk < kc; kk += 2) {
-            const float a0 = Ac[wr * 64 + lr][kk + lk], a1 = Ac[wr * 64 + 32 + lr][kk + lk];
-            const float b0 = Bc[wc * 64 + lr][kk + lk], b1 = Bc[wc * 64 + 32 + lr][kk + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TA], bv[TA];
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                av[i] = Ac[wr * WS + i * 32 + lr][kk + lk];
+                bv[i] = Bc[wc * WS + i * 32 + lr][kk + lk];
+            }
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (c == n_chunks - 1) {  // tile finished: epilogue, then clear the accumulators
-            tile_origin(t_begin + it / n_chunks, gx, gy, m0, n0);
+            tile_origin<BT>(t_begin + it / n_chunks, gx, gy, m0, n0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TA; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TA; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                        const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + j * 32 + lr;
+                        const int m = m0 + wr * WS + i * 32 + row, n = n0 + wc * WS + j * 32 + lr;
                         if (m < g.M && n < g.N) {
                             float s = acc[i][j][r];
                             if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
@@ -208,19 +223,24 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     static bool attr_set = false;
     static const int variant = getenv("RK_GEMM_VARIANT") ? atoi(getenv("RK_GEMM_VARIANT")) : 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<2, 2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<128, 2, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<128>(2));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nwg = ((g.N + kGT - 1) / kGT) * ((g.M + kGT - 1) / kGT);
+    const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
+    if (nwg128 < 384 && variant != 3) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
+        const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg), dim3(256), gemm_lds_bytes<64>(1), s, g, 1);
+        return hipGetLastError();
+    }
     // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
-    int tpb = (g.K <= 64) ? nwg / 1024 : 1;
+    int tpb = (g.K <= 64) ? nwg128 / 1024 : 1;
     tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
-    const dim3 grid((nwg + tpb - 1) / tpb);
+    const dim3 grid((nwg128 + tpb - 1) / tpb);
     // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
     // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
-    if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, dim3(256), kGemmLdsBytes, s, g, tpb);
-    else hipLaunchKernelGGL((gemm_f32_kernel<1, 3>), grid, dim3(256), kGemmLdsBytes / 2, s, g, tpb);
+    if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 2, 2>), grid, dim3(256), gemm_lds_bytes<128>(2), s, g, tpb);
+    else hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     return hipGetLastError();
 }

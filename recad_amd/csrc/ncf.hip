@@ -99,31 +99,50 @@ __global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__
     }
 }
 
-// gpw[k] = sum_b d0[b] * z[b,k], z = [ug*ig | xL]; gpb = sum_b d0[b].  One thread per k: fixed order.
-__global__ void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug, const float *__restrict__ ig,
-                                         const float *__restrict__ xl, const float *__restrict__ d0, float *gpw, float *gpb)
+// gpw[k] = sum_b d0[b] * z[b,k], z = [ug*ig | xL]; gpb = sum_b d0[b].  64 outputs x 16 row groups
+// per workgroup, combined through LDS in fixed order (deterministic).
+__global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug,
+                                                                const float *__restrict__ ig, const float *__restrict__ xl,
+                                                                const float *__restrict__ d0, float *gpw, float *gpb)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > 2 * f) return;
+    __shared__ float red[16][64];
+    const int kc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kc;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) {
-        float z;
-        if (k == 2 * f) z = 1.f;
-        else if (k < f) { long long u, i; pair_at(p, b, u, i); z = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
-        else z = xl[(size_t)b * f + (k - f)];
-        s += d0[b] * z;
+    if (k <= 2 * f) {
+        for (int b = rg; b < nb; b += 16) {
+            float z;
+            if (k == 2 * f) z = 1.f;
+            else if (k < f) { long long u, i; pair_at(p, b, u, i); z = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
+            else z = xl[(size_t)b * f + (k - f)];
+            s += d0[b] * z;
+        }
     }
-    if (k == 2 * f) gpb[0] += s; else gpw[k] += s;
+    red[rg][kc] = s;
+    __syncthreads();
+    if (rg == 0 && k <= 2 * f) {
+        float t = red[0][kc];
+        for (int q = 1; q < 16; ++q) t += red[q][kc];
+        if (k == 2 * f) gpb[0] += t; else gpw[k] += t;
+    }
 }
 
-// db[n] += sum_m dY[m,n]  (one thread per column, fixed order)
-__global__ void colsum_kernel(int M, int N, const float *__restrict__ dY, float *db)
+// db[n] += sum_m dY[m,n]: 64 columns x 16 row groups per workgroup, fixed-order LDS combine
+__global__ __launch_bounds__(1024) void colsum_kernel(int M, int N, const float *__restrict__ dY, float *db)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[16][64];
+    const int nc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nc;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n];
-    db[n] += s;
+    if (n < N)
+        for (int m = rg; m < M; m += 16) s += dY[(size_t)m * N + n];
+    red[rg][nc] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = red[0][nc];
+        for (int q = 1; q < 16; ++q) t += red[q][nc];
+        db[n] += t;
+    }
 }
 
 // g_um[u] += dX0[b, :E], g_im[i] += dX0[b, E:]
@@ -271,7 +290,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         RK_CHECK_LAUNCH();
         hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
         RK_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64), dim3(64), 0, s, p, nb, f, d.ug, d.ig, xl, d.d0,
+        hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64), dim3(1024), 0, s, p, nb, f, d.ug, d.ig, xl, d.d0,
                            d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
         RK_CHECK_LAUNCH();
         // tower backward.  dY of the top layer is masked by its own ReLU here; for the layers below
@@ -288,7 +307,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
             // dW[out,in] += dY^T X : A(m=o,k=b) = dy[b*out+o], B(n=i,k=b) = x[b*in+i]
             rc = gemm(s, out, in, nb, dy, 1, out, x, 1, in, d.grad[4 + l], in, nullptr, 0, nullptr, 0);
             if (rc) return rc;
-            hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(64), 0, s, nb, out, dy, d.grad[4 + L + l]);
+            hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(1024), 0, s, nb, out, dy, d.grad[4 + L + l]);
             RK_CHECK_LAUNCH();
             // dX[nb,in] = dY W, masked by (x > 0) for l >= 1 (x is the previous layer's ReLU output)
             rc = gemm(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, in, nullptr, 0, l >= 1 ? x : nullptr, in);
