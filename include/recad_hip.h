@@ -56,14 +56,20 @@ int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_s
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);
 
-/* Tables for the LDS hot-row SpMM (the persistent kernel keeps the 128 KiB / (4*dim) most
- * frequently gathered X rows of each row class in LDS).  Host-built once per (graph, dim);
- * synchronous.  Outputs (device): col_tagged int32[nnz] (bit 31 => LDS slot), hot_rows
- * int32[2*H] with H = 32768/dim, pblocks int32[n_blocks]; meta (host int32[4]) = {H, number of
- * class-0 workgroups, two_classes, permille of nonzeros served from LDS}. */
-int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col,
-                      const int32_t *wave_desc, int32_t n_blocks, int32_t class_split, int32_t dim,
-                      int32_t *col_tagged, int32_t *hot_rows, int32_t *pblocks, int32_t *meta, void *stream);
+/* Tables for the persistent LDS hot-row SpMM: one 16-wave workgroup per CU stages the
+ * 128 KiB / (4*dim) most frequently gathered X rows of its row class in LDS, and every wave walks
+ * a host-balanced list of work items (whole rows, or <= 256-nonzero pieces of long rows whose
+ * partial sums a second tiny launch combines).  Host-built once per (graph, dim); synchronous.
+ * _build fills meta (host int32[8]) = {H, max_items, n_long_rows, two_classes, n_pieces, grid,
+ * permille of nonzeros served from LDS, 0}; _upload writes (device) col_tagged int32[nnz] and
+ * val_hot float[nnz] (every item reordered cold-first), hot_rows int32[2*H],
+ * witems int32[grid*16*max_items*4], long_rows int32[max(1,n_long)*4]. */
+typedef struct rk_hot *rk_hot_t;
+int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
+                      int32_t class_split, int32_t dim, void *stream, rk_hot_t *out, int32_t *meta);
+int rk_spmm_hot_upload(rk_hot_t h, int32_t *col_tagged, float *val_hot, int32_t *hot_rows, int32_t *witems,
+                       int32_t *long_rows, void *stream);
+int rk_spmm_hot_destroy(rk_hot_t h);
 
 /* D^-1/2 A D^-1/2 of the bipartite user-item graph straight into CSR, on device.
  * Replaces ImplicitData.getSparseGraph, recad/dataset/implicit.py:243-298 (scipy dok/lil).
@@ -127,9 +133,11 @@ typedef struct rk_lightgcn_desc {
     float *grad;                              /* nullable: receives dLoss/dE0 [N*dim] */
     int32_t *state;                           /* device int32[16], owned by the handle's user */
     float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] */
-    /* optional LDS hot-row tables from rk_spmm_hot_build (hot_H = 0: plain gather kernel) */
-    const int32_t *col_tagged, *hot_rows, *pblocks;
-    int32_t hot_H, nb_class0, two_classes, reserved2;
+    /* optional LDS hot-row tables from rk_spmm_hot_build/_upload (hot_H = 0: plain gather kernel) */
+    const int32_t *col_tagged, *hot_rows, *witems, *long_rows;
+    const float *val_hot;
+    float *partials;                          /* float[max(1,n_pieces)*dim] scratch */
+    int32_t hot_H, max_items, n_long, two_classes, hot_grid, reserved2;
 } rk_lightgcn_desc;
 #define RK_MAX_GRAPH_STEPS 64
 

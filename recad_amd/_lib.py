@@ -37,8 +37,10 @@ class LightGCNDesc(C.Structure):
         ("m_user", C.c_void_p), ("v_user", C.c_void_p), ("m_item", C.c_void_p), ("v_item", C.c_void_p),
         ("buf_a", C.c_void_p), ("buf_b", C.c_void_p), ("light", C.c_void_p), ("gprop", C.c_void_p), ("gego", C.c_void_p),
         ("grad", C.c_void_p), ("state", C.c_void_p), ("coef", C.c_void_p),
-        ("col_tagged", C.c_void_p), ("hot_rows", C.c_void_p), ("pblocks", C.c_void_p),
-        ("hot_H", C.c_int32), ("nb_class0", C.c_int32), ("two_classes", C.c_int32), ("reserved2", C.c_int32),
+        ("col_tagged", C.c_void_p), ("hot_rows", C.c_void_p), ("witems", C.c_void_p), ("long_rows", C.c_void_p),
+        ("val_hot", C.c_void_p), ("partials", C.c_void_p),
+        ("hot_H", C.c_int32), ("max_items", C.c_int32), ("n_long", C.c_int32), ("two_classes", C.c_int32),
+        ("hot_grid", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -79,7 +81,9 @@ _SIGNATURES = {
     "rk_csr_schedule_build": [_I32, _P, _I32, _P, C.POINTER(_P), C.POINTER(_I32)],
     "rk_csr_schedule_upload": [_P, _P, _P],
     "rk_csr_schedule_destroy": [_P],
-    "rk_spmm_hot_build": [_I32, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, C.POINTER(_I32), _P],
+    "rk_spmm_hot_build": [_I32, _I64, _P, _P, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32)],
+    "rk_spmm_hot_upload": [_P, _P, _P, _P, _P, _P, _P],
+    "rk_spmm_hot_destroy": [_P],
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
     "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],

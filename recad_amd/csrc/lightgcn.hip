@@ -177,9 +177,11 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
     a.n_rows = d.n_users + d.n_items;
     a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.wave_desc = reinterpret_cast<const int4 *>(d.wave_desc); a.n_blocks = d.n_blocks;
     a.d = d.dim;
-    if (d.hot_H > 0 && d.col_tagged && d.hot_rows && d.pblocks) {
-        a.col_tagged = d.col_tagged; a.hot_rows = d.hot_rows; a.pblocks = d.pblocks;
-        a.hot_H = d.hot_H; a.nb_class0 = d.nb_class0; a.two_classes = d.two_classes;
+    if (d.hot_H > 0 && d.col_tagged && d.val_hot && d.hot_rows && d.witems && d.long_rows && d.partials && d.hot_grid > 0) {
+        a.col_tagged = d.col_tagged; a.val_hot = d.val_hot; a.hot_rows = d.hot_rows;
+        a.witems = reinterpret_cast<const int4 *>(d.witems); a.long_rows = reinterpret_cast<const int4 *>(d.long_rows);
+        a.partials = d.partials;
+        a.hot_H = d.hot_H; a.max_items = d.max_items; a.n_long = d.n_long; a.two_classes = d.two_classes; a.hot_grid = d.hot_grid;
     }
     return a;
 }

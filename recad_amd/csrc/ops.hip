@@ -175,30 +175,40 @@ RK_EXPORT int rk_csr_schedule_destroy(rk_schedule_t sched)
     return RK_OK;
 }
 
-// ---- LDS hot-row tables for spmm_csr_hot_kernel (host-built once per graph and dim)
-RK_EXPORT int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col,
-                                const int32_t *wave_desc, int32_t n_blocks, int32_t class_split, int32_t dim,
-                                int32_t *col_tagged, int32_t *hot_rows, int32_t *pblocks, int32_t *meta, void *stream)
+// ---- tables for the persistent LDS hot-row SpMM (spmm_csr_hot_kernel), host-built per (graph, dim)
+struct rk_hot {
+    std::vector<int32_t> tagged, hot, witems, long_rows;
+    std::vector<float> val;
+};
+
+RK_EXPORT int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
+                                int32_t class_split, int32_t dim, void *stream, rk_hot_t *out, int32_t *meta)
 {
-    if (n_rows <= 0 || nnz < 0 || !rowptr || !col || !wave_desc || n_blocks <= 0 || dim <= 0 || !col_tagged || !hot_rows || !pblocks || !meta)
-        RK_FAIL(RK_EINVAL, "rk_spmm_hot_build: bad arguments");
+    if (n_rows <= 0 || nnz < 0 || !rowptr || !col || !val || dim <= 0 || !out || !meta) RK_FAIL(RK_EINVAL, "rk_spmm_hot_build: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const int W = spmm_waves();
+    int dev = 0;
+    hipDeviceProp_t prop;
+    RK_HIP(hipGetDevice(&dev));
+    RK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int grid = std::max(8, (prop.multiProcessorCount / 8) * 8);
     const int H = hot_rows_for_dim(dim);
-    std::vector<int32_t> rp((size_t)n_rows + 1), c((size_t)nnz), wd((size_t)n_blocks * W * 4);
+    std::vector<int32_t> rp((size_t)n_rows + 1), c((size_t)nnz);
     RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
+    std::vector<float> v((size_t)nnz);
     if (nnz) RK_HIP(hipMemcpyAsync(c.data(), col, sizeof(int32_t) * c.size(), hipMemcpyDeviceToHost, s));
-    RK_HIP(hipMemcpyAsync(wd.data(), wave_desc, sizeof(int32_t) * wd.size(), hipMemcpyDeviceToHost, s));
+    if (nnz) RK_HIP(hipMemcpyAsync(v.data(), val, sizeof(float) * v.size(), hipMemcpyDeviceToHost, s));
     RK_HIP(hipStreamSynchronize(s));
     const bool two = class_split > 0 && class_split < n_rows;
     auto cls_of = [&](int r) { return (two && r >= class_split) ? 1 : 0; };
-    // column frequency per row class
+    rk_hot *h = new rk_hot();
+    // hot set per row class = the most frequently gathered columns of that class's rows
     std::vector<int32_t> freq[2] = {std::vector<int32_t>((size_t)n_rows, 0), std::vector<int32_t>(two ? (size_t)n_rows : 0, 0)};
     for (int32_t r = 0; r < n_rows; ++r) {
         std::vector<int32_t> &f = freq[cls_of(r)];
         for (int32_t e = rp[r]; e < rp[r + 1]; ++e) f[(size_t)c[e]]++;
     }
-    std::vector<int32_t> hot((size_t)2 * H, -1), slot[2];
+    h->hot.assign((size_t)2 * H, -1);
+    std::vector<int32_t> slot[2];
     long long hot_nnz = 0;
     for (int k = 0; k < (two ? 2 : 1); ++k) {
         std::vector<int32_t> ids;
@@ -209,41 +219,106 @@ RK_EXPORT int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowp
             return freq[k][(size_t)x] != freq[k][(size_t)y] ? freq[k][(size_t)x] > freq[k][(size_t)y] : x < y;
         });
         slot[k].assign((size_t)n_rows, -1);
-        for (size_t h = 0; h < take; ++h) {
-            hot[(size_t)k * H + h] = ids[h];
-            slot[k][(size_t)ids[h]] = (int32_t)h;
-            hot_nnz += freq[k][(size_t)ids[h]];
+        for (size_t q = 0; q < take; ++q) {
+            h->hot[(size_t)k * H + q] = ids[q];
+            slot[k][(size_t)ids[q]] = (int32_t)q;
+            hot_nnz += freq[k][(size_t)ids[q]];
         }
     }
-    if (!two) for (int h = 0; h < H; ++h) hot[(size_t)H + h] = hot[(size_t)h];
-    std::vector<int32_t> tagged((size_t)nnz);
-    for (int32_t r = 0; r < n_rows; ++r) {
+    if (!two) for (int q = 0; q < H; ++q) h->hot[(size_t)H + q] = h->hot[(size_t)q];
+    // work items: whole rows (<= kPieceNnz nonzeros) or pieces of long rows; inside an item the
+    // entries are reordered cold-first (node ids), then hot (LDS slots), each group in column order
+    h->tagged.resize((size_t)nnz);
+    h->val.resize((size_t)nnz);
+    struct Item { int32_t row, eb, ee, flag, nnz; };
+    std::vector<Item> items[2];
+    int32_t n_pieces = 0;
+    auto emit = [&](int32_t r, int32_t pb, int32_t pe, int32_t piece) {
         const std::vector<int32_t> &sl = slot[cls_of(r)];
-        for (int32_t e = rp[r]; e < rp[r + 1]; ++e) {
-            const int32_t sidx = sl[(size_t)c[e]];
-            tagged[(size_t)e] = sidx >= 0 ? (int32_t)(0x80000000u | (uint32_t)sidx) : c[e];
+        int32_t w = pb;
+        for (int32_t e = pb; e < pe; ++e)
+            if (sl[(size_t)c[e]] < 0) { h->tagged[(size_t)w] = c[e]; h->val[(size_t)w] = v[e]; ++w; }
+        const int32_t n_cold = w - pb;
+        for (int32_t e = pb; e < pe; ++e)
+            if (sl[(size_t)c[e]] >= 0) { h->tagged[(size_t)w] = sl[(size_t)c[e]]; h->val[(size_t)w] = v[e]; ++w; }
+        items[cls_of(r)].push_back({r, pb, pe, (piece << 9) | n_cold, pe - pb});
+    };
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const int32_t b = rp[r], e = rp[r + 1], nz = e - b;
+        if (nz <= kPieceNnz) { emit(r, b, e, 0); continue; }
+        const int32_t np = (nz + kPieceNnz - 1) / kPieceNnz;
+        h->long_rows.insert(h->long_rows.end(), {r, n_pieces, np, 0});
+        for (int32_t p = 0; p < np; ++p) {
+            const int32_t pb = b + p * kPieceNnz;
+            emit(r, pb, std::min(e, pb + kPieceNnz), 1 + n_pieces);
+            ++n_pieces;
         }
     }
-    // schedule workgroups by the class of their rows (a workgroup never mixes classes when class_split is used)
-    std::vector<int32_t> pb0, pb1;
-    for (int32_t b = 0; b < n_blocks; ++b) {
-        int k = 0;
-        for (int w = 0; w < W; ++w) {
-            const int32_t r = wd[((size_t)b * W + w) * 4];
-            if (r >= 0) { k = cls_of(r); break; }
+    const int n_waves = grid * kHotWaves;
+    std::vector<std::vector<Item>> lists((size_t)n_waves);
+    for (int k = 0; k < 2; ++k) {
+        // waves of the workgroups of class k (blockIdx % 8 < 4 -> class 0 when two classes)
+        std::vector<int> waves;
+        for (int b = 0; b < grid; ++b) {
+            const int bc = two ? ((b & 7) >= 4) : 0;
+            if (bc != k) continue;
+            for (int w = 0; w < kHotWaves; ++w) waves.push_back(b * kHotWaves + w);
         }
-        (k ? pb1 : pb0).push_back(b);
+        if (waves.empty() || items[k].empty()) continue;
+        std::stable_sort(items[k].begin(), items[k].end(), [](const Item &x, const Item &y) { return x.nnz > y.nnz; });
+        // longest-processing-time first on (load, wave) min-heap; +16 per item models the fixed per-item cost
+        std::vector<std::pair<long long, int>> heap;
+        for (int wv : waves) heap.push_back({0LL, wv});
+        auto cmp = [](const std::pair<long long, int> &x, const std::pair<long long, int> &y) { return x > y; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (const Item &it : items[k]) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            std::pair<long long, int> &top = heap.back();
+            lists[(size_t)top.second].push_back(it);
+            top.first += it.nnz + 16;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
     }
-    std::vector<int32_t> pbl(pb0);
-    pbl.insert(pbl.end(), pb1.begin(), pb1.end());
-    if (nnz) RK_HIP(hipMemcpyAsync(col_tagged, tagged.data(), sizeof(int32_t) * tagged.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipMemcpyAsync(hot_rows, hot.data(), sizeof(int32_t) * hot.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipMemcpyAsync(pblocks, pbl.data(), sizeof(int32_t) * pbl.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipStreamSynchronize(s));
+    size_t max_items = 1;
+    for (const auto &l : lists) max_items = std::max(max_items, l.size());
+    h->witems.assign((size_t)n_waves * max_items * 4, 0);
+    for (int wv = 0; wv < n_waves; ++wv)
+        for (size_t k = 0; k < max_items; ++k) {
+            int32_t *d = &h->witems[((size_t)wv * max_items + k) * 4];
+            if (k < lists[(size_t)wv].size()) {
+                const Item &it = lists[(size_t)wv][k];
+                d[0] = it.row; d[1] = it.eb; d[2] = it.ee; d[3] = it.flag;
+            } else d[0] = -1;
+        }
+    *out = h;
     meta[0] = H;
-    meta[1] = (int32_t)pb0.size();
-    meta[2] = two ? 1 : 0;
-    meta[3] = nnz ? (int32_t)(1000 * hot_nnz / nnz) : 0;  // permille of nonzeros served from LDS
+    meta[1] = (int32_t)max_items;
+    meta[2] = (int32_t)(h->long_rows.size() / 4);
+    meta[3] = two ? 1 : 0;
+    meta[4] = n_pieces;
+    meta[5] = grid;
+    meta[6] = nnz ? (int32_t)(1000 * hot_nnz / nnz) : 0;  // permille of nonzeros served from LDS
+    meta[7] = 0;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_spmm_hot_upload(rk_hot_t h, int32_t *col_tagged, float *val_hot, int32_t *hot_rows, int32_t *witems, int32_t *long_rows,
+                                 void *stream)
+{
+    if (!h || !col_tagged || !val_hot || !hot_rows || !witems || !long_rows) RK_FAIL(RK_EINVAL, "rk_spmm_hot_upload: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->tagged.empty()) RK_HIP(hipMemcpyAsync(col_tagged, h->tagged.data(), sizeof(int32_t) * h->tagged.size(), hipMemcpyHostToDevice, s));
+    if (!h->val.empty()) RK_HIP(hipMemcpyAsync(val_hot, h->val.data(), sizeof(float) * h->val.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipMemcpyAsync(hot_rows, h->hot.data(), sizeof(int32_t) * h->hot.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipMemcpyAsync(witems, h->witems.data(), sizeof(int32_t) * h->witems.size(), hipMemcpyHostToDevice, s));
+    if (!h->long_rows.empty()) RK_HIP(hipMemcpyAsync(long_rows, h->long_rows.data(), sizeof(int32_t) * h->long_rows.size(), hipMemcpyHostToDevice, s));
+    RK_HIP(hipStreamSynchronize(s));
+    return RK_OK;
+}
+
+RK_EXPORT int rk_spmm_hot_destroy(rk_hot_t h)
+{
+    delete h;
     return RK_OK;
 }
 

@@ -45,10 +45,13 @@ struct SpmmArgs {
     const float *x;  // [n_rows, d] row-major; n_rows*d*4 < 4 GiB (32-bit byte offsets)
     int dbg;
     // LDS hot-row variant (spmm_csr_hot_kernel); hot_H == 0 disables it
-    const int *col_tagged;  // col with bit 31 set => low bits are an LDS slot of the row's class
+    const int *col_tagged;  // per item: cold entries (node ids) first, then hot entries (LDS slots of the row's class)
+    const float *val_hot;   // values in the same (reordered) order
     const int *hot_rows;    // [2][hot_H] node ids staged in LDS by class-0 / class-1 workgroups
-    const int *pblocks;     // schedule workgroup indices: class 0 first (nb_class0), then class 1
-    int hot_H, nb_class0, two_classes;
+    const int4 *witems;     // [n_cu*16 waves][max_items] {row, e_begin, e_end, 0 | 1 + piece slot}; row -1 ends a list
+    const int4 *long_rows;  // [n_long] {row, first piece slot, n pieces, 0}
+    float *partials;        // [n_pieces][d] scratch
+    int hot_H, max_items, n_long, two_classes, hot_grid;
     SpmmEpi e;
 };
 
@@ -83,6 +86,9 @@ __device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n
         float aa = __shfl(a, src & 63, 64);
         const bool ok = src < n;
         cc = ok ? cc : 0;
+#ifdef RK_SPMM_L1TEST
+        cc &= RK_SPMM_L1TEST;  // diagnostic build: confine the gather to a few rows (L1/L2-hit ceiling)
+#endif
         av[j] = ok ? aa : 0.f;
         xv[j] = *reinterpret_cast<const float4 *>(x + (unsigned)(cc * D + sub * 4));
     }
@@ -127,9 +133,9 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
 
 // ---- LDS hot-row variant: tagged columns (bit 31) are served from the workgroup's LDS copy of the
 // hottest X rows ("LDS staging of embedding tiles"), everything else is gathered from L2 as above.
+// LDS-only gather round for the hot part of an item (col holds LDS slots there)
 template <int D, int UN>
-__device__ __forceinline__ float4 gather_round_hot(float4 acc, int c, float a, int n, int t0, const float *__restrict__ x,
-                                                   const float *hot, int grp, int sub)
+__device__ __forceinline__ float4 gather_round_lds(float4 acc, int c, float a, int n, int t0, const float *hot, int grp, int sub)
 {
     constexpr int NG = 64 / (D / 4);
     float4 xv[UN];
@@ -142,42 +148,10 @@ __device__ __forceinline__ float4 gather_round_hot(float4 acc, int c, float a, i
         const bool ok = src < n;
         cc = ok ? cc : 0;
         av[j] = ok ? aa : 0.f;
-        if (cc < 0) xv[j] = *reinterpret_cast<const float4 *>(hot + (unsigned)((cc & 0x7fffffff) * D + sub * 4));
-        else xv[j] = *reinterpret_cast<const float4 *>(x + (unsigned)(cc * D + sub * 4));
+        xv[j] = *reinterpret_cast<const float4 *>(hot + (unsigned)(cc * D + sub * 4));
     }
 #pragma unroll
     for (int j = 0; j < UN; ++j) acc = f4_fma(av[j], xv[j], acc);
-    return acc;
-}
-
-template <int D, int UNMAX>
-__device__ __forceinline__ float4 spmm_segment_hot(const int *__restrict__ col, const float *__restrict__ val, int eb, int ee,
-                                                   const float *__restrict__ x, const float *hot, int lane)
-{
-    constexpr int G = D / 4, NG = 64 / G;
-    const int grp = lane / G, sub = lane % G;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int c_next = 0;
-    float a_next = 0.f;
-    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = val[eb + lane]; }
-    for (int base = eb; base < ee; base += 64) {
-        const int n = min(64, ee - base);
-        const int c = c_next;
-        const float a = a_next;
-        c_next = 0; a_next = 0.f;
-        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = val[base + 64 + lane]; }
-        const int iters = (n + NG - 1) / NG;
-        int t = 0;
-        for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round_hot<D, UNMAX>(acc, c, a, n, t, x, hot, grp, sub);
-        const int rem = iters - t;
-        if (rem > 4) acc = gather_round_hot<D, 8>(acc, c, a, n, t, x, hot, grp, sub);
-        else if (rem > 0) acc = gather_round_hot<D, 4>(acc, c, a, n, t, x, hot, grp, sub);
-    }
-#pragma unroll
-    for (int o = G; o < 64; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-    }
     return acc;
 }
 
@@ -235,65 +209,146 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     }
 }
 
-// Persistent form: one 16-wave workgroup per CU keeps the hot X rows of its row class in LDS
-// (hot_H * D floats) and walks the schedule workgroups of that class, two (8-wave) at a time.
+// Persistent, barrier-free form ("LDS staging of embedding tiles"): one 16-wave workgroup per CU
+// stages the hot X rows of its row class in LDS once (the only barrier), then every wave walks its
+// OWN list of work items (a whole row, or a <= 256-nonzero piece of a long row) that the host
+// balanced by nonzeros.  Inside a wave the next item's descriptor, first column/value chunk and
+// epilogue operands are loaded while the current item's gathers are in flight, so the wave's
+// memory stream never drains.  Pieces of long rows store partial sums; spmm_long_combine_kernel
+// (second, tiny launch) adds them in fixed order and runs the row's epilogue.
 static constexpr int kHotWaves = 16;
 static constexpr int kHotLdsBytes = 128 * 1024;
+static constexpr int kPieceNnz = 256;
 __host__ __device__ inline int hot_rows_for_dim(int d) { return kHotLdsBytes / (4 * d); }
 
 template <int D>
 __global__ __launch_bounds__(kHotWaves * 64, 4) void spmm_csr_hot_kernel(const SpmmArgs a)
 {
-    constexpr int G = D / 4, NG = 64 / G, SW = 8;  // SW = waves per schedule workgroup
-    extern __shared__ __attribute__((aligned(16))) float hot[];  // [hot_H][D] then partials
-    float4 (*part)[G] = reinterpret_cast<float4 (*)[G]>(hot + (size_t)a.hot_H * D);
+    constexpr int G = D / 4, NG = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) float hot[];  // [hot_H][D]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane / G, sub = lane % G;
     if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
-    // class of this workgroup: XCD halves (blockIdx % 8 < 4 -> class 0), see rk_csr_schedule_build
-    const int pb = blockIdx.x, P = gridDim.x;
-    int cls = 0, ord = pb, Pc = P;
-    if (a.two_classes) {
-        cls = (pb & 7) >= 4;
-        ord = (pb >> 3) * 4 + (pb & 3);
-        Pc = P / 2;
-    }
-    const int *list = a.pblocks + (cls ? a.nb_class0 : 0);
-    const int n_list = cls ? a.n_blocks - a.nb_class0 : a.nb_class0;
-    // stage the class's hot rows: 64/G rows per wave step, 16-byte loads
-    {
+    // class of this workgroup: XCD halves (blockIdx % 8 < 4 -> class 0), as the host assumed
+    const int cls = a.two_classes ? ((blockIdx.x & 7) >= 4) : 0;
+    if (!(a.dbg & 16)) {
+        // hot_H / (16 waves * NG rows per wave step) == 8 for every D: issue all 8 index loads, then
+        // all 8 row loads, then the LDS writes -- one latency, not eight
         const int *hr = a.hot_rows + (size_t)cls * a.hot_H;
-        const int grp = lane / G, sub = lane % G;
-        for (int h = w * NG + grp; h < a.hot_H; h += kHotWaves * NG) {
-            const int r = hr[h];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r >= 0) v = *reinterpret_cast<const float4 *>(a.x + (unsigned)(r * D + sub * 4));
-            *reinterpret_cast<float4 *>(hot + (size_t)h * D + sub * 4) = v;
+        int rid[8];
+        float4 rv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int h = q * kHotWaves * NG + w * NG + grp;
+            rid[q] = h < a.hot_H ? hr[h] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rid[q] >= 0) rv[q] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(rid[q] * D + sub * 4));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int h = q * kHotWaves * NG + w * NG + grp;
+            if (h < a.hot_H) *reinterpret_cast<float4 *>(hot + (size_t)h * D + sub * 4) = rv[q];
         }
     }
     __syncthreads();
-    const int iters = (n_list + Pc * 2 - 1) / (Pc * 2);
-    for (int it = 0; it < iters; ++it) {
-        const int j = (it * Pc + ord) * 2 + (w >> 3);
-        int4 ds = make_int4(-1, 0, 0, 0);
-        if (j < n_list) ds = a.wave_desc[(size_t)list[j] * SW + (w & 7)];
-        const bool lead = ds.w > 0 && lane < G;
-        float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
-        const size_t eoff = (size_t)max(ds.x, 0) * D + (size_t)(lane % G) * 4;
-        if (lead && a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
-        if (lead && a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ds.z > ds.y) acc = spmm_segment_hot<D, 8>(a.col_tagged, a.val, ds.y, ds.z, a.x, hot, lane);
-        if (lane < G) part[w][lane] = acc;
-        __syncthreads();
-        if (lead) {
-            for (int k = 1; k < ds.w; ++k) acc = f4_add(acc, part[w + k][lane]);
-            spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
+    const int4 *items = a.witems + ((size_t)blockIdx.x * kHotWaves + w) * a.max_items;
+    // item = {row, e_begin, e_end, (piece slot + 1) << 9 | n_cold}: nonzeros [e_begin, e_begin + n_cold)
+    // are gathered from global memory, the rest of the item from the LDS copy (the host reordered
+    // every item cold-first in col_tagged / val_hot).  Pipeline registers hold the NEXT item.
+    int4 nd = items[0];
+    int nc = 0;
+    float na = 0.f;
+    float4 naddv = make_float4(0.f, 0.f, 0.f, 0.f), nsumv = naddv;
+    auto prefetch = [&](const int4 &d) {
+        nc = 0; na = 0.f;
+        if (d.x >= 0) {
+            if (d.y + lane < d.z) { nc = a.col_tagged[d.y + lane]; na = a.val_hot[d.y + lane]; }
+            if ((d.w >> 9) == 0 && lane < G) {  // whole row: epilogue operands
+                const size_t eoff = (size_t)d.x * D + (size_t)sub * 4;
+                if (a.e.add) naddv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+                if (a.e.sum_out) nsumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+            }
         }
-        __syncthreads();
+    };
+    if (!(a.dbg & 32)) prefetch(nd);
+    for (int k = 0; k < a.max_items; ++k) {
+        const int4 ds = nd;
+        if (ds.x < 0 || (a.dbg & 32)) break;
+        const int c0 = nc;
+        const float a0 = na;
+        const float4 addv = naddv, sumv = nsumv;
+        nd = (k + 1 < a.max_items) ? items[k + 1] : make_int4(-1, 0, 0, 0);
+        prefetch(nd);
+        const int em = ds.y + (ds.w & 511), piece = ds.w >> 9;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (c0, a0) hold entries [ds.y, ds.y + 64) of the item, cold and hot alike
+        for (int base = ds.y; base < ds.z; base += 64) {
+            int c = c0;
+            float av = a0;
+            if (base != ds.y) {
+                c = 0; av = 0.f;
+                if (base + lane < ds.z) { c = a.col_tagged[base + lane]; av = a.val_hot[base + lane]; }
+            }
+            // cold entries of this chunk: [base, min(base+64, em)); hot: the rest up to ds.z
+            const int n_all = min(64, ds.z - base);
+            const int n_cold = max(0, min(64, em - base));
+            if (n_cold > 0) {
+                const int iters = (n_cold + NG - 1) / NG;
+                int t = 0;
+                for (; t + 8 <= iters; t += 8) acc = gather_round<D, 8>(acc, c, av, n_cold, t, a.x, grp, sub);
+                const int rem = iters - t;
+                if (rem > 4) acc = gather_round<D, 8>(acc, c, av, n_cold, t, a.x, grp, sub);
+                else if (rem > 0) acc = gather_round<D, 4>(acc, c, av, n_cold, t, a.x, grp, sub);
+            }
+            if (n_all > n_cold) {
+                // hot entries sit at chunk positions [n_cold, n_all): rotate so they start at lane 0
+                const int hc = __shfl(c, (lane + n_cold) & 63, 64);
+                const float ha = __shfl(av, (lane + n_cold) & 63, 64);
+                const int n_hot = n_all - n_cold;
+                const int iters = (n_hot + NG - 1) / NG;
+                int t = 0;
+                for (; t + 8 <= iters; t += 8) acc = gather_round_lds<D, 8>(acc, hc, ha, n_hot, t, hot, grp, sub);
+                const int rem = iters - t;
+                if (rem > 4) acc = gather_round_lds<D, 8>(acc, hc, ha, n_hot, t, hot, grp, sub);
+                else if (rem > 0) acc = gather_round_lds<D, 4>(acc, hc, ha, n_hot, t, hot, grp, sub);
+            }
+        }
+#pragma unroll
+        for (int o = G; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (lane < G) {
+            if (piece == 0) spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
+            else *reinterpret_cast<float4 *>(a.partials + (size_t)(piece - 1) * D + (size_t)sub * 4) = acc;
+        }
     }
+}
+
+// long rows: one wave per row adds the pieces' partial sums in piece order, then the epilogue
+template <int D>
+__global__ __launch_bounds__(256) void spmm_long_combine_kernel(const SpmmArgs a)
+{
+    constexpr int G = D / 4;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n_long || lane >= G) return;
+    const int4 lr = a.long_rows[i];  // {row, first piece slot, n pieces, -}
+    const size_t eoff = (size_t)lr.x * D + (size_t)lane * 4;
+    float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
+    if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+    if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+    float4 acc = *reinterpret_cast<const float4 *>(a.partials + (size_t)lr.y * D + (size_t)lane * 4);
+    for (int p = 1; p < lr.z; ++p) acc = f4_add(acc, *reinterpret_cast<const float4 *>(a.partials + (size_t)(lr.y + p) * D + (size_t)lane * 4));
+    SpmmEpi e = a.e;
+    e.bump = 0;
+    spmm_epilogue<D>(e, lr.x, lane, acc, addv, sumv);
 }
 
 // Any d (<= 512): one X row per wave step, lanes stride over the row.  Same schedule and
@@ -355,28 +410,25 @@ inline hipError_t spmm_launch(const SpmmArgs &a, hipStream_t s)
     if (a.n_rows <= 0) return hipSuccess;
     const int W = spmm_waves();
     static const int hot_off = getenv("RK_SPMM_NO_HOT") ? atoi(getenv("RK_SPMM_NO_HOT")) : 0;
-    if (a.hot_H > 0 && !hot_off && W == 8 && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
-        static int n_cu = 0;
+    static const int dbg0 = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
+    const_cast<SpmmArgs &>(a).dbg = dbg0;
+    if (a.hot_H > 0 && !hot_off && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
         static bool attr_set = false;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t p;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-            n_cu = (p.multiProcessorCount / 8) * 8;
-            if (n_cu < 8) n_cu = 8;
+        if (!attr_set) {
+            const int lim = 160 * 1024 - 256;
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return hipErrorUnknown;
+            attr_set = true;
         }
-        const size_t lds = (size_t)a.hot_H * a.d * 4 + (size_t)kHotWaves * (a.d / 4) * 16;
-#define RK_HOT_CASE(D)                                                                                          \
-    {                                                                                                           \
-        if (!attr_set) {                                                                                        \
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
-            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
-            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return hipErrorUnknown; \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        hipLaunchKernelGGL(spmm_csr_hot_kernel<D>, dim3(n_cu), dim3(kHotWaves * 64), lds, s, a);               \
+        const size_t lds = (size_t)a.hot_H * a.d * 4;
+        const dim3 cg((a.n_long + 3) / 4);
+#define RK_HOT_CASE(D)                                                                                     \
+    {                                                                                                      \
+        hipLaunchKernelGGL(spmm_csr_hot_kernel<D>, dim3(a.hot_grid), dim3(kHotWaves * 64), lds, s, a);     \
+        if (a.n_long > 0) hipLaunchKernelGGL(spmm_long_combine_kernel<D>, cg, dim3(256), 0, s, a);         \
     }
         switch (a.d) {
             case 32: RK_HOT_CASE(32) break;

@@ -16,21 +16,26 @@ class CsrGraph:
         self._hot = {}
 
     def hot_tables(self, dim, min_permille=150):
-        """LDS hot-row tables for the persistent SpMM (rk_spmm_hot_build), cached per dim.
-        Returns None when too few nonzeros would be served from LDS to pay for the staging."""
+        """Tables of the persistent LDS hot-row SpMM (rk_spmm_hot_build/_upload), cached per dim.
+        None when too few nonzeros would be served from LDS to pay for the staging."""
         if dim not in self._hot:
             nnz = self.col.numel()
-            H = 32768 // dim
-            tagged = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)
-            hot_rows = torch.empty(2 * H, dtype=torch.int32, device=self.device)
-            pblocks = torch.empty(self.n_blocks, dtype=torch.int32, device=self.device)
-            meta = (C.c_int32 * 4)()
-            _lib.check(_lib.lib().rk_spmm_hot_build(self.n_rows, nnz, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.wave_desc),
-                                                    self.n_blocks, self.class_split, dim, _lib.ptr(tagged), _lib.ptr(hot_rows),
-                                                    _lib.ptr(pblocks), meta, _lib.stream_ptr()), "rk_spmm_hot_build")
-            t = {"col_tagged": tagged, "hot_rows": hot_rows, "pblocks": pblocks, "H": int(meta[0]), "nb_class0": int(meta[1]),
-                 "two_classes": int(meta[2]), "permille": int(meta[3])}
-            self._hot[dim] = t if t["permille"] >= min_permille else None
+            h, meta = C.c_void_p(), (C.c_int32 * 8)()
+            _lib.check(_lib.lib().rk_spmm_hot_build(self.n_rows, nnz, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val), self.class_split,
+                                                    dim, _lib.stream_ptr(), C.byref(h), meta), "rk_spmm_hot_build")
+            try:
+                H, max_items, n_long, two, n_pieces, grid, permille = (int(meta[k]) for k in range(7))
+                t = None
+                if permille >= min_permille:
+                    i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+                    t = {"col_tagged": i32(nnz), "val_hot": torch.empty(max(nnz, 1), device=self.device), "hot_rows": i32(2 * H), "witems": i32(grid * 16 * max_items * 4),
+                         "long_rows": i32(n_long * 4), "partials": torch.zeros(max(n_pieces, 1) * dim, device=self.device),
+                         "H": H, "max_items": max_items, "n_long": n_long, "two_classes": two, "grid": grid, "permille": permille}
+                    _lib.check(_lib.lib().rk_spmm_hot_upload(h, _lib.ptr(t["col_tagged"]), _lib.ptr(t["val_hot"]), _lib.ptr(t["hot_rows"]), _lib.ptr(t["witems"]),
+                                                             _lib.ptr(t["long_rows"]), _lib.stream_ptr()), "rk_spmm_hot_upload")
+                self._hot[dim] = t
+            finally:
+                _lib.lib().rk_spmm_hot_destroy(h)
         return self._hot[dim]
 
     @property

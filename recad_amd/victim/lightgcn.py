@@ -137,8 +137,11 @@ class LightGCN(BaseVictim):
             gprop=_lib.ptr(ws["gprop"]), gego=_lib.ptr(ws["gego"]), grad=_lib.ptr(ws["grad"]),
             state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]),
             col_tagged=_lib.ptr(hot["col_tagged"]) if hot else None, hot_rows=_lib.ptr(hot["hot_rows"]) if hot else None,
-            pblocks=_lib.ptr(hot["pblocks"]) if hot else None, hot_H=hot["H"] if hot else 0,
-            nb_class0=hot["nb_class0"] if hot else 0, two_classes=hot["two_classes"] if hot else 0)
+            witems=_lib.ptr(hot["witems"]) if hot else None, long_rows=_lib.ptr(hot["long_rows"]) if hot else None,
+            val_hot=_lib.ptr(hot["val_hot"]) if hot else None,
+            partials=_lib.ptr(hot["partials"]) if hot else None, hot_H=hot["H"] if hot else 0,
+            max_items=hot["max_items"] if hot else 0, n_long=hot["n_long"] if hot else 0,
+            two_classes=hot["two_classes"] if hot else 0, hot_grid=hot["grid"] if hot else 0)
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         self._handle, self._handle_key, self._ws = h, key, ws
