@@ -44,15 +44,19 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
                   float *val /*[nnz]*/, void *stream);
 
 /* Work schedule for rk_spmm_csr (load balance for power-law rows): every row is cut into
- * segments of <= 64 nonzeros, whole rows are packed into workgroups of 16 segments (first-fit
- * decreasing), rows with more than 1024 nonzeros get a workgroup of their own.  Built on the
- * host once per graph (reads rowptr back: synchronous).  Two calls: _build returns the number
- * of workgroups, _upload writes the per-wave descriptors int32[n_blocks*16*4] to the device.
+ * segments of <= 64 nonzeros; whole rows are packed into workgroups of 8 waves (best-fit
+ * decreasing), one segment per wave; a row with more than 8 segments is cut into pieces of 8
+ * segments, one workgroup each, whose partial sums meet in scratch slots -- the last workgroup
+ * of a row to arrive (agent-scope ticket) adds them in piece order and runs the epilogue.
+ * Built on the host once per graph (reads rowptr back: synchronous).  _build returns the number of
+ * workgroups and the size in int32 words of the device buffer `wave_desc` that _upload fills:
+ * wave descriptors, workgroup metas, arrival counters and the partial-sum slots (max_dim floats
+ * each; max_dim bounds the `dim` the schedule can be used with).
  * class_split > 0 (= n_users for the bipartite adjacency): rows < split and rows >= split are
  * scheduled separately and interleaved 4:4 over the 8 XCDs so each XCD L2 holds one table. */
 typedef struct rk_schedule *rk_schedule_t;
-int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, void *stream,
-                          rk_schedule_t *out, int32_t *n_blocks);
+int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t max_dim, void *stream,
+                          rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words);
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);
 
@@ -138,6 +142,9 @@ typedef struct rk_lightgcn_desc {
     const float *val_hot;
     float *partials;                          /* float[max(1,n_pieces)*dim] scratch */
     int32_t hot_H, max_items, n_long, two_classes, hot_grid, reserved2;
+    /* optional: device uint32[(N+31)/32] bitmap of the current minibatch's rows; when given (and
+     * n_layers >= 2) the last forward layer computes only those rows of `light` */
+    uint32_t *row_bits;
 } rk_lightgcn_desc;
 #define RK_MAX_GRAPH_STEPS 64
 

@@ -41,6 +41,7 @@ class LightGCNDesc(C.Structure):
         ("val_hot", C.c_void_p), ("partials", C.c_void_p),
         ("hot_H", C.c_int32), ("max_items", C.c_int32), ("n_long", C.c_int32), ("two_classes", C.c_int32),
         ("hot_grid", C.c_int32), ("reserved2", C.c_int32),
+        ("row_bits", C.c_void_p),
     ]
 
 
@@ -78,7 +79,7 @@ _SIGNATURES = {
     "rk_last_error": [],
     "rk_device_info": [C.c_char_p, _I32, C.POINTER(_I32)],
     "rk_coo_to_csr": [_I32, _I64, _P, _P, _P, _P, _P, _P, _P],
-    "rk_csr_schedule_build": [_I32, _P, _I32, _P, C.POINTER(_P), C.POINTER(_I32)],
+    "rk_csr_schedule_build": [_I32, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32), C.POINTER(_I64)],
     "rk_csr_schedule_upload": [_P, _P, _P],
     "rk_csr_schedule_destroy": [_P],
     "rk_spmm_hot_build": [_I32, _I64, _P, _P, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32)],

@@ -135,7 +135,7 @@ RK_EXPORT int rk_adam_step(int64_t n, float *param, const float *grad, float *m,
 static int check_desc(const rk_lightgcn_desc &d)
 {
     if (d.n_users <= 0 || d.n_items <= 0 || d.dim <= 0 || d.n_layers < 0) RK_FAIL(RK_EINVAL, "lightgcn: bad sizes");
-    if (d.dim > 512) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 512 unsupported", d.dim);
+    if (d.dim > 256) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 256 unsupported (long-row scratch slots are 256 floats)", d.dim);
     if (!d.rowptr || !d.col || !d.val || !d.wave_desc || d.n_blocks <= 0) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
     if (!d.user_emb || !d.item_emb || !d.m_user || !d.v_user || !d.m_item || !d.v_item)
         RK_FAIL(RK_EINVAL, "lightgcn: parameter/moment pointers missing");
@@ -188,7 +188,14 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
 
 
 // forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
-static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s)
+struct BatchRef {
+    const int64_t *users, *pos, *neg;
+    int k;
+};
+
+// forward: light = mean_l A^l E0.  With a BatchRef (training) the first layer marks the minibatch's
+// rows in d.row_bits and the last layer computes only those rows of `light`.
+static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchRef *batch = nullptr)
 {
     const int N = d.n_users + d.n_items, L = d.n_layers;
     const float inv = 1.0f / (float)(L + 1);
@@ -206,6 +213,13 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s)
         a.e.sum_in = (l == 1) ? d.user_emb : d.light;
         a.e.sum_out = d.light;
         a.e.sum_scale = (l == L) ? inv : 1.0f;
+        if (batch && d.row_bits && L >= 2) {
+            if (l == 1) {
+                a.mark_bits = d.row_bits; a.mark_U = d.n_users; a.mark_k = batch->k; a.mark_state = d.state;
+                a.mark_users = batch->users; a.mark_pos = batch->pos; a.mark_neg = batch->neg;
+            }
+            if (l == L) a.row_filter = d.row_bits;
+        }
         RK_HIP(spmm_launch(a, s));
     }
     return RK_OK;
@@ -232,6 +246,9 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
         SpmmArgs a = base_args(d);
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
         const bool last = (j == L);
+        if (d.row_bits && L >= 2) {
+            if (last) { a.clear_bits = d.row_bits; a.n_words = (N + 31) / 32; }
+        }
         a.e.add = last ? d.gego : d.gprop;
         if (last) {
             a.e.zero1 = d.gego;
@@ -249,7 +266,8 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
 static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const int64_t *pos, const int64_t *neg,
                        float *loss_partials, int k, int apply_update, int bump, hipStream_t s)
 {
-    int rc = launch_forward(d, s);
+    const BatchRef br{users, pos, neg, k};
+    int rc = launch_forward(d, s, &br);
     if (rc) return rc;
     BprArgs b;
     b.U = d.n_users; b.d = d.dim; b.L = d.n_layers; b.lam = d.lambda;
@@ -286,6 +304,7 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     // scatter targets start (and, by the self-cleaning epilogues, stay) zero
     RK_HIP(hipMemsetAsync(d.gprop, 0, sizeof(float) * (size_t)N * d.dim, s));
     RK_HIP(hipMemsetAsync(d.gego, 0, sizeof(float) * (size_t)N * d.dim, s));
+    if (d.row_bits) RK_HIP(hipMemsetAsync(d.row_bits, 0, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(1), 0, s, d.state, 0, adam_t0, (long long)n, batch);
     RK_CHECK_LAUNCH();
 
@@ -335,7 +354,7 @@ RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_
                              const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x, int64_t x_rows,
                              const rk_spmm_epilogue *epi, void *stream)
 {
-    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !epi)
+    if (n_rows <= 0 || dim <= 0 || dim > 256 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !epi)
         RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: bad arguments");
     if ((size_t)x_rows * dim * sizeof(float) >= (1ULL << 32)) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: x_rows*dim*4 must be < 4 GiB");
     hipStream_t s = (hipStream_t)stream;

@@ -62,14 +62,19 @@ RK_EXPORT int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row,
 
 // ---- SpMM work schedule (see spmm.h)
 struct rk_schedule {
-    std::vector<int32_t> desc;  // int4 per wave: {row, e_begin, e_end, n_segments if leader else 0}
-    int32_t n_blocks = 0;
+    std::vector<int32_t> desc;   // int4 per wave: {row, e_begin, e_end, n_segments if leader else 0}
+    std::vector<int32_t> bmeta;  // int4 per workgroup: {n_pieces, piece index, first slot, counter index}; zeros = whole rows
+    int32_t n_blocks = 0, n_long = 0, n_slots = 0, max_dim = 0;
+    size_t words() const
+    {
+        return desc.size() + 4 + bmeta.size() + (size_t)((n_long + 3) & ~3) + (size_t)n_slots * (size_t)max_dim;
+    }
 };
 
-RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, void *stream,
-                                    rk_schedule_t *out, int32_t *n_blocks)
+RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t max_dim, void *stream,
+                                    rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words)
 {
-    if (n_rows <= 0 || !rowptr || !out || !n_blocks || class_split < 0 || class_split > n_rows)
+    if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || class_split < 0 || class_split > n_rows || max_dim <= 0 || max_dim > 512)
         RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     std::vector<int32_t> rp((size_t)n_rows + 1);
@@ -90,13 +95,16 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     // class_split > 0 the rows < split (users) and >= split (items) are scheduled into separate
     // workgroup lists that are then interleaved 4:4 per group of 8, so an XCD's L2 only ever
     // fetches ONE of the two embedding tables (speed only; any placement is correct).
-    std::vector<int32_t> cls[2];
+    std::vector<int32_t> cls[2], clsm[2];
+    int32_t n_long = 0, n_slots = 0;
     for (int pass = 0; pass < 2; ++pass) {
     std::vector<int32_t> &d = cls[pass];
+    std::vector<int32_t> &dm = clsm[pass];
     auto new_block = [&]() {
         const size_t base = d.size();
         d.resize(base + (size_t)kSpmmWaves * 4, 0);
         for (int w = 0; w < kSpmmWaves; ++w) d[base + (size_t)w * 4] = -1;
+        dm.resize(dm.size() + 4, 0);
         return base;
     };
     // open workgroups by free wave count: free_list[k] = blocks with exactly k free waves
@@ -106,17 +114,25 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
         if ((class_split > 0 && r >= class_split) != (pass == 1)) continue;
         const int32_t b = rp[r], e = rp[r + 1], nnz = e - b;
         int32_t nseg = std::max(1, (nnz + seg_nnz - 1) / seg_nnz);
-        if (nseg > kSpmmWaves) {  // long row: own workgroup, waves loop over ceil(nnz/16) nonzeros each
-            const size_t base = new_block();
-            int32_t chunk = (nnz + kSpmmWaves - 1) / kSpmmWaves;
-            chunk = (chunk + 3) & ~3;
-            for (int w = 0; w < kSpmmWaves; ++w) {
-                const int32_t eb = std::min(e, b + w * chunk), ee = std::min(e, eb + chunk);
-                d[base + (size_t)w * 4 + 0] = r;
-                d[base + (size_t)w * 4 + 1] = eb;
-                d[base + (size_t)w * 4 + 2] = ee;
-                d[base + (size_t)w * 4 + 3] = (w == 0) ? kSpmmWaves : 0;
+        if (nseg > kSpmmWaves) {
+            // long row: ceil(nseg / W) workgroups, each a "piece" of W segments; the pieces' partial sums
+            // meet in scratch slots and the last workgroup to arrive adds them in piece order
+            const int32_t np = (nseg + kSpmmWaves - 1) / kSpmmWaves;
+            for (int32_t p = 0; p < np; ++p) {
+                const size_t base = new_block();
+                const int32_t s0 = p * kSpmmWaves, s1 = std::min(nseg, s0 + kSpmmWaves);
+                for (int32_t sgi = s0; sgi < s1; ++sgi) {
+                    const size_t o = base + (size_t)(sgi - s0) * 4;
+                    d[o + 0] = r;
+                    d[o + 1] = std::min(e, b + sgi * seg_nnz);
+                    d[o + 2] = std::min(e, b + (sgi + 1) * seg_nnz);
+                    d[o + 3] = (sgi == s0) ? (s1 - s0) : 0;
+                }
+                int32_t *m = &dm[dm.size() - 4];
+                m[0] = np; m[1] = p; m[2] = n_slots; m[3] = n_long;
             }
+            n_slots += np;
+            ++n_long;
             continue;
         }
         // best fit: the open workgroup with the fewest free waves that still fits
@@ -150,13 +166,17 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
         if (want1 && i1 >= nb1) want1 = false;
         if (!want1 && i0 >= nb0) want1 = true;
         const std::vector<int32_t> &src = want1 ? cls[1] : cls[0];
+        const std::vector<int32_t> &srcm = want1 ? clsm[1] : clsm[0];
         size_t &idx = want1 ? i1 : i0;
         d.insert(d.end(), src.begin() + (long)(idx * bw), src.begin() + (long)((idx + 1) * bw));
+        sc->bmeta.insert(sc->bmeta.end(), srcm.begin() + (long)(idx * 4), srcm.begin() + (long)((idx + 1) * 4));
         ++idx;
     }
     sc->n_blocks = (int32_t)(d.size() / bw);
+    sc->n_long = n_long; sc->n_slots = n_slots; sc->max_dim = max_dim;
     *out = sc;
     *n_blocks = sc->n_blocks;
+    *n_words = (int64_t)sc->words();
     return RK_OK;
 }
 
@@ -164,7 +184,13 @@ RK_EXPORT int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, vo
 {
     if (!sched || !wave_desc) RK_FAIL(RK_EINVAL, "rk_csr_schedule_upload: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    RK_HIP(hipMemcpyAsync(wave_desc, sched->desc.data(), sizeof(int32_t) * sched->desc.size(), hipMemcpyHostToDevice, s));
+    // layout: [wave descriptors][header {n_long, n_slots, max_dim, 0}][workgroup metas][counters][partial slots]
+    std::vector<int32_t> head(sched->desc);
+    const int32_t hdr[4] = {sched->n_long, sched->n_slots, sched->max_dim, 0};
+    head.insert(head.end(), hdr, hdr + 4);
+    head.insert(head.end(), sched->bmeta.begin(), sched->bmeta.end());
+    head.resize(head.size() + (size_t)((sched->n_long + 3) & ~3), 0);  // arrival counters start at zero
+    RK_HIP(hipMemcpyAsync(wave_desc, head.data(), sizeof(int32_t) * head.size(), hipMemcpyHostToDevice, s));
     RK_HIP(hipStreamSynchronize(s));
     return RK_OK;
 }
@@ -478,7 +504,7 @@ RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *
                           const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
                           const float *add, float *y, void *stream)
 {
-    if (n_rows <= 0 || dim <= 0 || dim > 512 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !y)
+    if (n_rows <= 0 || dim <= 0 || dim > 256 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !y)
         RK_FAIL(RK_EINVAL, "rk_spmm_csr: bad arguments");
     SpmmArgs a;
     memset(&a, 0, sizeof(a));

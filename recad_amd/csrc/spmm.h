@@ -52,6 +52,16 @@ struct SpmmArgs {
     const int4 *long_rows;  // [n_long] {row, first piece slot, n pieces, 0}
     float *partials;        // [n_pieces][d] scratch
     int hot_H, max_items, n_long, two_classes, hot_grid;
+    // Batch sparsity of a train step (bitmap over node rows, bit r = row r is a user/pos/neg row of
+    // this step's minibatch): the last forward layer only needs those rows of `light`.  (Skipping
+    // the gathers of all-zero gradient rows in the first backward layer was measured too: the
+    // predicated loads cost more than they save, 26.0 vs 18.1 us.)
+    const unsigned *row_filter;  // skip rows whose bit is clear (outputs not written)
+    unsigned *mark_bits;         // set the bits of the current minibatch (first forward layer)
+    unsigned *clear_bits;        // zero the bitmap (last backward layer)
+    int n_words, mark_U, mark_k;
+    const int64_t *mark_users, *mark_pos, *mark_neg;
+    const int *mark_state;
     SpmmEpi e;
 };
 
@@ -182,6 +192,69 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmEpi &e, int r, int sub, 
     }
 }
 
+// ---- long rows: pieces (one workgroup each) meet in scratch slots; the last to arrive combines.
+// Hand-off form (cdna_hip_programming.md G16 / MI355X_MICROARCH.md "Valid forms"): the payload is
+// written with 8-byte agent-scope atomic stores (write-through, sc1) by ONE wave, that wave drains
+// vmcnt, one lane draws a ticket with a relaxed agent-scope fetch_add, and the wave whose add
+// returned n_pieces-1 reads every slot with 8-byte agent-scope atomic loads (sc1) after the add
+// has returned.  No fence, no placement assumption; summation in piece order => deterministic.
+struct PieceRef {
+    int4 meta;            // {n_pieces, piece index, first slot, counter index}
+    float *partials;      // slot s at partials + s * stride
+    int *counters;
+    int stride;
+};
+
+__device__ __forceinline__ PieceRef piece_ref(const int4 *wave_desc, int n_blocks, int waves, int block)
+{
+    const int4 *hdr = wave_desc + (size_t)n_blocks * waves;  // {n_long, n_slots, max_dim, 0}
+    PieceRef p;
+    p.meta = hdr[1 + block];
+    const int4 h = hdr[0];
+    int *cnt = reinterpret_cast<int *>(const_cast<int4 *>(hdr + 1 + n_blocks));
+    p.counters = cnt;
+    p.partials = reinterpret_cast<float *>(cnt + ((h.x + 3) & ~3));
+    p.stride = h.z;
+    return p;
+}
+
+typedef unsigned long long u64_t;
+__device__ __forceinline__ void slot_store(float *slot, int sub, float4 v)
+{
+    u64_t *q = reinterpret_cast<u64_t *>(slot + sub * 4);
+    const u64_t lo = ((u64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const u64_t hi = ((u64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 slot_load(const float *slot, int sub)
+{
+    u64_t *q = reinterpret_cast<u64_t *>(const_cast<float *>(slot) + sub * 4);
+    const u64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                       __uint_as_float((unsigned)(hi >> 32)));
+}
+
+// Called by the piece's leader wave (all 64 lanes; lanes >= g_lanes carry no data).  Returns true
+// in the wave that arrived last, with `acc` replaced by the row's total.
+__device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_lanes, float4 &acc)
+{
+    if (lane < g_lanes) slot_store(p.partials + (size_t)(p.meta.z + p.meta.y) * p.stride, lane, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(p.counters + p.meta.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket != p.meta.x - 1) return false;
+    if (lane == 0) __hip_atomic_store(p.counters + p.meta.w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    if (lane < g_lanes) {
+        float4 t = slot_load(p.partials + (size_t)p.meta.z * p.stride, lane);
+        for (int q = 1; q < p.meta.x; ++q) t = f4_add(t, slot_load(p.partials + (size_t)(p.meta.z + q) * p.stride, lane));
+        acc = t;
+    }
+    return true;
+}
+
 template <int D, int UNMAX, int WAVES, int MINW>
 __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmArgs a)
 {
@@ -192,20 +265,42 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
-    const int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
-    const bool lead = ds.w > 0 && lane < G;
-    // epilogue operands do not depend on the gather: fetch them first so their latency hides
-    float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
-    const size_t eoff = (size_t)max(ds.x, 0) * D + (size_t)(lane % G) * 4;
-    if (lead && a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
-    if (lead && a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+    if (a.clear_bits)
+        for (int i = blockIdx.x * (WAVES * 64) + threadIdx.x; i < a.n_words; i += gridDim.x * WAVES * 64) a.clear_bits[i] = 0u;
+    if (a.mark_bits) {  // rows of this step's minibatch; consumed two launches later
+        const int step = a.mark_state[ST_STEP_BASE] + a.mark_k;
+        const long long ntrip = ((long long)(unsigned)a.mark_state[ST_NTRIP_LO]) | ((long long)a.mark_state[ST_NTRIP_HI] << 32);
+        const int B = a.mark_state[ST_BATCH];
+        const long long off = (long long)step * B;
+        const int nb = (int)max(0LL, min((long long)B, ntrip - off));
+        for (int b = blockIdx.x * (WAVES * 64) + threadIdx.x; b < nb; b += gridDim.x * WAVES * 64) {
+            const int r0 = (int)a.mark_users[off + b], r1 = a.mark_U + (int)a.mark_pos[off + b], r2 = a.mark_U + (int)a.mark_neg[off + b];
+            atomicOr(&a.mark_bits[r0 >> 5], 1u << (r0 & 31));
+            atomicOr(&a.mark_bits[r1 >> 5], 1u << (r1 & 31));
+            atomicOr(&a.mark_bits[r2 >> 5], 1u << (r2 & 31));
+        }
+    }
+    int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
+    const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x);  // scalar loads, in flight under the gather
+    if (a.row_filter && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ds.z > ds.y && !(a.dbg & 1)) acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane);
+    if (ds.z > ds.y && !(a.dbg & 1)) {
+        acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane);
+    }
     if (lane < G) part[w][lane] = acc;
     __syncthreads();
-    if (lead && !(a.dbg & 2)) {
-        for (int k = 1; k < ds.w; ++k) acc = f4_add(acc, part[w + k][lane]);
-        spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
+    if (ds.w > 0 && !(a.dbg & 2)) {  // leader wave of a row (or of a long row's piece), whole wave
+        if (lane < G)
+            for (int k = 1; k < ds.w; ++k) acc = f4_add(acc, part[w + k][lane]);
+        bool fin = true;
+        if (pr.meta.x > 0) fin = piece_arrive(pr, lane, G, acc);
+        if (fin && lane < G) {
+            float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
+            const size_t eoff = (size_t)ds.x * D + (size_t)lane * 4;
+            if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+            if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+            spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
+        }
     }
 }
 
@@ -383,6 +478,30 @@ static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const Spm
 #pragma unroll
     for (int k = 0; k < kGenMaxC; ++k)
         for (int ww = 1; ww < ds.w; ++ww) acc[k] += part[w + ww][k * 64 + lane];
+    {
+        const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, kSpmmWaves, blockIdx.x);
+        if (pr.meta.x > 0) {  // piece of a long row: same hand-off as the vector kernel, 4 bytes per lane and k
+            float *slot = pr.partials + (size_t)(pr.meta.z + pr.meta.y) * pr.stride;
+#pragma unroll
+            for (int k = 0; k < kGenMaxC; ++k)
+                if (k * 64 + lane < d) __hip_atomic_store(reinterpret_cast<unsigned *>(slot) + k * 64 + lane, __float_as_uint(acc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(pr.counters + pr.meta.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __shfl(ticket, 0, 64);
+            if (ticket != pr.meta.x - 1) return;
+            if (lane == 0) __hip_atomic_store(pr.counters + pr.meta.w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < kGenMaxC; ++k) {
+                if (k * 64 + lane >= d) continue;
+                float t = 0.f;
+                for (int q = 0; q < pr.meta.x; ++q)
+                    t += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(pr.partials + (size_t)(pr.meta.z + q) * pr.stride) + k * 64 + lane,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                acc[k] = t;
+            }
+        }
+    }
     const SpmmEpi &e = a.e;
     const float w1 = (float)(1.0 - (double)e.b1), w2 = (float)(1.0 - (double)e.b2);
 #pragma unroll
@@ -412,7 +531,8 @@ inline hipError_t spmm_launch(const SpmmArgs &a, hipStream_t s)
     static const int hot_off = getenv("RK_SPMM_NO_HOT") ? atoi(getenv("RK_SPMM_NO_HOT")) : 0;
     static const int dbg0 = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
     const_cast<SpmmArgs &>(a).dbg = dbg0;
-    if (a.hot_H > 0 && !hot_off && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
+    const bool filtered = a.row_filter || a.mark_bits || a.clear_bits;  // segment kernel only
+    if (a.hot_H > 0 && !hot_off && !filtered && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
         static bool attr_set = false;
         if (!attr_set) {
             const int lim = 160 * 1024 - 256;

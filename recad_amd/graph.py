@@ -56,12 +56,13 @@ class CsrGraph:
                         self.wave_desc.to(device), self.n_blocks, self.class_split)
 
     @staticmethod
-    def _schedule(n_rows, rowptr, class_split=0):
-        sched, n_blocks = C.c_void_p(), C.c_int32(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, _lib.stream_ptr(), C.byref(sched),
-                                                    C.byref(n_blocks)), "rk_csr_schedule_build")
+    def _schedule(n_rows, rowptr, class_split=0, max_dim=256):
+        sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, max_dim, _lib.stream_ptr(), C.byref(sched),
+                                                    C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
         try:
-            desc = torch.empty(int(n_blocks.value) * 16 * 4, device=rowptr.device, dtype=torch.int32)  # >= waves*4 per block
+            # descriptors + workgroup metas + arrival counters + partial-sum slots of the long rows
+            desc = torch.zeros(int(n_words.value), device=rowptr.device, dtype=torch.int32)
             _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
         finally:
             _lib.lib().rk_csr_schedule_destroy(sched)

@@ -36,11 +36,11 @@ class HipOps:
 
     def make_slab(self, rowptr, col, val, device):
         rp = torch.as_tensor(rowptr, dtype=torch.int32, device=device).contiguous()
-        sched, n_blocks = C.c_void_p(), C.c_int32(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(len(rowptr) - 1, _lib.ptr(rp), 0, _lib.stream_ptr(), C.byref(sched),
-                                                    C.byref(n_blocks)), "rk_csr_schedule_build")
+        sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+        _lib.check(_lib.lib().rk_csr_schedule_build(len(rowptr) - 1, _lib.ptr(rp), 0, 256, _lib.stream_ptr(), C.byref(sched),
+                                                    C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
         try:
-            desc = torch.empty(int(n_blocks.value) * 64, device=device, dtype=torch.int32)
+            desc = torch.zeros(int(n_words.value), device=device, dtype=torch.int32)
             _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
         finally:
             _lib.lib().rk_csr_schedule_destroy(sched)
