@@ -48,6 +48,11 @@ WORKFLOW = {
         "rec_epoch": 400, "attack_epoch": 100, "target_id_list": [0], "filter_num": 4, "topks": [10, 20, 50, 100],
         "logging_level": logging.INFO, "device": DEVICE, "cache_dir": os.path.join(".", "workflows_results"),
     },
+    "defense": {
+        "rec_epoch": 400, "attack_epoch": 100, "target_id_list": [0], "filter_num": 4, "topks": [10, 20, 50, 100],
+        "defense_epoch": 1,
+        "logging_level": logging.INFO, "device": DEVICE, "cache_dir": os.path.join(".", "workflows_results"),
+    },
 }
 
 

@@ -157,7 +157,68 @@ class Normal:
         return results
 
 
-factories = {"no defense": Normal}
+class Defense(Normal):
+    """Counterpart of recad/workflow/defense.py:177-303: Normal's steps, then the defender flags
+    users (``defense_step() -> ids``), the flagged users are dropped from the poisoned dataset
+    (``delete_data``), the victim is retrained a THIRD time from a fresh init and evaluated again.
+    RNGs are re-seeded before the retrains like the reference does (defense.py:102-106,222,281).
+    The defender is any object with the reference's interface (``I``, ``to``, ``input_describe``,
+    optional ``train_step``, ``defense_step``); it never calls the victim."""
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        self.defender = config["defender"].I(dataset=config.get("defense_data", config["attack_data"]))
+
+    @classmethod
+    def from_config(cls, **kwargs):
+        need = ("victim_data", "attack_data", "victim", "attacker", "defender")
+        if any(k not in kwargs for k in need):
+            raise TypeError(f"Expect for user arguments [{', '.join(need)}]")
+        config = {k: copy(v) for k, v in WORKFLOW["defense"].items()}
+        for k, v in kwargs.items():
+            if k in config or k in need or k == "defense_data":
+                config[k] = v
+        return cls(**config)
+
+    @staticmethod
+    def random_seed_set(seed=None):
+        import random
+        from .default import SEED
+        seed = SEED if seed is None else seed
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+
+    def execute(self):
+        dev = self.c["device"]
+        self.victim = self.victim.to(dev)
+        self.attacker = self.attacker.to(dev)
+        self.defender = self.defender.to(dev)
+        self.losses = self.normal_train(self.victim, self.c["rec_epoch"])
+        if "train_step" in self.attacker.input_describe():
+            self.normal_train(self.attacker, self.c["attack_epoch"])
+        fake_array = self.attacker.generate_fake(**self.info_describe())
+        fake_dataset = self.victim_data.inject_data("explicit", fake_array, filter_num=self.c["filter_num"])
+        self.random_seed_set()
+        fake_victim = self.victim.reset().I(dataset=fake_dataset).to(dev)
+        self.normal_train(fake_victim, self.c["rec_epoch"])
+        results = OrderedDict()
+        results["attacked"] = self.normal_evaluate(self.victim, fake_victim, self.victim_data, self.c["target_id_list"], self.c["topks"])
+        if "train_step" in self.defender.input_describe():
+            self.normal_train(self.defender, self.c["defense_epoch"])
+        flagged = list(self.defender.defense_step())
+        cleaned = self.victim_data.delete_data("explicit", flagged, fake_array, filter_num=self.c["filter_num"])
+        self.random_seed_set()
+        defended_victim = self.victim.reset().I(dataset=cleaned).to(dev)
+        self.normal_train(defended_victim, self.c["rec_epoch"])
+        results["defended"] = self.normal_evaluate(self.victim, defended_victim, self.victim_data, self.c["target_id_list"], self.c["topks"])
+        results["n_flagged"] = len(flagged)
+        self.fake_dataset, self.cleaned_dataset, self.defended_victim = fake_dataset, cleaned, defended_victim
+        self.results = results
+        return results
+
+
+factories = {"no defense": Normal, "defense": Defense}
 
 
 def from_config(name, **kwargs):

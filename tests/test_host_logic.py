@@ -227,3 +227,40 @@ def test_eligible_users_and_rows():
     res = {"target_score": np.array([[1.5], [2.5]], dtype=np.float32), "target_rank": np.array([[9], [10]], dtype=np.int32)}
     rows = hr_rows([4, 7], res, [10, 20])
     assert rows.tolist() == [[4.0, 1.5, 1.0, 1.0], [7.0, 2.5, 0.0, 1.0]]
+
+
+class _StubDefender:
+    """Flags the injected users (ids >= the clean user count) plus one genuine user."""
+    model_name = "stub-defender"
+
+    def __init__(self, n_clean):
+        self.n_clean = n_clean
+
+    def I(self, **kw):
+        return self
+
+    def to(self, device):
+        return self
+
+    def input_describe(self):
+        return {}
+
+    def defense_step(self, **kw):
+        return list(range(self.n_clean, self.n_clean + 10)) + [3]
+
+
+def test_defense_workflow_plumbing_cpu(tiny):
+    _, ds = tiny
+    wf = workflow.from_config("defense", victim_data=ds, attack_data=None, victim=_StubVictim(),
+                              attacker=workflow.RandomAttack(ds.n_items, attack_num=10, filler_num=5, seed=1),
+                              defender=_StubDefender(ds.n_users), rec_epoch=1, attack_epoch=0, device=torch.device("cpu"))
+    res = wf.execute()
+    assert res["n_flagged"] == 11 and set(res) == {"attacked", "defended", "n_flagged"}
+    # every fake user and the flagged genuine user are gone from the cleaned train set
+    ptr, _ = wf.cleaned_dataset._csr["train"]
+    deg = np.diff(ptr)
+    assert deg[3] == 0 and (len(deg) <= ds.n_users or deg[ds.n_users:].sum() == 0)
+    assert wf.cleaned_dataset.traindataSize == ds.traindataSize - np.diff(ds._csr["train"][0])[3]
+    assert res["attacked"]["pred_shift"] == pytest.approx(50.0) and res["defended"]["pred_shift"] == pytest.approx(0.0)
+    with pytest.raises(TypeError):
+        workflow.from_config("defense", victim_data=ds, attack_data=None, victim=_StubVictim(), attacker=None)
