@@ -48,14 +48,16 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
  * decreasing), one segment per wave; a row with more than 8 segments is cut into pieces of 8
  * segments, one workgroup each, whose partial sums meet in scratch slots -- the last workgroup
  * of a row to arrive (agent-scope ticket) adds them in piece order and runs the epilogue.
- * Built on the host once per graph (reads rowptr back: synchronous).  _build returns the number of
- * workgroups and the size in int32 words of the device buffer `wave_desc` that _upload fills:
- * wave descriptors, workgroup metas, arrival counters and the partial-sum slots (max_dim floats
- * each; max_dim bounds the `dim` the schedule can be used with).
+ * Rows that fit one lane-group chunk (<= dim/4 nonzeros, dim in {32,64,128}) are packed 256/dim per
+ * wave, one row per lane group.  Built on the host once per (graph, dim) (reads rowptr back:
+ * synchronous) and only valid for SpMMs of that `dim`.  _build returns `n_blocks`, an opaque launch
+ * parameter (workgroup count plus a flag bit) to hand back to the SpMM entry points unchanged,
+ * and the size in int32 words of the device buffer `wave_desc` that _upload fills: wave
+ * descriptors, workgroup metas, packed-row table, arrival counters and the partial-sum slots.
  * class_split > 0 (= n_users for the bipartite adjacency): rows < split and rows >= split are
  * scheduled separately and interleaved 4:4 over the 8 XCDs so each XCD L2 holds one table. */
 typedef struct rk_schedule *rk_schedule_t;
-int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t max_dim, void *stream,
+int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim, void *stream,
                           rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words);
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);

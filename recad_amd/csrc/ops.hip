@@ -64,18 +64,23 @@ RK_EXPORT int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row,
 struct rk_schedule {
     std::vector<int32_t> desc;   // int4 per wave: {row, e_begin, e_end, n_segments if leader else 0}
     std::vector<int32_t> bmeta;  // int4 per workgroup: {n_pieces, piece index, first slot, counter index}; zeros = whole rows
-    int32_t n_blocks = 0, n_long = 0, n_slots = 0, max_dim = 0;
+    std::vector<int32_t> packed; // int4 per packed short row: {row, e_begin, e_end, 0}
+    int32_t n_blocks = 0, n_long = 0, n_slots = 0, dim = 0;
     size_t words() const
     {
-        return desc.size() + 4 + bmeta.size() + (size_t)((n_long + 3) & ~3) + (size_t)n_slots * (size_t)max_dim;
+        return desc.size() + 4 + bmeta.size() + packed.size() + (size_t)((n_long + 3) & ~3) + (size_t)n_slots * (size_t)dim;
     }
 };
 
-RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t max_dim, void *stream,
+RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim, void *stream,
                                     rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words)
 {
-    if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || class_split < 0 || class_split > n_rows || max_dim <= 0 || max_dim > 512)
+    if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || class_split < 0 || class_split > n_rows || dim <= 0 || dim > 256)
         RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
+    // short rows are packed one per lane group (dim/4 lanes): only the vector kernels with >= 2 groups do that
+    static const int no_pack = getenv("RK_SPMM_NO_PACK") ? atoi(getenv("RK_SPMM_NO_PACK")) : 0;  // tuning only
+    int pack_groups = (!no_pack && (dim == 32 || dim == 64 || dim == 128)) ? 256 / dim : 1;
+    int pack_max = pack_groups > 1 ? dim / 4 : -1;  // nonzeros a lane group reads in one chunk
     hipStream_t s = (hipStream_t)stream;
     std::vector<int32_t> rp((size_t)n_rows + 1);
     RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
@@ -88,6 +93,13 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
     for (int32_t r = 0; r < n_rows; ++r) order[(size_t)cnt[(size_t)(maxdeg - (rp[r + 1] - rp[r]))]++] = r;
 
+    if (pack_groups > 1) {
+        // packing uses a separate kernel instantiation (the packed path costs the plain one ~2 %): only
+        // worth it when a good share of the rows is short (the reference's as-is test-edge graphs)
+        int32_t n_short = 0;
+        for (int32_t r = 0; r < n_rows; ++r) n_short += (rp[r + 1] - rp[r] <= pack_max) ? 1 : 0;
+        if (4LL * n_short < n_rows) { pack_groups = 1; pack_max = -1; }
+    }
     const int kSpmmWaves = spmm_waves();
     static const int seg_nnz = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : kSegNnz;
     rk_schedule *sc = new rk_schedule();
@@ -96,6 +108,7 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     // workgroup lists that are then interleaved 4:4 per group of 8, so an XCD's L2 only ever
     // fetches ONE of the two embedding tables (speed only; any placement is correct).
     std::vector<int32_t> cls[2], clsm[2];
+    std::vector<int32_t> &packed = sc->packed;
     int32_t n_long = 0, n_slots = 0;
     for (int pass = 0; pass < 2; ++pass) {
     std::vector<int32_t> &d = cls[pass];
@@ -109,10 +122,47 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     };
     // open workgroups by free wave count: free_list[k] = blocks with exactly k free waves
     std::vector<std::vector<size_t>> free_list((size_t)kSpmmWaves + 1);
+    auto take_wave = [&](int nseg, int &used) {  // best fit: the open workgroup with the fewest free waves that still fits
+        size_t base = (size_t)-1;
+        used = 0;
+        for (int k = nseg; k <= kSpmmWaves && base == (size_t)-1; ++k)
+            if (!free_list[(size_t)k].empty()) {
+                base = free_list[(size_t)k].back();
+                free_list[(size_t)k].pop_back();
+                used = kSpmmWaves - k;
+            }
+        if (base == (size_t)-1) { base = new_block(); used = 0; }
+        const int left = kSpmmWaves - used - nseg;
+        if (left > 0) free_list[(size_t)left].push_back(base);
+        return base;
+    };
+    // short rows (<= one lane-group chunk) are packed pack_groups per wave, one row per lane group
+    std::vector<int32_t> pending;
+    auto flush_packed = [&]() {
+        if (pending.empty()) return;
+        int used = 0;
+        const size_t base = take_wave(1, used);
+        const size_t o = base + (size_t)used * 4;
+        int32_t maxn = 0;
+        d[o + 0] = (int32_t)(packed.size() / 4);
+        for (int32_t r : pending) {
+            packed.insert(packed.end(), {r, rp[r], rp[r + 1], 0});
+            maxn = std::max(maxn, rp[r + 1] - rp[r]);
+        }
+        d[o + 1] = (int32_t)pending.size();
+        d[o + 2] = maxn;
+        d[o + 3] = -1;  // packed wave
+        pending.clear();
+    };
     for (int32_t oi = 0; oi < n_rows; ++oi) {
         const int32_t r = order[(size_t)oi];
         if ((class_split > 0 && r >= class_split) != (pass == 1)) continue;
         const int32_t b = rp[r], e = rp[r + 1], nnz = e - b;
+        if (nnz <= pack_max) {
+            pending.push_back(r);
+            if ((int)pending.size() == pack_groups) flush_packed();
+            continue;
+        }
         int32_t nseg = std::max(1, (nnz + seg_nnz - 1) / seg_nnz);
         if (nseg > kSpmmWaves) {
             // long row: ceil(nseg / W) workgroups, each a "piece" of W segments; the pieces' partial sums
@@ -135,16 +185,8 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
             ++n_long;
             continue;
         }
-        // best fit: the open workgroup with the fewest free waves that still fits
-        size_t base = (size_t)-1;
         int used = 0;
-        for (int k = nseg; k <= kSpmmWaves && base == (size_t)-1; ++k)
-            if (!free_list[(size_t)k].empty()) {
-                base = free_list[(size_t)k].back();
-                free_list[(size_t)k].pop_back();
-                used = kSpmmWaves - k;
-            }
-        if (base == (size_t)-1) { base = new_block(); used = 0; }
+        const size_t base = take_wave(nseg, used);
         for (int sgi = 0; sgi < nseg; ++sgi) {
             const size_t o = base + (size_t)(used + sgi) * 4;
             d[o + 0] = r;
@@ -152,9 +194,8 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
             d[o + 2] = std::min(e, b + (sgi + 1) * seg_nnz);
             d[o + 3] = (sgi == 0) ? nseg : 0;
         }
-        const int left = kSpmmWaves - used - nseg;
-        if (left > 0) free_list[(size_t)left].push_back(base);
     }
+    flush_packed();
     }
     const size_t bw = (size_t)kSpmmWaves * 4;
     const size_t nb0 = cls[0].size() / bw, nb1 = cls[1].size() / bw;
@@ -173,9 +214,9 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
         ++idx;
     }
     sc->n_blocks = (int32_t)(d.size() / bw);
-    sc->n_long = n_long; sc->n_slots = n_slots; sc->max_dim = max_dim;
+    sc->n_long = n_long; sc->n_slots = n_slots; sc->dim = dim;
     *out = sc;
-    *n_blocks = sc->n_blocks;
+    *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag);  // opaque launch parameter
     *n_words = (int64_t)sc->words();
     return RK_OK;
 }
@@ -184,11 +225,12 @@ RK_EXPORT int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, vo
 {
     if (!sched || !wave_desc) RK_FAIL(RK_EINVAL, "rk_csr_schedule_upload: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    // layout: [wave descriptors][header {n_long, n_slots, max_dim, 0}][workgroup metas][counters][partial slots]
+    // layout: [wave descriptors][header {n_long, n_slots, dim, n_packed}][workgroup metas][packed rows][counters][partial slots]
     std::vector<int32_t> head(sched->desc);
-    const int32_t hdr[4] = {sched->n_long, sched->n_slots, sched->max_dim, 0};
+    const int32_t hdr[4] = {sched->n_long, sched->n_slots, sched->dim, (int32_t)(sched->packed.size() / 4)};
     head.insert(head.end(), hdr, hdr + 4);
     head.insert(head.end(), sched->bmeta.begin(), sched->bmeta.end());
+    head.insert(head.end(), sched->packed.begin(), sched->packed.end());
     head.resize(head.size() + (size_t)((sched->n_long + 3) & ~3), 0);  // arrival counters start at zero
     RK_HIP(hipMemcpyAsync(wave_desc, head.data(), sizeof(int32_t) * head.size(), hipMemcpyHostToDevice, s));
     RK_HIP(hipStreamSynchronize(s));

@@ -73,6 +73,8 @@ inline int spmm_waves()
     return (w == 4 || w == 8 || w == 16) ? w : 8;
 }
 
+// bit 30 of the opaque `n_blocks` launch parameter: the schedule contains packed short-row waves
+static constexpr int kSchedPackedFlag = 1 << 30;
 static constexpr int kSegNnz = 64;  // default nonzeros per schedule segment (RK_SEG_NNZ overrides, tuning only)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc)
@@ -200,6 +202,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmEpi &e, int r, int sub, 
 // has returned.  No fence, no placement assumption; summation in piece order => deterministic.
 struct PieceRef {
     int4 meta;            // {n_pieces, piece index, first slot, counter index}
+    const int4 *packed;   // {row, e_begin, e_end, 0} of the packed short rows
     float *partials;      // slot s at partials + s * stride
     int *counters;
     int stride;
@@ -207,11 +210,12 @@ struct PieceRef {
 
 __device__ __forceinline__ PieceRef piece_ref(const int4 *wave_desc, int n_blocks, int waves, int block)
 {
-    const int4 *hdr = wave_desc + (size_t)n_blocks * waves;  // {n_long, n_slots, max_dim, 0}
+    const int4 *hdr = wave_desc + (size_t)n_blocks * waves;  // {n_long, n_slots, dim, n_packed}
     PieceRef p;
     p.meta = hdr[1 + block];
     const int4 h = hdr[0];
-    int *cnt = reinterpret_cast<int *>(const_cast<int4 *>(hdr + 1 + n_blocks));
+    p.packed = hdr + 1 + n_blocks;
+    int *cnt = reinterpret_cast<int *>(const_cast<int4 *>(hdr + 1 + n_blocks + h.w));
     p.counters = cnt;
     p.partials = reinterpret_cast<float *>(cnt + ((h.x + 3) & ~3));
     p.stride = h.z;
@@ -255,7 +259,7 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
     return true;
 }
 
-template <int D, int UNMAX, int WAVES, int MINW>
+template <int D, int UNMAX, int WAVES, int MINW, bool PACKED = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmArgs a)
 {
     constexpr int G = D / 4;
@@ -282,8 +286,46 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     }
     int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
     const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x);  // scalar loads, in flight under the gather
-    if (a.row_filter && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
+    if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PACKED && ds.w < 0) {
+        // packed wave: lane group g owns short row packed[ds.x + g] (<= G nonzeros): no cross-group
+        // reduction, no LDS combine, 64/G rows finished per gather instruction
+        constexpr int NG = 64 / G;
+        const int grp = lane / G, sub = lane % G;
+        int4 pk = make_int4(-1, 0, 0, 0);
+        if (grp < ds.y) pk = pr.packed[ds.x + grp];
+        if (a.row_filter && pk.x >= 0 && !((a.row_filter[(unsigned)pk.x >> 5] >> (pk.x & 31)) & 1u)) pk = make_int4(-1, 0, 0, 0);
+        const int n = pk.x >= 0 ? pk.z - pk.y : 0;
+        int c = 0;
+        float av = 0.f;
+        if (sub < n) { c = a.col[pk.y + sub]; av = a.val[pk.y + sub]; }
+        float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
+        if (pk.x >= 0) {
+            const size_t eoff = (size_t)pk.x * D + (size_t)sub * 4;
+            if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+            if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
+        }
+        for (int t0 = 0; t0 < ds.z; t0 += 8) {  // ds.z = longest row of this wave
+            float4 xv[8];
+            float aw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j;
+                int cc = __shfl(c, (grp * G + t) & 63, 64);
+                float aa = __shfl(av, (grp * G + t) & 63, 64);
+                const bool ok = t < n;
+                cc = ok ? cc : 0;
+                aw[j] = ok ? aa : 0.f;
+                xv[j] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(cc * D + sub * 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = f4_fma(aw[j], xv[j], acc);
+        }
+        __syncthreads();  // keep the workgroup's barrier count uniform
+        if (pk.x >= 0 && !(a.dbg & 2)) spmm_epilogue<D>(a.e, pk.x, sub, acc, addv, sumv);
+        return;
+    }
     if (ds.z > ds.y && !(a.dbg & 1)) {
         acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane);
     }
@@ -524,13 +566,16 @@ static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const Spm
 }
 
 // Host-side launch (asynchronous).  Returns a hipError_t from the launch.
-inline hipError_t spmm_launch(const SpmmArgs &a, hipStream_t s)
+inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
 {
-    if (a.n_rows <= 0) return hipSuccess;
+    if (a_in.n_rows <= 0) return hipSuccess;
+    SpmmArgs a = a_in;
+    const bool packed = (a.n_blocks & kSchedPackedFlag) != 0;
+    a.n_blocks &= ~kSchedPackedFlag;
     const int W = spmm_waves();
     static const int hot_off = getenv("RK_SPMM_NO_HOT") ? atoi(getenv("RK_SPMM_NO_HOT")) : 0;
     static const int dbg0 = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
-    const_cast<SpmmArgs &>(a).dbg = dbg0;
+    a.dbg = dbg0;
     const bool filtered = a.row_filter || a.mark_bits || a.clear_bits;  // segment kernel only
     if (a.hot_H > 0 && !hot_off && !filtered && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
         static bool attr_set = false;
@@ -562,8 +607,12 @@ inline hipError_t spmm_launch(const SpmmArgs &a, hipStream_t s)
     const dim3 grid(a.n_blocks), block(W * 64);
     static const int variant = getenv("RK_SPMM_VARIANT") ? atoi(getenv("RK_SPMM_VARIANT")) : 0;
     static const int dbg = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
-    const_cast<SpmmArgs &>(a).dbg = dbg;
-#define RK_SPMM_CASE(D, UN, WV, MW) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW>), grid, block, 0, s, a)
+    a.dbg = dbg;
+#define RK_SPMM_CASE(D, UN, WV, MW)                                                              \
+    do {                                                                                         \
+        if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, false>), grid, block, 0, s, a);  \
+    } while (0)
 #define RK_SPMM_D(D)                                                                         \
     if (W == 16) { if (variant == 1) RK_SPMM_CASE(D, 16, 16, 4); else RK_SPMM_CASE(D, 8, 16, 8); } \
     else if (W == 8) { if (variant == 1) RK_SPMM_CASE(D, 8, 8, 8); else if (variant == 2) RK_SPMM_CASE(D, 16, 8, 4); else RK_SPMM_CASE(D, 8, 8, 6); } \

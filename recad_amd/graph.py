@@ -10,10 +10,17 @@ class CsrGraph:
     """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the
     per-wave work schedule rk_spmm_csr uses.  Immutable after construction."""
 
-    def __init__(self, n_rows, rowptr, col, val, wave_desc, n_blocks, class_split=0):
+    def __init__(self, n_rows, rowptr, col, val, class_split=0):
         self.n_rows, self.rowptr, self.col, self.val = n_rows, rowptr, col, val
-        self.wave_desc, self.n_blocks, self.class_split = wave_desc, n_blocks, class_split
+        self.class_split = class_split
         self._hot = {}
+        self._sched = {}
+
+    def schedule(self, dim):
+        """(wave_desc int32 device tensor, n_blocks) of the SpMM work schedule for this dim (cached)."""
+        if dim not in self._sched:
+            self._sched[dim] = self._schedule(self.n_rows, self.rowptr, self.class_split, dim)
+        return self._sched[dim]
 
     def hot_tables(self, dim, min_permille=150):
         """Tables of the persistent LDS hot-row SpMM (rk_spmm_hot_build/_upload), cached per dim.
@@ -52,13 +59,12 @@ class CsrGraph:
             device = torch.device("cuda", torch.cuda.current_device())
         if self.rowptr.device == device:
             return self
-        return CsrGraph(self.n_rows, self.rowptr.to(device), self.col.to(device), self.val.to(device),
-                        self.wave_desc.to(device), self.n_blocks, self.class_split)
+        return CsrGraph(self.n_rows, self.rowptr.to(device), self.col.to(device), self.val.to(device), self.class_split)
 
     @staticmethod
-    def _schedule(n_rows, rowptr, class_split=0, max_dim=256):
+    def _schedule(n_rows, rowptr, class_split, dim):
         sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, max_dim, _lib.stream_ptr(), C.byref(sched),
+        _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, dim, _lib.stream_ptr(), C.byref(sched),
                                                     C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
         try:
             # descriptors + workgroup metas + arrival counters + partial-sum slots of the long rows
@@ -84,8 +90,7 @@ class CsrGraph:
         val = torch.empty(max(nnz, 1), device=device, dtype=torch.float32)[:nnz]
         _lib.check(_lib.lib().rk_coo_to_csr(n, nnz, _lib.ptr(row), _lib.ptr(col64), _lib.ptr(v), _lib.ptr(rowptr),
                                             _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()), "rk_coo_to_csr")
-        desc, n_blocks = cls._schedule(n, rowptr, class_split)
-        return cls(n, rowptr, col, val, desc, n_blocks, class_split)
+        return cls(n, rowptr, col, val, class_split)
 
     @classmethod
     def from_user_item_csr(cls, n_users, n_items, r_ptr, r_idx, device):
@@ -103,8 +108,7 @@ class CsrGraph:
         _lib.check(_lib.lib().rk_build_norm_adj(n_users, n_items, _lib.ptr(r_ptr), _lib.ptr(r_idx), _lib.ptr(rowptr),
                                                 _lib.ptr(col), _lib.ptr(val), _lib.ptr(tmp), _lib.stream_ptr()),
                    "rk_build_norm_adj")
-        desc, n_blocks = cls._schedule(N, rowptr, n_users)
-        return cls(N, rowptr, col, val, desc, n_blocks, n_users)
+        return cls(N, rowptr, col, val, n_users)
 
     def to_torch_coo(self):
         """The graph in the reference's own format (a coalesced torch sparse COO tensor)."""
@@ -117,7 +121,8 @@ class CsrGraph:
         """y = A.x (+ add) for a dense [N,d] fp32 tensor (torch.sparse.mm replacement)."""
         x = x.contiguous()
         y = torch.empty_like(x)
+        wave_desc, n_blocks = self.schedule(x.shape[1])
         _lib.check(_lib.lib().rk_spmm_csr(self.n_rows, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val),
-                                          _lib.ptr(self.wave_desc), self.n_blocks, x.shape[1], _lib.ptr(x),
+                                          _lib.ptr(wave_desc), n_blocks, x.shape[1], _lib.ptr(x),
                                           _lib.ptr(add), _lib.ptr(y), _lib.stream_ptr()), "rk_spmm_csr")
         return y

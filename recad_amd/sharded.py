@@ -35,18 +35,24 @@ class HipOps:
     name = "hip"
 
     def make_slab(self, rowptr, col, val, device):
-        rp = torch.as_tensor(rowptr, dtype=torch.int32, device=device).contiguous()
-        sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
-        _lib.check(_lib.lib().rk_csr_schedule_build(len(rowptr) - 1, _lib.ptr(rp), 0, 256, _lib.stream_ptr(), C.byref(sched),
-                                                    C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
-        try:
-            desc = torch.zeros(int(n_words.value), device=device, dtype=torch.int32)
-            _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
-        finally:
-            _lib.lib().rk_csr_schedule_destroy(sched)
-        return {"n_rows": len(rowptr) - 1, "rowptr": rp, "col": torch.as_tensor(col, dtype=torch.int32, device=device).contiguous(),
-                "val": torch.as_tensor(val, dtype=torch.float32, device=device).contiguous(), "desc": desc,
-                "n_blocks": int(n_blocks.value), "coef": torch.zeros(2, device=device)}
+        return {"n_rows": len(rowptr) - 1, "rowptr": torch.as_tensor(rowptr, dtype=torch.int32, device=device).contiguous(),
+                "col": torch.as_tensor(col, dtype=torch.int32, device=device).contiguous(),
+                "val": torch.as_tensor(val, dtype=torch.float32, device=device).contiguous(), "sched": {},
+                "coef": torch.zeros(2, device=device)}
+
+    @staticmethod
+    def _sched(slab, dim):
+        if dim not in slab["sched"]:
+            sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+            _lib.check(_lib.lib().rk_csr_schedule_build(slab["n_rows"], _lib.ptr(slab["rowptr"]), 0, dim, _lib.stream_ptr(), C.byref(sched),
+                                                        C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
+            try:
+                desc = torch.zeros(int(n_words.value), device=slab["rowptr"].device, dtype=torch.int32)
+                _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
+            finally:
+                _lib.lib().rk_csr_schedule_destroy(sched)
+            slab["sched"][dim] = (desc, int(n_blocks.value))
+        return slab["sched"][dim]
 
     def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None):
         e = _lib.SpmmEpilogue(add=_lib.ptr(add), y=_lib.ptr(y), sum_in=_lib.ptr(sum_in), sum_out=_lib.ptr(sum_out),
@@ -55,8 +61,9 @@ class HipOps:
             e.adam_t, e.adam_p, e.adam_m, e.adam_v = adam["t"], _lib.ptr(adam["p"]), _lib.ptr(adam["m"]), _lib.ptr(adam["v"])
             e.coef_scratch = _lib.ptr(slab["coef"])
             e.lr, e.beta1, e.beta2, e.eps = adam["lr"], adam["b1"], adam["b2"], adam["eps"]
+        desc, n_blocks = self._sched(slab, x.shape[1])
         _lib.check(_lib.lib().rk_spmm_csr_ex(slab["n_rows"], _lib.ptr(slab["rowptr"]), _lib.ptr(slab["col"]), _lib.ptr(slab["val"]),
-                                             _lib.ptr(slab["desc"]), slab["n_blocks"], x.shape[1], _lib.ptr(x), x.shape[0],
+                                             _lib.ptr(desc), n_blocks, x.shape[1], _lib.ptr(x), x.shape[0],
                                              C.byref(e), _lib.stream_ptr()), "rk_spmm_csr_ex")
 
     def bpr(self, dim, n_layers, lam, light, emb, gprop, gego, ru, rp, rn, loss_partials):

@@ -118,6 +118,7 @@ class LightGCN(BaseVictim):
         self._drop_handle()
         g = self._csr(dev)
         N, d = self.num_users + self.num_items, self.latent_dim
+        wave_desc, n_blocks = g.schedule(d)
         ws = {k: torch.zeros(N, d, device=dev, dtype=torch.float32) for k in ("buf_a", "buf_b", "light", "gprop", "gego")}
         ws["grad"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if want_grad else None
         ws["state"] = torch.zeros(16, device=dev, dtype=torch.int32)
@@ -131,8 +132,8 @@ class LightGCN(BaseVictim):
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
             lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
             eps=float(grp.get("eps", 1e-8)),
-            rowptr=_lib.ptr(g.rowptr), col=_lib.ptr(g.col), val=_lib.ptr(g.val), wave_desc=_lib.ptr(g.wave_desc),
-            n_blocks=g.n_blocks,
+            rowptr=_lib.ptr(g.rowptr), col=_lib.ptr(g.col), val=_lib.ptr(g.val), wave_desc=_lib.ptr(wave_desc),
+            n_blocks=n_blocks,
             user_emb=_lib.ptr(wu.data), item_emb=_lib.ptr(wi.data),
             m_user=_lib.ptr(su["exp_avg"]), v_user=_lib.ptr(su["exp_avg_sq"]),
             m_item=_lib.ptr(si["exp_avg"]), v_item=_lib.ptr(si["exp_avg_sq"]),

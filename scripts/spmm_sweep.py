@@ -15,4 +15,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(300): _lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr())
 e1.record(); torch.cuda.synchronize()
-print(which, "variant", os.environ.get("RK_SPMM_VARIANT", "0"), "seg", os.environ.get("RK_SEG_NNZ", "64"), "blocks", ds.graph_csr().n_blocks, "us/spmm %.2f" % (e0.elapsed_time(e1) * 1000 / 900))
+print(which, "variant", os.environ.get("RK_SPMM_VARIANT", "0"), "seg", os.environ.get("RK_SEG_NNZ", "64"), "blocks", ds.graph_csr().schedule(64)[1], "us/spmm %.2f" % (e0.elapsed_time(e1) * 1000 / 900))
