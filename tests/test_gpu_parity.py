@@ -467,3 +467,38 @@ def test_full_size_properties_ml1m(gpu_device):
     # idempotence: evaluating twice gives identical lists
     res2 = full_catalog_topk(m, users, ptr, idx, [0, 17], K=100)
     assert np.array_equal(res2["top_ids"], ti)
+
+
+def test_state_dict_roundtrip_and_device_moves(gpu_device):
+    """The victim stays an ordinary nn.Module: state_dict()/load_state_dict() and optimizer state
+    round-trip, .to() moves are followed (tables re-fused lazily), CPU use fails loudly."""
+    from recad_amd import _lib, model
+    g = G.load("lightgcn_game_d64_tg")
+    m, ds = _make_lgn(g, gpu_device, steps=[0, 1])
+    m.train_step()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    import copy
+    osd = copy.deepcopy(m.optimizer.state_dict())  # state_dict() hands out the live tensors
+    assert set(sd) == {"embedding_user.weight", "embedding_item.weight"}
+    assert osd["state"][0]["exp_avg"].shape == m.embedding_user.weight.shape and int(osd["state"][0]["step"]) == 2
+    users = torch.arange(0, 500, device=gpu_device)
+    items = torch.arange(100, 600, device=gpu_device)
+    ref = m(users, items).clone()
+    m2 = model.from_config("victim", "lightgcn", latent_dim_rec=int(g["dim"]), lightGCN_n_layers=int(g["layers"])).I(dataset=ds)
+    m2.load_state_dict(sd)
+    m2 = m2.to(gpu_device)
+    assert torch.equal(m2(users, items), ref)
+    # continue training on both: identical results (Adam state restored through the optimizer API)
+    m2._adam_state(m2.embedding_user.weight), m2._adam_state(m2.embedding_item.weight)
+    m2.optimizer.load_state_dict(osd)
+    ds.steps = [2]
+    la, lb = m.train_step()[0], m2.train_step()[0]
+    assert la == pytest.approx(lb, rel=1e-6)
+    assert G.relerr(m2.embedding_user.weight.detach().cpu().numpy(), m.embedding_user.weight.detach().cpu().numpy()) < 1e-6
+    # round trip through the CPU: values survive, and the HIP path refuses to run there
+    mc = m.to("cpu")
+    with pytest.raises(_lib.HipCallError):
+        mc(users.cpu(), items.cpu())
+    mg = mc.to(gpu_device)
+    out = mg(users, items)
+    assert G.relerr(out.cpu().numpy(), m2(users, items).cpu().numpy()) < 1e-5
