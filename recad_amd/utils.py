@@ -13,15 +13,20 @@ class InstantiateFail(Exception):
 
 
 class VarDim:
-    """Symbolic variable dimension used by input_describe()/output_describe() (recad/utils.py:128-138)."""
+    """Symbolic variable-length dimension for input_describe()/output_describe(); prints as
+    ``comment[min~max]`` like the reference's (recad/utils.py:128-138)."""
+
+    __slots__ = ("max", "min", "comment")
 
     def __init__(self, max=None, min=None, comment=""):
-        self.max = max or "?"
-        self.min = min or "0"
+        self.max = "?" if not max else max
+        self.min = "0" if not min else min
         self.comment = comment
 
     def __repr__(self):
-        return f"{self.comment}[{self.min}~{self.max}]"
+        return "%s[%s~%s]" % (self.comment, self.min, self.max)
+
+    __str__ = __repr__
 
 
 def get_logger(name, level=None):
@@ -35,12 +40,15 @@ def get_logger(name, level=None):
 
 
 def pick_optim(which):
-    """recad/utils.py:181-189: 'adam' -> torch.optim.Adam, else any torch.optim class by name."""
-    if which.lower() == "adam":
+    """Optimizer class by name: 'adam' (any case) -> torch.optim.Adam, otherwise the torch.optim
+    attribute of that exact name; unknown names raise ValueError (recad/utils.py:181-189)."""
+    name = str(which)
+    if name.lower() == "adam":
         return optim.Adam
-    if hasattr(optim, which):
-        return getattr(optim, which)
-    raise ValueError("optimizer not supported")
+    cls = getattr(optim, name, None)
+    if cls is None:
+        raise ValueError("optimizer not supported")
+    return cls
 
 
 def parse_args(args):
