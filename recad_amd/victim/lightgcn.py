@@ -185,17 +185,28 @@ class LightGCN(BaseVictim):
         h = self._ensure_handle(want_grad=want_grad)
         n = users.numel()
         n_steps = (n + batch - 1) // batch
-        loss_partials = torch.empty(n_steps * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)
+        # Stable staging buffers: the hipGraph bakes the triplet / loss pointers in, so copying each
+        # epoch's indices into the same allocations lets one captured graph serve every epoch.
+        st = self._ws.get("staging")
+        if st is None or st["idx"].shape[1] < n or st["loss"].numel() < n_steps * _lib.RK_LOSS_PARTIALS or st["idx"].device != users.device:
+            cap = max(n, int(1.25 * n) if st is not None else n)
+            st = {"idx": torch.empty(3, cap, device=users.device, dtype=torch.int64),
+                  "loss": torch.empty(((cap + batch - 1) // batch + 1) * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)}
+            self._ws["staging"] = st
+        st["idx"][0, :n].copy_(users)
+        st["idx"][1, :n].copy_(pos)
+        st["idx"][2, :n].copy_(neg)
+        loss_partials = st["loss"]
         su = self._adam_state(self.embedding_user.weight)
         t0 = int(su["step"].item()) if apply_update else 0
         _lib.check(_lib.lib().rk_lightgcn_train_epoch(
-            h, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch, t0, _lib.ptr(loss_partials),
+            h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), n, batch, t0, _lib.ptr(loss_partials),
             1 if apply_update else 0, int(self.graph_steps) if apply_update else 0, _lib.stream_ptr()),
             "rk_lightgcn_train_epoch")
         if apply_update:
             for p in (self.embedding_user.weight, self.embedding_item.weight):
                 self.optimizer.state[p]["step"] += n_steps
-        return loss_partials.view(n_steps, _lib.RK_LOSS_PARTIALS)
+        return loss_partials[: n_steps * _lib.RK_LOSS_PARTIALS].view(n_steps, _lib.RK_LOSS_PARTIALS)
 
     def train_step(self, **config):
         """One epoch over dataset.generate_batch() (lightgcn.py:132-172) -> (mean step loss,)."""
