@@ -10,11 +10,12 @@ import torch
 from . import _lib
 
 
-def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096):
+def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096, to_host=True):
     """For every user in user_ids (int array): top-K unseen items and the score/rank of each target.
 
     seen_ptr/seen_idx: CSR (indexed by user id) of the items to exclude (the train items).
-    Returns dict of host numpy arrays: top_ids[n,K], top_scores[n,K], target_score[n,T], target_rank[n,T].
+    Returns dict of arrays top_ids[n,K], top_scores[n,K], target_score[n,T], target_rank[n,T]: host numpy
+    arrays, or (to_host=False) device tensors left in HBM, no synchronisation.
     """
     _lib.require_gpu()
     dot = hasattr(victim, "scoring_tables")
@@ -26,12 +27,12 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     else:  # score_matrix(user_ids, out) victims (NCF): scores are not a dot product
         dev = next(victim.parameters()).device
         n_items = victim.num_items
-    user_ids_t = torch.as_tensor(np.asarray(user_ids), dtype=torch.int32, device=dev).contiguous()
-    seen_ptr_t = torch.as_tensor(np.asarray(seen_ptr), dtype=torch.int32, device=dev).contiguous()
-    seen_idx_t = torch.as_tensor(np.asarray(seen_idx), dtype=torch.int32, device=dev).contiguous()
+    as_dev = lambda a: (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
+                        else torch.as_tensor(np.asarray(a), dtype=torch.int32, device=dev)).contiguous()
+    user_ids_t, seen_ptr_t, seen_idx_t = as_dev(user_ids), as_dev(seen_ptr), as_dev(seen_idx)
     if seen_idx_t.numel() == 0:
         seen_idx_t = torch.zeros(1, dtype=torch.int32, device=dev)
-    targets_t = torch.as_tensor(np.asarray(targets), dtype=torch.int32, device=dev).contiguous()
+    targets_t = as_dev(targets)
     n, T = user_ids_t.numel(), targets_t.numel()
     top_ids = torch.empty(n, K, dtype=torch.int32, device=dev)
     top_scores = torch.empty(n, K, dtype=torch.float32, device=dev)
@@ -56,6 +57,8 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
             _lib.ptr(ibias.contiguous()) if ibias is not None else None, float(mean), _lib.ptr(seen_ptr_t),
             _lib.ptr(seen_idx_t), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]), _lib.ptr(targets_t), T,
             _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+    if not to_host:
+        return {"top_ids": top_ids, "top_scores": top_scores, "target_score": tscore[:, :T], "target_rank": trank[:, :T]}
     return {
         "top_ids": top_ids.cpu().numpy(), "top_scores": top_scores.cpu().numpy(),
         "target_score": tscore[:, :T].cpu().numpy(), "target_rank": trank[:, :T].cpu().numpy(),
