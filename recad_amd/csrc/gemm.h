@@ -26,6 +26,8 @@ struct GemmArgs {
     float const_add;
     int relu;
     const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
+    int split_k;                           // > 1: gridDim.y K-slices, each ADDS its partial into C (C pre-zeroed,
+                                           // no bias/relu/mask; float atomics => summation order not fixed)
 };
 
 static constexpr int kGK = 32, kGLd = kGK + 1;
@@ -146,14 +148,20 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
-    const int n_chunks = (g.K + kGK - 1) / kGK;
+    // K-slice of this workgroup (split_k > 1: blockIdx.y picks a contiguous range of k-chunks)
+    const int all_chunks = (g.K + kGK - 1) / kGK;
+    const int splits = g.split_k > 1 ? g.split_k : 1;
+    const int per = (all_chunks + splits - 1) / splits;
+    const int c_lo = (int)blockIdx.y * per, c_hi = min(all_chunks, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int n_chunks = c_hi - c_lo;
     const int total = (t_end - t_begin) * n_chunks;
     TileRegs<BT> ta, tb;
     int m0, n0;
     tile_origin<BT>(t_begin, gx, gy, m0, n0);
-    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs), mb = tile_mode<BT>(g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
-    tile_load(ta, ma, g.A, g.M, g.K, m0, 0, g.a_rs, g.a_cs);
-    tile_load(tb, mb, g.B, g.N, g.K, n0, 0, g.b_rs, g.b_cs);
+    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
+    tile_load(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs);
+    tile_load(tb, mb, g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
     tile_store(ta, ma, tileA(0));
     tile_store(tb, mb, tileB(0));
     __syncthreads();
@@ -161,10 +169,10 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     // loads are in flight under the current chunk's MFMAs, and a finished tile's stores drain under
     // the next tile's MFMAs.
     for (int it = 0; it < total; ++it) {
-        const int cur = (NBUF == 2) ? (it & 1) : 0, c = it % n_chunks;
+        const int cur = (NBUF == 2) ? (it & 1) : 0, c = c_lo + it % n_chunks;
         const bool more = it + 1 < total;
         if (more) {
-            const int c1 = (it + 1) % n_chunks;
+            const int c1 = c_lo + (it + 1) % n_chunks;
             int m1, n1;
             tile_origin<BT>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
             ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
@@ -187,7 +195,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
 #pragma unroll
                 for (int j = 0; j < TA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (c == n_chunks - 1) {  // tile finished: epilogue, then clear the accumulators
+        if (c == c_hi - 1) {  // tile finished: epilogue, then clear the accumulators
             tile_origin<BT>(t_begin + it / n_chunks, gx, gy, m0, n0);
 #pragma unroll
             for (int i = 0; i < TA; ++i)
@@ -199,6 +207,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
                         const int m = m0 + wr * WS + i * 32 + row, n = n0 + wc * WS + j * 32 + lr;
                         if (m < g.M && n < g.N) {
                             float s = acc[i][j][r];
+                            if (splits > 1) { unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s); acc[i][j][r] = 0.f; continue; }
                             if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
                             else if (g.col_bias) s += g.col_bias[n];
                             if (g.relu) s = s > 0.f ? s : 0.f;
@@ -231,9 +240,11 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
     if (nwg128 < 384 && variant != 3) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg), dim3(256), gemm_lds_bytes<64>(1), s, g, 1);
+        const int splits = g.split_k > 1 ? g.split_k : 1;
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g, 1);
         return hipGetLastError();
     }
+    if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
     // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
     int tpb = (g.K <= 64) ? nwg128 / 1024 : 1;
     tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);

@@ -6,10 +6,12 @@
 #include "gemm.h"
 
 static int gemm(hipStream_t s, int M, int N, int K, const float *A, long long a_rs, long long a_cs, const float *B,
-                long long b_rs, long long b_cs, float *C, int ldc, const float *bias, int relu, const float *mask, int ldmask)
+                long long b_rs, long long b_cs, float *C, int ldc, const float *bias, int relu, const float *mask, int ldmask,
+                int split_k = 1)
 {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.split_k = split_k;
     g.M = M; g.N = N; g.K = K; g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
     g.C = C; g.ldc = ldc; g.col_bias = bias; g.relu = relu; g.mask = mask; g.ldmask = ldmask;
     RK_HIP(gemm_f32_launch(g, s));
@@ -304,8 +306,11 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
                                    (long long)nb * out, dy, y);
                 RK_CHECK_LAUNCH();
             }
-            // dW[out,in] += dY^T X : A(m=o,k=b) = dy[b*out+o], B(n=i,k=b) = x[b*in+i]
-            rc = gemm(s, out, in, nb, dy, 1, out, x, 1, in, d.grad[4 + l], in, nullptr, 0, nullptr, 0);
+            // dW[out,in] += dY^T X : A(m=o,k=b) = dy[b*out+o], B(n=i,k=b) = x[b*in+i].  K = batch is long and
+            // the tile count small: split K over workgroups that add into the (zeroed) gradient.
+            const int tiles = ((out + 63) / 64) * ((in + 63) / 64);
+            const int splits = ((out + 127) / 128) * ((in + 127) / 128) < 384 ? std::max(1, std::min((nb + 31) / 32, 512 / std::max(tiles, 1))) : 1;
+            rc = gemm(s, out, in, nb, dy, 1, out, x, 1, in, d.grad[4 + l], in, nullptr, 0, nullptr, 0, splits);
             if (rc) return rc;
             hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(1024), 0, s, nb, out, dy, d.grad[4 + L + l]);
             RK_CHECK_LAUNCH();
