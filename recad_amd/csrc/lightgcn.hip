@@ -106,6 +106,13 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     }
 }
 
+__global__ void zero_f4_kernel(float4 *p4, long long n4, float *p, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = t; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long i = n4 * 4 + t; i < n; i += stride) p[i] = 0.f;
+}
+
 // standalone dense Adam (L == 0 and the MF/NCF tables)
 __global__ void adam_kernel(long long n, float *p, const float *g, float *m, float *v, float step_size, float bc2s,
                             float b1, float b2, float eps)
@@ -259,7 +266,16 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
         }
         RK_HIP(spmm_launch(a, s));
     }
-    if (L == 1) RK_HIP(hipMemsetAsync(d.gprop, 0, sizeof(float) * (size_t)N * d.dim, s));
+    if (L == 1) {
+        // gprop is the gather operand of the only backward SpMM, so it cannot clean itself there.  A
+        // kernel (not hipMemsetAsync): as the trailing node of a replayed hipGraph a memset node was
+        // observed to race with the next step's scatter-add on the stream (wrong gradients from the
+        // second epoch on, tests/test_gpu_parity.py::test_lightgcn_vs_oracle_shapes[*-1-*]).
+        const long long n4 = (long long)N * d.dim / 4;
+        hipLaunchKernelGGL(zero_f4_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s,
+                           reinterpret_cast<float4 *>(d.gprop), n4, d.gprop, (long long)N * d.dim);
+        RK_CHECK_LAUNCH();
+    }
     return RK_OK;
 }
 
