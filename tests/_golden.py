@@ -100,5 +100,6 @@ def adam_close(a, b, lr, steps, rtol=1e-4, outlier_frac=1e-3, travel_frac=0.25):
     b = np.asarray(b, dtype=np.float64).reshape(-1)
     diff = np.abs(a - b)
     scale = max(np.abs(b).max(), 1e-30)
-    bad = float((diff > rtol * scale).mean())
-    return bad <= outlier_frac and diff.max() <= travel_frac * lr * steps, (bad, diff.max())
+    n_bad = int((diff > rtol * scale).sum())
+    # small tensors: a handful of near-cancelling entries is already above any sensible fraction
+    return n_bad <= max(outlier_frac * diff.size, 8) and diff.max() <= travel_frac * lr * steps, (n_bad, diff.size, diff.max())

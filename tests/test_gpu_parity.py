@@ -540,3 +540,91 @@ def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source):
     out = m(uu, ii).cpu().numpy()
     ref = orc.pair_scores(light[: ds.n_users], light[ds.n_users:], uu.cpu().numpy(), ii.cpu().numpy())
     assert np.allclose(out, ref, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dim", [16, 64, 100, 130])
+def test_mf_vs_oracle_shapes(gpu_device, dim):
+    from recad_amd import dataset, model, synth
+    dd = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"], need_graph=False,
+                             device=gpu_device, sample="pointwise", seed=dim, pointwise_batch_size=700)
+    torch.manual_seed(dim)
+    m = model.from_config("victim", "mf", embedding_size=dim).I(dataset=ds).to(gpu_device)
+    P = orc.MFParams(*(p.weight.detach().cpu().numpy() for p in (m.user_emb, m.item_emb, m.user_bias, m.item_bias)), float(m.mean.item()))
+    for ep in range(2):
+        e = ds.generate_epoch()
+        cols = [e[k] for k in PW_KEYS]
+        losses = m._run_epoch(*cols, 700).sum(1).double().cpu().numpy()
+        un, it, lb = (c.cpu().numpy() for c in cols)
+        for s in range(len(losses)):
+            sl = slice(s * 700, (s + 1) * 700)
+            ref = orc.mf_step(P, un[sl], it[sl], lb[sl])
+            assert abs(losses[s] - ref) <= 2e-5 * abs(ref), (ep, s, losses[s], ref)
+    for got, ref in ((m.user_emb, P.ue), (m.item_emb, P.ie), (m.user_bias, P.ub), (m.item_bias, P.ib)):
+        assert G.relerr(got.weight.detach().cpu().numpy().reshape(ref.shape), ref) < TABLE_RTOL
+    uu = torch.arange(0, ds.n_users, 2, device=gpu_device)
+    ii = (uu * 5) % ds.n_items
+    ref = orc.pair_scores(P.ue, P.ie, uu.cpu().numpy(), ii.cpu().numpy(), P.ub, P.ib, P.mean)
+    assert np.allclose(m(uu, ii).cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("f,L", [(8, 1), (16, 2), (4, 4), (32, 3)])
+def test_ncf_vs_oracle_shapes(gpu_device, f, L):
+    from recad_amd import dataset, model, synth
+    dd = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"], need_graph=False,
+                             device=gpu_device, sample="pointwise", seed=f * 10 + L, pointwise_batch_size=1000)
+    torch.manual_seed(f * 10 + L)
+    m = model.from_config("victim", "ncf", factor_num=f, num_layers=L).I(dataset=ds).to(gpu_device)
+    ts = [t.detach().cpu().numpy().copy() for t in m._tensors()]
+    P = orc.NCFParams(f, L, ts[0], ts[1], ts[2], ts[3], ts[4:4 + L], ts[4 + L:4 + 2 * L], ts[-2], ts[-1])
+    e = ds.generate_epoch()
+    cols = [e[k][:8000] for k in PW_KEYS]
+    un, it, lb = (c.cpu().numpy() for c in cols)
+    pred = m(cols[0][:500], cols[1][:500]).cpu().numpy()
+    assert np.allclose(pred, orc.ncf_forward(P, un[:500], it[:500]), rtol=1e-5, atol=1e-7)
+    # step-0 gradients on identical parameters, then one Adam step
+    part = m._run_epoch(cols[0][:1000], cols[1][:1000], cols[2][:1000], 1000, apply_update=False)
+    loss0, grads = orc.ncf_step(P, un[:1000], it[:1000], lb[:1000], apply_update=False)
+    assert abs(float(part.sum()) - loss0) <= 2e-5 * abs(loss0)
+    for got, ref in zip(m._ws["grad"], grads):
+        assert G.relerr(got.cpu().numpy(), ref.reshape(got.shape)) < 2e-5
+    for gbuf in m._ws["grad"]:
+        gbuf.zero_()
+    losses = m._run_epoch(*cols, 1000).sum(1).double().cpu().numpy()
+    ref_losses = [orc.ncf_step(P, un[s * 1000:(s + 1) * 1000], it[s * 1000:(s + 1) * 1000], lb[s * 1000:(s + 1) * 1000])[0]
+                  for s in range(len(losses))]
+    # Later steps: the ReLU gates of this tiny-activation init flip on 1e-7 parameter differences, so
+    # trajectories separate chaotically (same happens between two CPU summation orders); the losses
+    # stay close and both decrease.
+    assert np.allclose(losses, ref_losses, rtol=2e-3) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("K,n_targets", [(1, 0), (10, 1), (256, 4)])
+def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
+    from recad_amd import _lib
+    rng = np.random.default_rng(K)
+    nb, I = 40, 700
+    scores = rng.standard_normal((nb, I), dtype=np.float32)
+    scores[:, 100] = scores[:, 5]  # ties
+    seen = [np.sort(rng.choice(I, size=rng.integers(0, 30), replace=False)).astype(np.int32) for _ in range(nb)]
+    sp = np.zeros(nb + 1, dtype=np.int32); sp[1:] = np.cumsum([len(x) for x in seen])
+    si = np.concatenate(seen + [np.zeros(1, dtype=np.int32)]).astype(np.int32)
+    targets = np.array([5, 100, 0, 699][:n_targets], dtype=np.int32)
+    dev = gpu_device
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
+    sc = t(scores.copy(), torch.float32)
+    top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev); top_sc = torch.empty(nb, K, device=dev)
+    ts_ = torch.empty(nb, max(n_targets, 1), device=dev); tr = torch.empty(nb, max(n_targets, 1), dtype=torch.int32, device=dev)
+    tg = t(targets if n_targets else np.zeros(1, dtype=np.int32), torch.int32)
+    # named tensors: a temporary passed through _lib.ptr() would be freed (and its block reused) before the launch
+    uid, sp_d, si_d = torch.arange(nb, dtype=torch.int32, device=dev), t(sp, torch.int32), t(si, torch.int32)
+    _lib.check(_lib.lib().rk_topk_rows(_lib.ptr(sc), nb, I, _lib.ptr(uid), _lib.ptr(sp_d), _lib.ptr(si_d), K, _lib.ptr(top_ids),
+                                       _lib.ptr(top_sc), _lib.ptr(tg), n_targets, _lib.ptr(ts_), _lib.ptr(tr), _lib.stream_ptr()),
+               "rk_topk_rows")
+    torch.cuda.synchronize()
+    for b in range(nb):
+        rid, rsc, rts, rtr = orc.topk_row(scores[b], seen[b], K, targets)
+        assert np.array_equal(top_ids[b].cpu().numpy(), rid) and np.array_equal(top_sc[b].cpu().numpy(), rsc), b
+        if n_targets:
+            assert np.array_equal(ts_[b, :n_targets].cpu().numpy(), rts) and np.array_equal(tr[b, :n_targets].cpu().numpy(), rtr), b
