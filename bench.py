@@ -205,18 +205,26 @@ def main():
     warm = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)  # warm (allocator, torch kernels)
     float((warm["target_rank"][:, 0] < 50).float().mean().item())
     del warm
+    # EV_REPS complete evaluations back to back (each: propagate + GEMM + select + HR reduction), one sync at the end
+    EV_REPS = 8
     barrier()
     t1 = time.perf_counter()
-    res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
-    hr50_t = (res["target_rank"][:, 0] < 50).float().mean()
+    for _ in range(EV_REPS):
+        res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
+        hr50_t = (res["target_rank"][:, 0] < 50).float().mean()
     torch.cuda.synchronize()
-    ev_el = time.perf_counter() - t1
+    ev_el = (time.perf_counter() - t1) / EV_REPS
     hr50 = float(hr50_t.item())
+    t1 = time.perf_counter()  # one evaluation on an idle device, host enqueue included (latency, not throughput)
+    res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
+    float((res["target_rank"][:, 0] < 50).float().mean().item())
+    ev_single = time.perf_counter() - t1
     deg = np.diff(ptr)
     pairs = float((ds.n_items - deg[ev_users]).sum())
     flops = 2.0 * len(ev_users) * ds.n_items * args.dim
     topk = {"value": world * len(ev_users) / ev_el, "unit": "users/s", "pair_scorings_per_s": world * pairs / ev_el,
-            "eligible_users": int(len(ev_users)), "seconds": ev_el, "hr@50": hr50,
+            "eligible_users": int(len(ev_users)), "seconds": ev_el, "evaluations_timed": EV_REPS,
+            "single_evaluation_seconds": ev_single, "hr@50": hr50,
             "gemm_tflops_e2e": flops / ev_el / 1e12,
             "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@50 reduction; inputs and outputs resident in HBM"}
 

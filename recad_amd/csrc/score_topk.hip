@@ -11,62 +11,198 @@
 // ---------------------------------------------------------------- pass 2
 __device__ __forceinline__ unsigned score_key(float s)
 {
-    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf)
+    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf).  -0.0 is
+    // folded onto +0.0 so that key equality is float equality (the oracle compares floats).
     if (s == -INFINITY) return 0u;
-    const unsigned u = __float_as_uint(s);
+    unsigned u = __float_as_uint(s);
+    if (u == 0x80000000u) u = 0u;
     const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return k == 0u ? 1u : k;
 }
 
 static constexpr int kMaxK = 256;
+static constexpr int kTopkNT = 256;      // threads per user row
+static constexpr int kInPassTargets = 4; // targets ranked inside the histogram pass
 
-// LDS_ROW: the user's score row is staged once in (dynamic) LDS and every pass reads it from
-// there; the scores matrix is then left untouched.  Otherwise passes stream the row from global
-// memory / L2 and seen items are overwritten with -inf in place.
-// NT = threads per user row: 256 for long rows, 64 (one wave, barriers degenerate) for short ones.
-template <bool LDS_ROW, int NT>
-__global__ __launch_bounds__(NT) void topk_rows_kernel(float *__restrict__ scores, int n_items, const int *__restrict__ user_ids,
-                                                        const int *__restrict__ seen_ptr, const int *__restrict__ seen_idx, int K,
-                                                        int *__restrict__ top_ids, float *__restrict__ top_scores,
-                                                        const int *__restrict__ targets, int n_targets,
-                                                        float *__restrict__ target_score, int *__restrict__ target_rank)
+// One radix digit of a 256-bin histogram, scanned by wave 0 alone (4 bins per lane, shuffles only).
+// Finds the bin holding the `need`-th largest entry: out[0] = bin (untouched when the histogram holds
+// fewer than `need` entries), out[1] = how many entries of that bin are needed, out[2] = entries in or
+// above the bin.  Called by every thread; ends with a workgroup barrier.
+__device__ __forceinline__ void find_bin(const int *hist, int need, int tid, int *out)
 {
-    __shared__ int hist[256];
-    __shared__ unsigned long long sel[kMaxK];
-    __shared__ int sh_i[8];
-    constexpr int NW = NT / 64;
-    __shared__ int wtot[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    extern __shared__ __attribute__((aligned(16))) float lds_row[];
-    const int b = blockIdx.x;
-    float *grow = scores + (size_t)b * n_items;
-    float *row = LDS_ROW ? lds_row : grow;
-    const int u = user_ids[b];
-    // target scores before masking (normal.py:83-85)
-    for (int t = tid; t < n_targets; t += NT) target_score[(size_t)b * n_targets + t] = grow[targets[t]];
-    if (LDS_ROW) {
-        if ((((uintptr_t)grow) & 15) == 0) {
-            for (int i = tid * 4; i + 3 < n_items; i += NT * 4) *reinterpret_cast<float4 *>(row + i) = *reinterpret_cast<const float4 *>(grow + i);
-            for (int i = (n_items & ~3) + tid; i < n_items; i += NT) row[i] = grow[i];
-        } else {
-            for (int i = tid; i < n_items; i += NT) row[i] = grow[i];
+    if (tid < 64) {
+        const int4 v = *reinterpret_cast<const int4 *>(hist + 4 * tid);
+        const int own = v.x + v.y + v.z + v.w;
+        int inc = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_down(inc, o, 64);
+            if (tid + o < 64) inc += n;
+        }
+        const int above = inc - own;
+        if (above < need && need <= above + own) {
+            int cum = above, bin = 4 * tid + 3, h = v.w;
+            if (need > cum + h) { cum += h; bin = 4 * tid + 2; h = v.z; }
+            if (need > cum + h) { cum += h; bin = 4 * tid + 1; h = v.y; }
+            if (need > cum + h) { cum += h; bin = 4 * tid; h = v.x; }
+            out[0] = bin; out[1] = need - cum; out[2] = cum + h;
         }
     }
     __syncthreads();
-    for (int k = seen_ptr[u] + tid; k < seen_ptr[u + 1]; k += NT) row[seen_idx[k]] = -INFINITY;
-    __threadfence_block();
+}
+
+__device__ __forceinline__ float key_score(unsigned k)
+{
+    // inverse of score_key for every finite score and +inf (-0.0 comes back as +0.0)
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// One 256-thread workgroup per user row.
+//   1. keys (monotone uint of the score, 0 = seen) -- staged in LDS when the row is short (LDS_ROW),
+//      otherwise recomputed from the score row in L2 (seen items overwritten with -inf in place);
+//   2. one pass: every thread takes the maximum of its (strided) keys and counts the rank of up to 4
+//      targets.  The K-th largest of the 256 thread maxima is a lower bound of the K-th largest key
+//      (each maximum is a distinct item), and for K around 100 only ~1.2 K keys lie above it.  Two
+//      8-bit radix digits over the MAXIMA ONLY (256 LDS atomics per digit instead of one per item --
+//      LDS atomics retire about one lane per clock) with a parallel suffix scan give that bound to 16 bits;
+//   3. every key at or above the bound is collected unordered; if at most 256 of them, they are
+//      rank-sorted (each thread counts the candidates above its own (key, ~id) composite) -- ties
+//      resolve to the lowest item id exactly like the oracle's scan;
+//   4. otherwise (large K, heavy ties, near-constant rows) the exact path: 8-bit radix rounds over the
+//      candidates refine the threshold, leaving early as soon as the candidate set fits; with all 32
+//      bits resolved the ties are taken in id order.
+// LDS: 3 KB + the key row, so 8 workgroups per CU hide the dependent loads of the prologue.
+template <bool LDS_ROW>
+__global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ scores, int n_items, const int *__restrict__ user_ids,
+                                                            const int *__restrict__ seen_ptr, const int *__restrict__ seen_idx, int K,
+                                                            int *__restrict__ top_ids, float *__restrict__ top_scores,
+                                                            const int *__restrict__ targets, int n_targets,
+                                                            float *__restrict__ target_score, int *__restrict__ target_rank)
+{
+    constexpr int NT = kTopkNT, NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ __attribute__((aligned(16))) int hist2[256];
+    __shared__ unsigned long long sel[kMaxK];
+    __shared__ int sh_i[8];
+    __shared__ int wtot[NW];
+    __shared__ int tcount[kInPassTargets][NW];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_keys[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    float *grow = scores + (size_t)b * n_items;
+    auto key_at = [&](int i) -> unsigned { return LDS_ROW ? lds_keys[i] : score_key(grow[i]); };
+    // f(item, key) over this thread's share of the row: four consecutive items per 16-byte LDS read
+    // (the LDS row is padded with excluded keys to a multiple of 4), or a strided walk of the row in L2.
+    // Any disjoint partition of the items serves the thread-maxima bound.
+    auto for_keys = [&](auto f) {
+        if (LDS_ROW) {
+            const int n4 = (n_items + 3) >> 2;
+            for (int q = tid; q < n4; q += NT) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lds_keys + 4 * q);
+                f(4 * q, v.x); f(4 * q + 1, v.y); f(4 * q + 2, v.z); f(4 * q + 3, v.w);
+            }
+        } else {
+            for (int i = tid; i < n_items; i += NT) f(i, score_key(grow[i]));
+        }
+    };
+
+    // the seen list hangs off two dependent loads: start them before the row is streamed
+    const int u = user_ids[b];
+    const int seen_b = seen_ptr[u], seen_e = seen_ptr[u + 1];
+    const int seen_first = seen_b + tid < seen_e ? seen_idx[seen_b + tid] : -1;
+    // target scores before masking (normal.py:83-85); the first four are ranked inside pass A, so
+    // their (wave-uniform) loads are started here as well
+    for (int t = tid; t < n_targets; t += NT) target_score[(size_t)b * n_targets + t] = grow[targets[t]];
+    const int n_in = min(n_targets, kInPassTargets);
+    unsigned tkey[kInPassTargets];
+    int tgt[kInPassTargets];
+#pragma unroll
+    for (int t = 0; t < kInPassTargets; ++t) {
+        tgt[t] = t < n_in ? targets[t] : -1;
+        tkey[t] = t < n_in ? score_key(grow[tgt[t]]) : 0xffffffffu;
+    }
+    hist[tid] = 0;
+    hist2[tid] = 0;
+    if (tid == 0) { sh_i[0] = -1; sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; sh_i[4] = 0; }
+    if (LDS_ROW) {
+        if ((((uintptr_t)grow) & 15) == 0) {
+            // four 16-byte loads per thread in flight
+            for (int i0 = tid * 4; i0 + 3 < n_items; i0 += NT * 16) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * NT * 4;
+                    v[j] = (i + 3 < n_items) ? *reinterpret_cast<const float4 *>(grow + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * NT * 4;
+                    if (i + 3 < n_items)
+                        *reinterpret_cast<uint4 *>(lds_keys + i) =
+                            make_uint4(score_key(v[j].x), score_key(v[j].y), score_key(v[j].z), score_key(v[j].w));
+                }
+            }
+            for (int i = (n_items & ~3) + tid; i < n_items; i += NT) lds_keys[i] = score_key(grow[i]);
+        } else {
+            for (int i = tid; i < n_items; i += NT) lds_keys[i] = score_key(grow[i]);
+        }
+        if (tid < ((4 - (n_items & 3)) & 3)) lds_keys[n_items + tid] = 0u;  // pad to a multiple of 4
+        __syncthreads();
+        if (seen_first >= 0) lds_keys[seen_first] = 0u;
+        for (int k = seen_b + NT + tid; k < seen_e; k += NT) lds_keys[seen_idx[k]] = 0u;
+    } else {
+        if (seen_first >= 0) grow[seen_first] = -INFINITY;
+        for (int k = seen_b + NT + tid; k < seen_e; k += NT) grow[seen_idx[k]] = -INFINITY;
+        __threadfence_block();
+    }
     __syncthreads();
-    // rank of every target among the unseen items: #(s > st) + #(s == st and id < target)
-    for (int t = 0; t < n_targets; ++t) {
+
+    // ---- pass A: thread maxima + rank of the first targets:  #(s > st) + #(s == st and id < target)
+    unsigned mx = 0u;
+    if (n_in == 0) {
+        for_keys([&](int, unsigned k) { mx = max(mx, k); });
+    } else if (n_in == 1) {
+        const int tg = tgt[0];
+        const unsigned kt = tkey[0];
+        int c = 0;
+        for_keys([&](int i, unsigned k) {
+            mx = max(mx, k);
+            c += (k != 0u && i != tg && (k > kt || (k == kt && i < tg))) ? 1 : 0;
+        });
+        c = (int)wave_sum((float)c);  // counts < 2^24: exact in fp32
+        if (lane == 0) tcount[0][w] = c;
+    } else {
+        int tc[kInPassTargets] = {0, 0, 0, 0};
+        for_keys([&](int i, unsigned k) {
+            mx = max(mx, k);
+#pragma unroll
+            for (int t = 0; t < kInPassTargets; ++t)
+                tc[t] += (k != 0u && i != tgt[t] && (k > tkey[t] || (k == tkey[t] && i < tgt[t]))) ? 1 : 0;
+        });
+#pragma unroll
+        for (int t = 0; t < kInPassTargets; ++t) {
+            const int c = (int)wave_sum((float)tc[t]);
+            if (lane == 0) tcount[t][w] = c;
+        }
+    }
+    if (mx != 0u) atomicAdd(&hist[mx >> 24], 1);
+    __syncthreads();
+    if (tid < n_in) {
+        int tot = 0;
+        for (int q = 0; q < NW; ++q) tot += tcount[tid][q];
+        target_rank[(size_t)b * n_targets + tid] = tot;
+    }
+    // remaining targets: one pass each
+    for (int t = kInPassTargets; t < n_targets; ++t) {
         const int tg = targets[t];
-        const float st = target_score[(size_t)b * n_targets + t];
+        const unsigned kt = score_key(target_score[(size_t)b * n_targets + t]);
         int c = 0;
         for (int i = tid; i < n_items; i += NT) {
-            const float s = row[i];
-            if (s == -INFINITY || i == tg) continue;
-            c += (s > st || (s == st && i < tg)) ? 1 : 0;
+            const unsigned k = key_at(i);
+            c += (k != 0u && i != tg && (k > kt || (k == kt && i < tg))) ? 1 : 0;
         }
-        c = (int)wave_sum((float)c);  // counts < 2^24: exact in fp32
+        c = (int)wave_sum((float)c);
+        __syncthreads();
         if (lane == 0) wtot[w] = c;
         __syncthreads();
         if (tid == 0) {
@@ -74,93 +210,122 @@ __global__ __launch_bounds__(NT) void topk_rows_kernel(float *__restrict__ score
             for (int q = 0; q < NW; ++q) tot += wtot[q];
             target_rank[(size_t)b * n_targets + t] = tot;
         }
-        __syncthreads();
     }
-    // radix select: K-th largest key among the valid ones
-    unsigned prefix = 0u, mask = 0u;
-    int need = K;
-    bool take_all = false;
-    for (int round = 0; round < 4; ++round) {
-        const int shift = 24 - 8 * round;
-        for (int q = tid; q < 256; q += NT) hist[q] = 0;
+
+    // ---- 16-bit lower bound of the K-th largest thread maximum (fewer than K non-empty threads:
+    //      every valid key is a candidate)
+    unsigned cthr = 1u;  // candidates: keys >= cthr (1 = every valid key)
+    find_bin(hist, K, tid, sh_i);
+    if (sh_i[0] >= 0) {
+        const unsigned d1 = (unsigned)sh_i[0];
+        const int need1 = sh_i[1];
+        if (mx != 0u && (mx >> 24) == d1) atomicAdd(&hist2[(mx >> 16) & 255u], 1);
         __syncthreads();
-        for (int i = tid; i < n_items; i += NT) {
-            const unsigned k = score_key(row[i]);
-            if (k != 0u && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int cum = 0, digit = -1, nd = need;
-            for (int bin = 255; bin >= 0; --bin) {
-                if (cum + hist[bin] >= need) { digit = bin; nd = need - cum; break; }
-                cum += hist[bin];
-            }
-            sh_i[0] = digit;
-            sh_i[1] = nd;
-        }
-        __syncthreads();
-        if (sh_i[0] < 0) { take_all = true; break; }  // fewer than K valid items
-        prefix |= (unsigned)sh_i[0] << shift;
-        mask |= 255u << shift;
-        need = sh_i[1];
-        __syncthreads();
+        find_bin(hist2, need1, tid, sh_i);
+        cthr = max((d1 << 24) | ((unsigned)sh_i[0] << 16), 1u);
     }
-    const unsigned T = take_all ? 1u : prefix;
-    const int n_gt_slots = take_all ? K : K - need;
-    // collect: keys > T anywhere in [0, n_gt_slots), keys == T (lowest ids first) after them
-    if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }
-    for (int k = tid; k < kMaxK; k += NT) sel[k] = 0ULL;
-    __syncthreads();
-    for (int base = 0; base < n_items; base += NT) {
-        const int i = base + tid;
-        const unsigned k = i < n_items ? score_key(row[i]) : 0u;
-        const bool gt = take_all ? (k != 0u) : (k > T);
-        const bool eq = !take_all && k == T && k != 0u;
-        if (gt) {
-            const int p = atomicAdd(&sh_i[2], 1);
+
+    // ---- optimistic unordered collection of the candidates
+    for_keys([&](int i, unsigned k) {
+        if (k >= cthr) {
+            const int p = atomicAdd(&sh_i[3], 1);
             if (p < kMaxK) sel[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
         }
-        const unsigned long long m = __ballot(eq);
-        if (lane == 0) wtot[w] = __popcll(m);
+    });
+    __syncthreads();
+    int n_cand = sh_i[3];  // >= min(K, valid keys) by construction
+    int n_sel = n_cand;
+    if (n_cand > kMaxK) {
+        // ---- exact path: radix rounds over the candidates, most significant digit first
+        unsigned prefix = 0u, mask = 0u;
+        int need = K, shift = 32;
         __syncthreads();
-        int pre = __popcll(m & ((1ULL << lane) - 1ULL));
-        for (int ww = 0; ww < w; ++ww) pre += wtot[ww];
-        const int eq_base = sh_i[3];
-        if (eq) {
-            const int idx = eq_base + pre;
-            if (idx < need) sel[n_gt_slots + idx] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+        if (tid == 0) sh_i[3] = 0;
+        while (n_cand > kMaxK && shift > 0) {
+            shift -= 8;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_items; i += NT) {
+                const unsigned k = key_at(i);
+                if (k >= cthr && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            find_bin(hist, need, tid, sh_i);  // more than 256 >= K candidates: always found
+            const int n_gt = K - need;  // keys strictly above the old prefix range
+            prefix |= (unsigned)sh_i[0] << shift;
+            mask |= 255u << shift;
+            n_cand = n_gt + sh_i[2];
+            need = sh_i[1];
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = eq_base;
-            for (int q = 0; q < NW; ++q) tot += wtot[q];
-            sh_i[3] = tot;
+        if (n_cand <= kMaxK) {
+            for (int i = tid; i < n_items; i += NT) {
+                const unsigned k = key_at(i);
+                if (k >= cthr && (k & mask) >= prefix) {
+                    const int p = atomicAdd(&sh_i[3], 1);
+                    sel[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+                }
+            }
+            n_sel = n_cand;
+        } else {
+            // all 32 bits resolved: prefix is the K-th key itself and more than 256 keys are >= it:
+            // take the K - need larger ones in any order and the `need` lowest-id ties in id order
+            const unsigned T = prefix;
+            const int n_gt_slots = K - need;
+            for (int base = 0; base < n_items; base += NT) {
+                const int i = base + tid;
+                const unsigned k = i < n_items ? key_at(i) : 0u;
+                if (k > T) {
+                    const int p = atomicAdd(&sh_i[3], 1);
+                    sel[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+                }
+                const bool eq = k == T && k != 0u;
+                const unsigned long long m = __ballot(eq);
+                if (lane == 0) wtot[w] = __popcll(m);
+                __syncthreads();
+                int pre = __popcll(m & ((1ULL << lane) - 1ULL));
+                for (int ww = 0; ww < w; ++ww) pre += wtot[ww];
+                const int eq_base = sh_i[4];
+                if (eq) {
+                    const int idx = eq_base + pre;
+                    if (idx < need) sel[n_gt_slots + idx] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int tot = eq_base;
+                    for (int q = 0; q < NW; ++q) tot += wtot[q];
+                    sh_i[4] = tot;
+                }
+                __syncthreads();
+                if (sh_i[4] >= need && base + NT < n_items) {
+                    // ties are complete; only larger keys remain to be collected
+                    for (int i2 = base + NT + tid; i2 < n_items; i2 += NT) {
+                        const unsigned k2 = key_at(i2);
+                        if (k2 > T) {
+                            const int p = atomicAdd(&sh_i[3], 1);
+                            sel[p] = ((unsigned long long)k2 << 32) | (unsigned)(~(unsigned)i2);
+                        }
+                    }
+                    break;
+                }
+            }
+            n_sel = K;
         }
         __syncthreads();
     }
-    // bitonic sort of 256 composite keys, descending => score desc, item id asc
-    for (int size = 2; size <= kMaxK; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int q = tid; q < kMaxK; q += NT) {
-                const int partner = q ^ stride;
-                if (partner > q) {
-                    const bool desc = (q & size) == 0;
-                    const unsigned long long x = sel[q], y = sel[partner];
-                    if (desc ? (x < y) : (x > y)) { sel[q] = y; sel[partner] = x; }
-                }
-            }
-            __syncthreads();
+    // rank sort: composites are distinct (item id in the low word), so ranks are a permutation
+    if (tid < n_sel) {
+        const unsigned long long mine = sel[tid];
+        int rank = 0;
+        for (int j = 0; j < n_sel; ++j) rank += sel[j] > mine ? 1 : 0;
+        if (rank < K) {
+            top_ids[(size_t)b * K + rank] = (int)(~(unsigned)(mine & 0xffffffffULL));
+            top_scores[(size_t)b * K + rank] = key_score((unsigned)(mine >> 32));
         }
-    for (int k = tid; k < K; k += NT) {
-        const unsigned long long e = sel[k];
-        if (e == 0ULL) {
-            top_ids[(size_t)b * K + k] = -1;
-            top_scores[(size_t)b * K + k] = -INFINITY;
-        } else {
-            const int id = (int)(~(unsigned)(e & 0xffffffffULL));
-            top_ids[(size_t)b * K + k] = id;
-            top_scores[(size_t)b * K + k] = row[id];
-        }
+    }
+    for (int k = n_sel + tid; k < K; k += NT) {
+        top_ids[(size_t)b * K + k] = -1;
+        top_scores[(size_t)b * K + k] = -INFINITY;
     }
 }
 
@@ -177,15 +342,15 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     if (row_bytes <= 16 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            RK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_rows_kernel<true, 256>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            RK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_rows_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr_set = true;
         }
         // (one wave per short row -- NT = 64 -- was measured too: 333 vs 250 us for 5950 x 3702)
-        hipLaunchKernelGGL((topk_rows_kernel<true, 256>), dim3(nb), dim3(256), row_bytes, s, scores, n_items, user_ids, seen_ptr, seen_idx,
+        hipLaunchKernelGGL((topk_rows_kernel<true>), dim3(nb), dim3(kTopkNT), row_bytes, s, scores, n_items, user_ids, seen_ptr, seen_idx,
                            K, top_ids, top_scores, targets, n_targets, target_score, target_rank);
     } else {
-        hipLaunchKernelGGL((topk_rows_kernel<false, 256>), dim3(nb), dim3(256), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K,
+        hipLaunchKernelGGL((topk_rows_kernel<false>), dim3(nb), dim3(kTopkNT), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K,
                            top_ids, top_scores, targets, n_targets, target_score, target_rank);
     }
     RK_CHECK_LAUNCH();

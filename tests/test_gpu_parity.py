@@ -600,18 +600,13 @@ def test_ncf_vs_oracle_shapes(gpu_device, f, L):
     assert np.allclose(losses, ref_losses, rtol=2e-3) and losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("K,n_targets", [(1, 0), (10, 1), (256, 4)])
-def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
+def _topk_rows_vs_oracle(dev, scores, seen, K, targets):
+    """rk_topk_rows through the C-ABI against orc.topk_row, row by row, bit-exact."""
     from recad_amd import _lib
-    rng = np.random.default_rng(K)
-    nb, I = 40, 700
-    scores = rng.standard_normal((nb, I), dtype=np.float32)
-    scores[:, 100] = scores[:, 5]  # ties
-    seen = [np.sort(rng.choice(I, size=rng.integers(0, 30), replace=False)).astype(np.int32) for _ in range(nb)]
+    nb, I = scores.shape
+    n_targets = len(targets)
     sp = np.zeros(nb + 1, dtype=np.int32); sp[1:] = np.cumsum([len(x) for x in seen])
-    si = np.concatenate(seen + [np.zeros(1, dtype=np.int32)]).astype(np.int32)
-    targets = np.array([5, 100, 0, 699][:n_targets], dtype=np.int32)
-    dev = gpu_device
+    si = np.concatenate(list(seen) + [np.zeros(1, dtype=np.int32)]).astype(np.int32)
     t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
     sc = t(scores.copy(), torch.float32)
     top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev); top_sc = torch.empty(nb, K, device=dev)
@@ -623,8 +618,50 @@ def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
                                        _lib.ptr(top_sc), _lib.ptr(tg), n_targets, _lib.ptr(ts_), _lib.ptr(tr), _lib.stream_ptr()),
                "rk_topk_rows")
     torch.cuda.synchronize()
+    top_ids, top_sc, ts_, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts_.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         rid, rsc, rts, rtr = orc.topk_row(scores[b], seen[b], K, targets)
-        assert np.array_equal(top_ids[b].cpu().numpy(), rid) and np.array_equal(top_sc[b].cpu().numpy(), rsc), b
+        assert np.array_equal(top_ids[b], rid), (b, top_ids[b][:8], rid[:8])
+        assert np.array_equal(top_sc[b], rsc), b
         if n_targets:
-            assert np.array_equal(ts_[b, :n_targets].cpu().numpy(), rts) and np.array_equal(tr[b, :n_targets].cpu().numpy(), rtr), b
+            assert np.array_equal(ts_[b, :n_targets], rts) and np.array_equal(tr[b, :n_targets], rtr), (b, tr[b], rtr)
+
+
+@pytest.mark.parametrize("K,n_targets", [(1, 0), (10, 1), (256, 4), (100, 7)])
+def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
+    rng = np.random.default_rng(K)
+    nb, I = 40, 700
+    scores = rng.standard_normal((nb, I), dtype=np.float32)
+    scores[:, 100] = scores[:, 5]  # ties
+    seen = [np.sort(rng.choice(I, size=rng.integers(0, 30), replace=False)).astype(np.int32) for _ in range(nb)]
+    targets = np.array([5, 100, 0, 699, 350, 351, 17][:n_targets], dtype=np.int32)
+    _topk_rows_vs_oracle(gpu_device, scores, seen, K, targets)
+
+
+@pytest.mark.parametrize("I", [50, 3702, 9000])
+@pytest.mark.parametrize("kind", ["const", "two_values", "tiny_spread", "signed_zero", "quantised", "mostly_seen"])
+def test_topk_rows_tie_heavy_rows(gpu_device, kind, I):
+    """Rows whose candidates do not fit the first radix bin: constant rows (an untrained MF victim scores
+    every item `mean`), a handful of distinct values, a spread of a few ulps, +-0, and rows with fewer
+    than K unseen items.  I = 9000 takes the row-in-L2 form of the kernel, the others the row-in-LDS form."""
+    rng = np.random.default_rng(I)
+    nb, K = 12, 100
+    if kind == "const":
+        scores = np.full((nb, I), 3.0, dtype=np.float32)
+    elif kind == "two_values":
+        scores = rng.choice(np.array([3.0, 3.0000002], dtype=np.float32), size=(nb, I))
+    elif kind == "tiny_spread":
+        base = np.float32(3.0)
+        scores = (base + np.spacing(base) * rng.integers(0, 6, (nb, I))).astype(np.float32)
+    elif kind == "signed_zero":
+        scores = rng.choice(np.array([0.0, -0.0, 1e-30, -1e-30], dtype=np.float32), size=(nb, I))
+    elif kind == "quantised":
+        scores = (rng.integers(-40, 40, (nb, I)) / 8.0).astype(np.float32)
+    else:
+        scores = rng.standard_normal((nb, I), dtype=np.float32)
+    if kind == "mostly_seen":
+        seen = [np.sort(rng.choice(I, size=I - int(rng.integers(0, min(I, 150))), replace=False)).astype(np.int32) for _ in range(nb)]
+    else:
+        seen = [np.sort(rng.choice(I, size=int(rng.integers(0, min(I, 40))), replace=False)).astype(np.int32) for _ in range(nb)]
+    targets = np.array([3, I - 1, I // 2], dtype=np.int32)
+    _topk_rows_vs_oracle(gpu_device, scores, seen, K, targets)
