@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 1
+#define RK_ABI_VERSION 2
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -182,13 +182,14 @@ int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v,
 
 /* Full-catalog scoring + top-K + target rank for a block of users: replaces the per-user
  * loop of Normal.user_item_model_generate, recad/workflow/normal.py:57-93.
- *   scores[b,i] = <urows[b], itab[i]> (+ ubias_rows[b] + ibias[i] + mean when ibias != NULL)
- * computed with fp32 MFMA; items in the user's seen list (CSR seen_ptr/seen_idx indexed by
+ *   scores[b,i] = <utab[user_ids[b]], itab[i]> (+ ubias[user_ids[b]] + ibias[i] + mean when ibias != NULL)
+ * computed with fp32 MFMA (utab/ubias are the whole user tables: the block's rows are gathered by
+ * the GEMM's tile loads); items in the user's seen list (CSR seen_ptr/seen_idx indexed by
  * user_ids[b]) are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K]
  * sorted by (score desc, item id asc), padded with -1/-inf; for each target t its score and
  * rank among the unseen items (hit@k <=> rank < k).  scratch: device float[nb*n_items]. */
-int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const int32_t *user_ids, const float *itab,
-                  int32_t n_items, const float *ubias_rows, const float *ibias, float mean,
+int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                  int32_t n_items, const float *ubias, const float *ibias, float mean,
                   const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
                   float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
                   int32_t *target_rank, float *scratch, void *stream);
@@ -220,12 +221,18 @@ int rk_pointwise_sample(int32_t n_users, int32_t n_items, const int32_t *train_p
                         int64_t n_edges, int32_t negative_ratio, uint64_t seed, int64_t *users, int64_t *items,
                         int64_t *labels, void *stream);
 
-/* Pass 2 of rk_score_topk on a ready score matrix scores[nb, n_items] (modified in place:
- * seen items are overwritten with -inf).  Used for victims whose scores are not a dot product. */
+/* Pass 2 of rk_score_topk on a ready score matrix scores[nb, n_items] (rows too long to stage
+ * in LDS are modified in place: seen items are overwritten with -inf).  Used for victims whose
+ * scores are not a dot product (NCF). */
 int rk_topk_rows(float *scores, int32_t nb, int32_t n_items, const int32_t *user_ids, const int32_t *seen_ptr,
                  const int32_t *seen_idx, int32_t K, int32_t *top_ids, float *top_scores,
                  const int32_t *targets, int32_t n_targets, float *target_score, int32_t *target_rank,
                  void *stream);
+
+/* HR@k numerators (normal.py:86-92,150-156: hit@k <=> the target's rank among the unseen items < k):
+ * counts[t*nk + q] = #{b < n : target_rank[b*n_targets + t] < ks[q]}.  All pointers on the device. */
+int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_targets, const int32_t *ks, int32_t nk,
+                  int32_t *counts, void *stream);
 
 /* ---------------------------------------------------------------- NCF -------------- */
 #define RK_NCF_MAX_LAYERS 8

@@ -18,11 +18,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
     int M, N, K;
-    const float *A; long long a_rs, a_cs;  // A(m,k) = A[m*a_rs + k*a_cs]
+    const float *A; long long a_rs, a_cs;  // A(m,k) = A[row(m)*a_rs + k*a_cs], row(m) = a_ridx ? a_ridx[m] : m
+    const int *a_ridx;                     // optional row gather of A (and of row_bias): scoring a block of user ids
     const float *B; long long b_rs, b_cs;  // B(n,k) = B[n*b_rs + k*b_cs]
     float *C; int ldc;
     const float *col_bias;                 // + col_bias[n]
-    const float *row_bias;                 // scoring: ((s + row_bias[m]) + col_bias[n]) + const_add
+    const float *row_bias;                 // scoring: ((s + row_bias[row(m)]) + col_bias[n]) + const_add
     float const_add;
     int relu;
     const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
@@ -39,18 +40,19 @@ template <int BT> constexpr int gemm_lds_bytes(int nbuf) { return nbuf * 2 * BT 
 template <int BT> struct TileRegs { float v[BT / 8]; };
 
 template <int BT>
-__device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, int r0, int k0, long long rs, long long cs)
+__device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, int r0, int k0, long long rs, long long cs,
+                                         bool gathered = false)
 {
     const bool full = (r0 + BT <= n_rows) && (k0 + kGK <= n_k);
     if (!full) return 0;
     if (cs == 1 && (rs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 1;
-    if (rs == 1 && (cs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 2;
+    if (!gathered && rs == 1 && (cs & 3) == 0 && ((uintptr_t)src & 15) == 0) return 2;
     return 0;
 }
 
 template <int BT>
 __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
-                                          int k0, long long rs, long long cs)
+                                          int k0, long long rs, long long cs, const int *__restrict__ ridx = nullptr)
 {
     const int tid = threadIdx.x;
     constexpr int NP = BT / 32;  // float4 loads per thread
@@ -58,7 +60,8 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
-            const float4 x = *reinterpret_cast<const float4 *>(src + (long long)(r0 + r) * rs + (k0 + c));
+            const long long gr = ridx ? ridx[r0 + r] : r0 + r;
+            const float4 x = *reinterpret_cast<const float4 *>(src + gr * rs + (k0 + c));
             t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
         }
     } else if (mode == 2) {  // BT/4 float4 per k column of BT rows: thread -> (k = p*KP + tid/(BT/4), row4 = tid%(BT/4))
@@ -75,7 +78,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
             const int idx = p * 256 + tid;
             const int r = idx / kGK, c = idx % kGK;
             const int gr = r0 + r, gc = k0 + c;
-            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)gr * rs + (long long)gc * cs] : 0.f;
+            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)(ridx ? ridx[gr] : gr) * rs + (long long)gc * cs] : 0.f;
         }
     }
 }
@@ -159,8 +162,8 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     TileRegs<BT> ta, tb;
     int m0, n0;
     tile_origin<BT>(t_begin, gx, gy, m0, n0);
-    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
-    tile_load(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs);
+    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx != nullptr), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
+    tile_load(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx);
     tile_load(tb, mb, g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
     tile_store(ta, ma, tileA(0));
     tile_store(tb, mb, tileB(0));
@@ -175,9 +178,9 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
             const int c1 = c_lo + (it + 1) % n_chunks;
             int m1, n1;
             tile_origin<BT>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
-            ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
+            ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx != nullptr);
             mb = tile_mode<BT>(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
-            tile_load(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs);
+            tile_load(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx);
             tile_load(tb, mb, g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
         }
         const int kc = min(kGK, g.K - c * kGK);
@@ -208,7 +211,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
                         if (m < g.M && n < g.N) {
                             float s = acc[i][j][r];
                             if (splits > 1) { unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s); acc[i][j][r] = 0.f; continue; }
-                            if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
+                            if (g.row_bias) s = ((s + g.row_bias[g.a_ridx ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
                             else if (g.col_bias) s += g.col_bias[n];
                             if (g.relu) s = s > 0.f ? s : 0.f;
                             if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;

@@ -204,7 +204,7 @@ struct BatchRef {
 // rows in d.row_bits and the last layer computes only those rows of `light`.
 static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchRef *batch = nullptr)
 {
-    const int N = d.n_users + d.n_items, L = d.n_layers;
+    const int L = d.n_layers;
     const float inv = 1.0f / (float)(L + 1);
     if (L == 0) {
         RK_HIP(hipMemcpyAsync(d.light, d.user_emb, sizeof(float) * (size_t)d.n_users * d.dim, hipMemcpyDeviceToDevice, s));

@@ -357,25 +357,62 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     return RK_OK;
 }
 
-RK_EXPORT int rk_score_topk(int32_t dim, const float *urows, int32_t nb, const int32_t *user_ids, const float *itab,
-                            int32_t n_items, const float *ubias_rows, const float *ibias, float mean,
+RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                            int32_t n_items, const float *ubias, const float *ibias, float mean,
                             const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
                             float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
                             int32_t *target_rank, float *scratch, void *stream)
 {
     if (nb <= 0) return RK_OK;
-    if (dim <= 0 || n_items <= 0 || !urows || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
+    if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
         RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
-    if ((ubias_rows == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
+    if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = nb; g.N = n_items; g.K = dim;
-    g.A = urows; g.a_rs = dim; g.a_cs = 1;
+    g.A = utab; g.a_rs = dim; g.a_cs = 1; g.a_ridx = user_ids;  // the user rows are gathered by the tile loads
     g.B = itab; g.b_rs = dim; g.b_cs = 1;
     g.C = scratch; g.ldc = n_items;
-    g.row_bias = ubias_rows; g.col_bias = ibias; g.const_add = mean;
+    g.row_bias = ubias; g.col_bias = ibias; g.const_add = mean;
     RK_HIP(gemm_f32_launch(g, s));
     return rk_topk_rows_impl(scratch, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
                              target_score, target_rank, s);
+}
+
+// ---------------------------------------------------------------- HR@k reduction
+// counts[t*nk + q] = #{b : target_rank[b*T + t] < ks[q]}   (hit@k <=> rank < k, normal.py:86-92,150-156)
+__global__ __launch_bounds__(1024) void hit_counts_kernel(const int *__restrict__ rank, long long n, int T, const int *__restrict__ ks,
+                                                          int nk, int *__restrict__ counts, int use_atomics)
+{
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int p = 0; p < T * nk; ++p) {
+        const int t = p / nk, k = ks[p % nk];
+        int c = 0;
+        for (long long b = (long long)blockIdx.x * 1024 + tid; b < n; b += (long long)gridDim.x * 1024) c += rank[b * T + t] < k ? 1 : 0;
+        c = (int)wave_sum((float)c);  // per-wave partial < 2^24: exact in fp32
+        if (lane == 0) wtot[w] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int q = 0; q < 16; ++q) tot += wtot[q];
+            if (use_atomics) atomicAdd(&counts[p], tot);
+            else counts[p] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+RK_EXPORT int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_targets, const int32_t *ks, int32_t nk,
+                            int32_t *counts, void *stream)
+{
+    if (n_targets <= 0 || nk <= 0) return RK_OK;
+    if (n < 0 || !target_rank || !ks || !counts) RK_FAIL(RK_EINVAL, "rk_hit_counts: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(64, (n + 16383) / 16384));
+    if (grid > 1) RK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_targets * nk, s));
+    hipLaunchKernelGGL(hit_counts_kernel, dim3(grid), dim3(1024), 0, s, target_rank, (long long)n, n_targets, ks, nk, counts, grid > 1);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
 }

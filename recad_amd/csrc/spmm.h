@@ -291,7 +291,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     if (PACKED && ds.w < 0) {
         // packed wave: lane group g owns short row packed[ds.x + g] (<= G nonzeros): no cross-group
         // reduction, no LDS combine, 64/G rows finished per gather instruction
-        constexpr int NG = 64 / G;
         const int grp = lane / G, sub = lane % G;
         int4 pk = make_int4(-1, 0, 0, 0);
         if (grp < ds.y) pk = pr.packed[ds.x + grp];

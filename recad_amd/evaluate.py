@@ -22,7 +22,9 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     if dot:
         utab, itab, ubias, ibias, mean = victim.scoring_tables()
         dev = itab.device
-        itab = itab.contiguous()
+        utab, itab = utab.contiguous(), itab.contiguous()
+        if ubias is not None:
+            ubias, ibias = ubias.contiguous().view(-1), ibias.contiguous().view(-1)
         n_items, d = itab.shape
     else:  # score_matrix(user_ids, out) victims (NCF): scores are not a dot product
         dev = next(victim.parameters()).device
@@ -50,19 +52,34 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
                 _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]), _lib.ptr(targets_t), T, _lib.ptr(tscore[s:e]),
                 _lib.ptr(trank[s:e]), _lib.stream_ptr()), "rk_topk_rows")
             continue
-        urows = utab.index_select(0, ids.long()).contiguous()
-        ub_rows = ubias.index_select(0, ids.long()).contiguous() if ubias is not None else None
         _lib.check(_lib.lib().rk_score_topk(
-            d, _lib.ptr(urows), e - s, _lib.ptr(ids), _lib.ptr(itab), n_items, _lib.ptr(ub_rows),
-            _lib.ptr(ibias.contiguous()) if ibias is not None else None, float(mean), _lib.ptr(seen_ptr_t),
-            _lib.ptr(seen_idx_t), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]), _lib.ptr(targets_t), T,
-            _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+            d, _lib.ptr(utab), e - s, _lib.ptr(ids), _lib.ptr(itab), n_items, _lib.ptr(ubias), _lib.ptr(ibias),
+            float(mean), _lib.ptr(seen_ptr_t), _lib.ptr(seen_idx_t), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]),
+            _lib.ptr(targets_t), T, _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), _lib.ptr(scratch), _lib.stream_ptr()),
+            "rk_score_topk")
     if not to_host:
         return {"top_ids": top_ids, "top_scores": top_scores, "target_score": tscore[:, :T], "target_rank": trank[:, :T]}
     return {
         "top_ids": top_ids.cpu().numpy(), "top_scores": top_scores.cpu().numpy(),
         "target_score": tscore[:, :T].cpu().numpy(), "target_rank": trank[:, :T].cpu().numpy(),
     }
+
+
+_KS_CACHE = {}
+
+
+def hit_counts(target_rank, topks):
+    """HR@k numerators on the device: int32 tensor [n_targets, len(topks)] with the number of users whose
+    target ranks below k (normal.py:86-92); divide by the number of users for HR@k.  No synchronisation."""
+    n, T = target_rank.shape
+    key = (target_rank.device, tuple(int(k) for k in topks))
+    ks = _KS_CACHE.get(key)
+    if ks is None:  # a host->device copy per call would stall the stream
+        ks = _KS_CACHE[key] = torch.as_tensor(list(key[1]), dtype=torch.int32, device=target_rank.device)
+    counts = torch.empty(T, len(ks), dtype=torch.int32, device=target_rank.device)
+    _lib.check(_lib.lib().rk_hit_counts(_lib.ptr(target_rank.contiguous()), n, T, _lib.ptr(ks), len(ks), _lib.ptr(counts),
+                                        _lib.stream_ptr()), "rk_hit_counts")
+    return counts
 
 
 def eligible_users(train_ptr, train_idx, targets):

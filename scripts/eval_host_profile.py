@@ -3,7 +3,7 @@ import cProfile, pstats, sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
 from recad_amd import dataset, model, synth
-from recad_amd.evaluate import eligible_users, full_catalog_topk
+from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 dev = torch.device('cuda:0')
 d = synth.make("ml1m")
 ds = dataset.from_config("implicit", "ml1m", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], device=dev, graph_source="train")
@@ -15,7 +15,7 @@ t = lambda a: torch.as_tensor(a, dtype=torch.int32, device=dev)
 ev_d, ptr_d, idx_d, tg_d = t(ev), t(ptr), t(idx), t(targets)
 def once():
     res = full_catalog_topk(victim, ev_d, ptr_d, idx_d, tg_d, K=100, chunk=8192, to_host=False)
-    return (res["target_rank"][:, 0] < 50).float().mean()
+    return hit_counts(res["target_rank"], (10, 20, 50, 100))
 for _ in range(3): once()
 torch.cuda.synchronize()
 for rep in range(3):

@@ -172,18 +172,19 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
     so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first)."""
     from recad_amd import _lib
     rng = np.random.default_rng(d)
-    nb, I, K = 150, 1000 + d, 100
-    urows = rng.standard_normal((nb, d), dtype=np.float32)
+    nu, nb, I, K = 220, 150, 1000 + d, 100
+    utab = rng.standard_normal((nu, d), dtype=np.float32)
     itab = rng.standard_normal((I, d), dtype=np.float32)
     itab[17] = itab[400]  # exact ties
     itab[18] = itab[400]
-    ub = rng.standard_normal(nb, dtype=np.float32) if with_bias else None
+    ub = rng.standard_normal(nu, dtype=np.float32) if with_bias else None
     ib = rng.standard_normal(I, dtype=np.float32) if with_bias else None
     if with_bias:
         ib[17] = ib[18] = ib[400]
-    seen_lists = [np.sort(rng.choice(I, size=rng.integers(0, 60), replace=False)).astype(np.int32) for _ in range(nb)]
-    seen_lists[3] = np.sort(rng.choice(I, size=I - 40, replace=False)).astype(np.int32)  # fewer than K unseen
-    seen_ptr = np.zeros(nb + 1, dtype=np.int32)
+    user_ids = rng.permutation(nu)[:nb].astype(np.int32)  # the block's rows are gathered from the user table
+    seen_lists = [np.sort(rng.choice(I, size=rng.integers(0, 60), replace=False)).astype(np.int32) for _ in range(nu)]
+    seen_lists[int(user_ids[3])] = np.sort(rng.choice(I, size=I - 40, replace=False)).astype(np.int32)  # fewer than K unseen
+    seen_ptr = np.zeros(nu + 1, dtype=np.int32)
     seen_ptr[1:] = np.cumsum([len(s) for s in seen_lists])
     seen_idx = np.concatenate(seen_lists).astype(np.int32)
     targets = np.array([0, 5, 400], dtype=np.int32)
@@ -194,22 +195,24 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
     ts = torch.empty(nb, 3, dtype=torch.float32, device=dev)
     tr = torch.empty(nb, 3, dtype=torch.int32, device=dev)
     scratch = torch.empty(nb * I, dtype=torch.float32, device=dev)
-    tu, ti, tub, tib = t(urows, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
-    ids = torch.arange(nb, dtype=torch.int32, device=dev)
+    tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
+    ids = t(user_ids, torch.int32)
     sp, si, tg = t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(targets, torch.int32)
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(ids), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.25 if with_bias else 0.0,
                                         _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 3,
                                         _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
-    ref_scores = orc.score_rows(urows, itab, ub, ib, 0.25 if with_bias else 0.0)
+    ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids] if with_bias else None, ib, 0.25 if with_bias else 0.0)
     got_scores = scratch.view(nb, I).cpu().numpy()
+    top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
+        seen = seen_lists[int(user_ids[b])]
         unseen = np.ones(I, dtype=bool)
-        unseen[seen_lists[b]] = False
+        unseen[seen] = False
         assert np.array_equal(got_scores[b][unseen], ref_scores[b][unseen]), f"row {b}: MFMA != fmaf chain"
-        rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen_lists[b], K, targets)
-        assert np.array_equal(top_ids[b].cpu().numpy(), rid), b
-        assert np.array_equal(top_sc[b].cpu().numpy(), rsc), b
-        assert np.array_equal(ts[b].cpu().numpy(), rts) and np.array_equal(tr[b].cpu().numpy(), rtr), b
+        rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen, K, targets)
+        assert np.array_equal(top_ids[b], rid), b
+        assert np.array_equal(top_sc[b], rsc), b
+        assert np.array_equal(ts[b], rts) and np.array_equal(tr[b], rtr), b
 
 
 def test_norm_adj_on_device(gpu_device):
@@ -665,3 +668,14 @@ def test_topk_rows_tie_heavy_rows(gpu_device, kind, I):
         seen = [np.sort(rng.choice(I, size=int(rng.integers(0, min(I, 40))), replace=False)).astype(np.int32) for _ in range(nb)]
     targets = np.array([3, I - 1, I // 2], dtype=np.int32)
     _topk_rows_vs_oracle(gpu_device, scores, seen, K, targets)
+
+
+@pytest.mark.parametrize("n,T", [(1, 1), (5893, 1), (100000, 3)])
+def test_hit_counts(gpu_device, n, T):
+    from recad_amd.evaluate import hit_counts
+    rng = np.random.default_rng(n)
+    rank = rng.integers(0, 300, (n, T)).astype(np.int32)
+    topks = (10, 20, 50, 100)
+    got = hit_counts(torch.from_numpy(rank).to(gpu_device), topks).cpu().numpy()
+    ref = np.array([[(rank[:, t] < k).sum() for k in topks] for t in range(T)])
+    assert np.array_equal(got, ref)
