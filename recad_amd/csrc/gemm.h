@@ -50,7 +50,7 @@ __device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, 
     return 0;
 }
 
-template <int BT>
+template <int BT, bool GATHER = false>
 __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
                                           int k0, long long rs, long long cs, const int *__restrict__ ridx = nullptr)
 {
@@ -60,7 +60,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
-            const long long gr = ridx ? ridx[r0 + r] : r0 + r;
+            const long long gr = GATHER ? ridx[r0 + r] : r0 + r;
             const float4 x = *reinterpret_cast<const float4 *>(src + gr * rs + (k0 + c));
             t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
         }
@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
             const int idx = p * 256 + tid;
             const int r = idx / kGK, c = idx % kGK;
             const int gr = r0 + r, gc = k0 + c;
-            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)(ridx ? ridx[gr] : gr) * rs + (long long)gc * cs] : 0.f;
+            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)(GATHER ? ridx[gr] : gr) * rs + (long long)gc * cs] : 0.f;
         }
     }
 }
@@ -123,7 +123,10 @@ __device__ __forceinline__ void tile_origin(int id, int gx, int gy, int &m0, int
 
 // BT = tile edge (128: each wave 2x2 accumulators of 32x32; 64: one accumulator per wave, for
 // skinny problems that would not fill the chip with 128-tiles).
-template <int BT, int NBUF, int MINW>
+// GATHER: rows of A (and of row_bias) are taken through g.a_ridx (scoring a block of user ids).
+// PLAIN: C = A.B^T with no bias / ReLU / mask / split-K (the LightGCN scoring GEMM) -- a separate
+// instantiation because the general epilogue costs this one registers (scratch spills at 3 workgroups/CU).
+template <int BT, int NBUF, int MINW, bool GATHER = false, bool PLAIN = false>
 static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs g, const int tiles_per_block)
 {
     constexpr int kGT = BT, TA = BT / 64, WS = BT / 2;  // TA accumulators per wave and dim, WS = wave sub-tile edge
@@ -162,8 +165,8 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     TileRegs<BT> ta, tb;
     int m0, n0;
     tile_origin<BT>(t_begin, gx, gy, m0, n0);
-    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx != nullptr), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
-    tile_load(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx);
+    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, GATHER), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
+    tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx);
     tile_load(tb, mb, g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
     tile_store(ta, ma, tileA(0));
     tile_store(tb, mb, tileB(0));
@@ -178,9 +181,9 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
             const int c1 = c_lo + (it + 1) % n_chunks;
             int m1, n1;
             tile_origin<BT>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
-            ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx != nullptr);
+            ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, GATHER);
             mb = tile_mode<BT>(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
-            tile_load(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx);
+            tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx);
             tile_load(tb, mb, g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
         }
         const int kc = min(kGK, g.K - c * kGK);
@@ -200,25 +203,72 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
         }
         if (c == c_hi - 1) {  // tile finished: epilogue, then clear the accumulators
             tile_origin<BT>(t_begin + it / n_chunks, gx, gy, m0, n0);
+            // accumulator register r of a 32x32 block = row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31:
+            // one store instruction writes two 128-byte row segments
+            if (PLAIN) {
+                const bool interior = (m0 + kGT <= g.M) && (n0 + kGT <= g.N);
+                float *cbase = g.C + (size_t)(m0 + wr * WS + 4 * lk) * g.ldc + (n0 + wc * WS + lr);
+                const size_t ld = (size_t)g.ldc;
+                if (interior) {  // no per-element tests, pointer bumps only
 #pragma unroll
-            for (int i = 0; i < TA; ++i)
+                    for (int i = 0; i < TA; ++i)
 #pragma unroll
-                for (int j = 0; j < TA; ++j)
+                        for (int j = 0; j < TA; ++j) {
+                            float *cp = cbase + (size_t)(i * 32) * ld + j * 32;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                        const int m = m0 + wr * WS + i * 32 + row, n = n0 + wc * WS + j * 32 + lr;
-                        if (m < g.M && n < g.N) {
-                            float s = acc[i][j][r];
-                            if (splits > 1) { unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s); acc[i][j][r] = 0.f; continue; }
-                            if (g.row_bias) s = ((s + g.row_bias[g.a_ridx ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
-                            else if (g.col_bias) s += g.col_bias[n];
-                            if (g.relu) s = s > 0.f ? s : 0.f;
-                            if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
-                            g.C[(size_t)m * g.ldc + n] = s;
+                            for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ld] = acc[i][j][r];
                         }
-                        acc[i][j][r] = 0.f;
-                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TA; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                                if (m0 + wr * WS + 4 * lk + row < g.M && n0 + wc * WS + lr + j * 32 < g.N)
+                                    cbase[(size_t)row * ld + j * 32] = acc[i][j][r];
+                            }
+                }
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TA; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            } else {
+                // general form (biases / ReLU / mask / split-K / edge tiles).  Where the accumulators are cleared
+                // is a measured choice (A/B on one box): inside the loop is +2 % for the NCF tower, afterwards is
+                // +35 % for the biased scoring GEMM (MF, short K: fewer scratch spills).
+                constexpr bool kClearInside = !GATHER;
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TA; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                            const int m = m0 + wr * WS + i * 32 + row, n = n0 + wc * WS + j * 32 + lr;
+                            if (m < g.M && n < g.N) {
+                                float s = acc[i][j][r];
+                                if (splits > 1) { unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s); if (kClearInside) acc[i][j][r] = 0.f; continue; }
+                                if (g.row_bias) s = ((s + g.row_bias[GATHER ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
+                                else if (g.col_bias) s += g.col_bias[n];
+                                if (g.relu) s = s > 0.f ? s : 0.f;
+                                if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                                g.C[(size_t)m * g.ldc + n] = s;
+                            }
+                            if (kClearInside) acc[i][j][r] = 0.f;
+                        }
+                if (!kClearInside) {
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TA; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            }
         }
         if (NBUF == 1) __syncthreads();  // everyone is done reading the single buffer
         if (more) {
@@ -241,7 +291,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         attr_set = true;
     }
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
-    if (nwg128 < 384 && variant != 3) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
+    if (nwg128 < 384 && variant != 3 && !g.a_ridx) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         const int splits = g.split_k > 1 ? g.split_k : 1;
         hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g, 1);
@@ -254,7 +304,10 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     const dim3 grid((nwg128 + tpb - 1) / tpb);
     // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
     // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
-    if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 2, 2>), grid, dim3(256), gemm_lds_bytes<128>(2), s, g, tpb);
+    const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.mask;
+    if (g.a_ridx && plain) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, true>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
+    else if (g.a_ridx) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, false>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
+    else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 2, 2>), grid, dim3(256), gemm_lds_bytes<128>(2), s, g, tpb);
     else hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     return hipGetLastError();
 }
