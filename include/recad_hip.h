@@ -251,6 +251,12 @@ typedef struct rk_ncf_desc {
     float *acts, *dacts;                       /* each float[max_batch * sum_{l=0..L} in_l] */
     float *d0;                                 /* float[max_batch] */
     int32_t max_batch, reserved;
+    /* optional split-K workspace for the backward (dX) tower GEMMs whose whole-K tiling would not fill
+     * the chip (batch 1024 against a few hundred outputs): K-slices park partial products here and are
+     * added in slice order (deterministic).  8 M floats is plenty for batch 1024; NULL / 0: no splitting. */
+    float *gemm_scratch;
+    int64_t gemm_scratch_floats;
+    float *wgrad_part;                         /* training: float[ceil(max_batch/64) * (2*factor + 1)] */
 } rk_ncf_desc;
 
 /* NCF.forward (ncf.py:112-131) for n pairs -> out[n].  Pairs are (users[b], items[b]), or -- when

@@ -67,6 +67,7 @@ class NCFDesc(C.Structure):
         ("grad", C.c_void_p * 24), ("m", C.c_void_p * 24), ("v", C.c_void_p * 24),
         ("acts", C.c_void_p), ("dacts", C.c_void_p), ("d0", C.c_void_p),
         ("max_batch", C.c_int32), ("reserved", C.c_int32),
+        ("gemm_scratch", C.c_void_p), ("gemm_scratch_floats", C.c_int64), ("wgrad_part", C.c_void_p),
     ]
 
 

@@ -45,6 +45,28 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Stream-ordered zero fill by a kernel.  Used instead of hipMemsetAsync wherever the NEXT launch on the
+// stream accumulates into the buffer: on this stack a memset was twice observed to overlap its neighbours
+// (as the trailing node of a replayed hipGraph -- lightgcn.hip -- and in front of a split-K GEMM that
+// adds into the zeroed tile with atomics: intermittently ~1/3 of a weight gradient lost a slice).
+static __global__ void rk_zero_kernel(unsigned *p, long long n_words)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    const long long n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? n_words / 4 : 0;
+    for (long long i = t; i < n4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = n4 * 4 + t; i < n_words; i += stride) p[i] = 0u;
+}
+static inline hipError_t rk_zero_async(void *p, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if (bytes & 3) return hipMemsetAsync(p, 0, bytes, s);
+    const long long n = (long long)(bytes / 4);
+    const int grid = (int)((n / 4 + 255) / 256 < 1 ? 1 : ((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256));
+    hipLaunchKernelGGL(rk_zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<unsigned *>(p), n);
+    return hipGetLastError();
+}
+
 // Adam coefficients for 1-based step t, torch.optim.Adam single-tensor math:
 // step_size = lr / (1 - b1^t); bc2s = sqrt(1 - b2^t).  Computed in double like Python does.
 struct AdamCoef {

@@ -27,6 +27,8 @@ struct GemmArgs {
     float const_add;
     int relu;
     const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
+    float *sk_part; long long sk_stride;   // split_k > 1 and sk_part: slice q STORES its partial at sk_part[q*sk_stride + m*ldc + n]
+                                           // (the caller adds the slices in order: deterministic, no zeroing, no atomics)
     int split_k;                           // > 1: gridDim.y K-slices, each ADDS its partial into C (C pre-zeroed,
                                            // no bias/relu/mask; float atomics => summation order not fixed)
 };
@@ -251,7 +253,12 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
                             const int m = m0 + wr * WS + i * 32 + row, n = n0 + wc * WS + j * 32 + lr;
                             if (m < g.M && n < g.N) {
                                 float s = acc[i][j][r];
-                                if (splits > 1) { unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s); if (kClearInside) acc[i][j][r] = 0.f; continue; }
+                                if (splits > 1) {
+                                    if (g.sk_part) g.sk_part[(size_t)blockIdx.y * g.sk_stride + (size_t)m * g.ldc + n] = s;
+                                    else unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s);
+                                    if (kClearInside) acc[i][j][r] = 0.f;
+                                    continue;
+                                }
                                 if (g.row_bias) s = ((s + g.row_bias[GATHER ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
                                 else if (g.col_bias) s += g.col_bias[n];
                                 if (g.relu) s = s > 0.f ? s : 0.f;
@@ -279,6 +286,15 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     }
 }
 
+// K-slices actually launched for a request of `splits`: every slice holds the same number of k-chunks
+// (the last one possibly fewer) and none is empty.
+inline int gemm_effective_splits(int K, int splits)
+{
+    if (splits <= 1) return 1;
+    const int chunks = (K + kGK - 1) / kGK, per = (chunks + splits - 1) / splits;
+    return (chunks + per - 1) / per;
+}
+
 // asynchronous launch; returns the hipError_t of the launch
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
@@ -293,8 +309,9 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
     if (nwg128 < 384 && variant != 3 && !g.a_ridx) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
-        const int splits = g.split_k > 1 ? g.split_k : 1;
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g, 1);
+        GemmArgs g2 = g;
+        const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
         return hipGetLastError();
     }
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form

@@ -18,6 +18,69 @@ static int gemm(hipStream_t s, int M, int N, int K, const float *A, long long a_
     return RK_OK;
 }
 
+// K-slices for a GEMM whose whole-K 64-tiles would not fill the chip (batch 1024 against a few hundred
+// outputs): aim at ~2-3 workgroups per CU, keep >= 2 k-chunks per slice, stay inside the workspace.
+static int pick_splits(int M, int N, int K, long long cap_floats)
+{
+    const long long nwg128 = (long long)((N + 127) / 128) * ((M + 127) / 128);
+    if (nwg128 >= 384) return 1;  // the 128-tile form takes it
+    const long long tiles = (long long)((N + 63) / 64) * ((M + 63) / 64);
+    long long sp = std::min<long long>(512 / std::max<long long>(tiles, 1), (K + 63) / 64);
+    sp = std::min<long long>(sp, cap_floats / std::max<long long>((long long)M * N, 1));
+    return gemm_effective_splits(K, (int)std::max<long long>(1, std::min<long long>(sp, 32)));
+}
+
+// y = epilogue(sum_q part[q]) in slice order q = 0..sp-1: bias + ReLU (forward) or the ReLU mask (dX)
+__global__ void slices_epilogue_kernel(long long n4, int N, int sp, const float *__restrict__ part, float *__restrict__ y,
+                                       const float *__restrict__ bias, int relu, const float *__restrict__ mask)
+{
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4 *>(part)[q];
+        for (int k = 1; k < sp; ++k) {
+            const float4 t = reinterpret_cast<const float4 *>(part)[(long long)k * n4 + q];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (bias) {
+            const float4 bb = *reinterpret_cast<const float4 *>(bias + (q * 4) % N);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (mask) {
+            const float4 mm = reinterpret_cast<const float4 *>(mask)[q];
+            v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+        }
+        reinterpret_cast<float4 *>(y)[q] = v;
+    }
+}
+
+// C[M,N] (contiguous: ldc == N == ldmask, N % 4 == 0) = epilogue(A.B^T).  Whole-K tiles with the fused epilogue
+// when they fill the chip or scratch == NULL; otherwise K-slices park their partial products in the workspace
+// and one elementwise pass adds them IN SLICE ORDER and applies the epilogue (deterministic).
+// Used for the dX GEMMs only.  The FORWARD GEMMs stay whole-K on purpose: their k-ordered fmaf chain is the
+// oracle's summation order, and the ReLU gates they decide are where ulp differences turn macroscopic -- a
+// unit that is dead for the whole batch has an exactly-zero weight-gradient row, and one flipped gate makes
+// Adam move that row by a full +-lr.  Splitting the forward K (ordered slices or atomics, both measured:
+// 2.85 -> 3.2 M samples/s) made tests/test_gpu_parity.py::test_ncf_train_golden fail in 3-7 of 14 runs with
+// 4e-4 differences on a third of MLP_layers.1.weight; with the dX GEMMs split only: 0 of 14.
+static int gemm_auto(hipStream_t s, int M, int N, int K, const float *A, long long a_rs, long long a_cs, const float *B,
+                     long long b_rs, long long b_cs, float *C, const float *bias, int relu, const float *mask,
+                     float *scratch, long long cap_floats)
+{
+    const int sp = (N % 4 == 0 && scratch) ? pick_splits(M, N, K, cap_floats) : 1;
+    if (sp <= 1) return gemm(s, M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, C, N, bias, relu, mask, N);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.split_k = sp; g.sk_part = scratch; g.sk_stride = (long long)M * N;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
+    g.C = C; g.ldc = N;
+    RK_HIP(gemm_f32_launch(g, s));
+    const long long n4 = (long long)M * N / 4;
+    hipLaunchKernelGGL(slices_epilogue_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, n4, N, sp,
+                       scratch, C, bias, relu, mask);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
 // ---------------------------------------------------------------- element kernels
 // pair b of this chunk: explicit (users[b], items[b]) or full-catalog (user_ids[b / I], b % I)
 struct PairSrc {
@@ -101,43 +164,75 @@ __global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__
     }
 }
 
-// gpw[k] = sum_b d0[b] * z[b,k], z = [ug*ig | xL]; gpb = sum_b d0[b].  64 outputs x 16 row groups
-// per workgroup, combined through LDS in fixed order (deterministic).
+// Predict-layer weight gradient: gpw[k] += sum_b d0[b] * z[b,k], z = [ug*ig | xL]; gpb += sum_b d0[b].
+// Deterministic two-stage sum (ulp noise in a weight gradient is amplified by Adam wherever the gradient is
+// otherwise exactly zero -- dead ReLU units -- so every reduction that can be ordered is): stage 1, one
+// workgroup per (64 outputs, slab of kWgradSlab batch rows), 16 row groups combined through LDS in fixed
+// order -> part[slab][k]; stage 2 adds the slabs in order.  (One workgroup per 64 outputs walking all 1024
+// rows' dependent gathers was 57 us of a 417 us step.)
+static constexpr int kWgradSlab = 64;
 __global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug,
                                                                 const float *__restrict__ ig, const float *__restrict__ xl,
-                                                                const float *__restrict__ d0, float *gpw, float *gpb)
+                                                                const float *__restrict__ d0, float *__restrict__ part)
 {
     __shared__ float red[16][64];
     const int kc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kc;
+    const int b_lo = blockIdx.y * kWgradSlab, b_hi = min(nb, b_lo + kWgradSlab);
     float s = 0.f;
     if (k <= 2 * f) {
-        for (int b = rg; b < nb; b += 16) {
-            float z;
-            if (k == 2 * f) z = 1.f;
-            else if (k < f) { long long u, i; pair_at(p, b, u, i); z = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
-            else z = xl[(size_t)b * f + (k - f)];
-            s += d0[b] * z;
+        float z[kWgradSlab / 16], dd[kWgradSlab / 16];
+#pragma unroll
+        for (int j = 0; j < kWgradSlab / 16; ++j) {
+            const int b = b_lo + rg + 16 * j;
+            z[j] = 0.f; dd[j] = 0.f;
+            if (b < b_hi) {
+                dd[j] = d0[b];
+                if (k == 2 * f) z[j] = 1.f;
+                else if (k < f) { long long u, i; pair_at(p, b, u, i); z[j] = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
+                else z[j] = xl[(size_t)b * f + (k - f)];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < kWgradSlab / 16; ++j) s += dd[j] * z[j];
     }
     red[rg][kc] = s;
     __syncthreads();
     if (rg == 0 && k <= 2 * f) {
         float t = red[0][kc];
         for (int q = 1; q < 16; ++q) t += red[q][kc];
-        if (k == 2 * f) gpb[0] += t; else gpw[k] += t;
+        part[(size_t)blockIdx.y * (2 * f + 1) + k] = t;
     }
 }
+__global__ void ncf_predict_wgrad_finish_kernel(int f, int n_slabs, const float *__restrict__ part, float *gpw, float *gpb)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 2 * f) return;
+    float t = 0.f;
+    for (int q = 0; q < n_slabs; ++q) t += part[(size_t)q * (2 * f + 1) + k];
+    if (k == 2 * f) gpb[0] += t; else gpw[k] += t;
+}
 
-// db[n] += sum_m dY[m,n]: 64 columns x 16 row groups per workgroup, fixed-order LDS combine
+// db[n] += sum_m dY[m,n]: 64 columns x 16 row groups per workgroup, fixed-order LDS combine (deterministic,
+// see above), eight independent loads in flight per thread.
 __global__ __launch_bounds__(1024) void colsum_kernel(int M, int N, const float *__restrict__ dY, float *db)
 {
     __shared__ float red[16][64];
     const int nc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + nc;
     float s = 0.f;
-    if (n < N)
-        for (int m = rg; m < M; m += 16) s += dY[(size_t)m * N + n];
+    if (n < N) {
+        for (int m0 = rg; m0 < M; m0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = m0 + 16 * j;
+                v[j] = m < M ? dY[(size_t)m * N + n] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+    }
     red[rg][nc] = s;
     __syncthreads();
     if (rg == 0 && n < N) {
@@ -219,8 +314,8 @@ static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, hip
     RK_CHECK_LAUNCH();
     for (int l = 0; l < L; ++l) {
         const int in = in_of(d, l), out = in / 2;
-        int rc = gemm(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
-                      d.acts + act_off(d, l + 1, d.max_batch), out, d.b[l], 1, nullptr, 0);
+        int rc = gemm_auto(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
+                           d.acts + act_off(d, l + 1, d.max_batch), d.b[l], 1, nullptr, nullptr, 0);  // whole-K: see gemm_auto
         if (rc) return rc;
     }
     return RK_OK;
@@ -261,6 +356,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
     const int L = d.n_layers, f = d.factor, E = f << (L - 1), T = 4 + 2 * L + 2;
     for (int t = 0; t < T; ++t)
         if (!d.grad[t] || !d.m[t] || !d.v[t]) RK_FAIL(RK_EINVAL, "ncf: grad/moment pointer %d missing", t);
+    if (!d.wgrad_part) RK_FAIL(RK_EINVAL, "ncf: desc.wgrad_part missing");
     hipStream_t s = (hipStream_t)stream;
     // tensor order: ug, ig, um, im, W0.., b0.., pw, pb
     float *P[RK_NCF_MAX_TENSORS];
@@ -292,9 +388,15 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         RK_CHECK_LAUNCH();
         hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
         RK_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64), dim3(1024), 0, s, p, nb, f, d.ug, d.ig, xl, d.d0,
-                           d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
-        RK_CHECK_LAUNCH();
+        {
+            const int n_slabs = (nb + kWgradSlab - 1) / kWgradSlab;
+            hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64, n_slabs), dim3(1024), 0, s, p, nb, f, d.ug, d.ig, xl,
+                               d.d0, d.wgrad_part);
+            RK_CHECK_LAUNCH();
+            hipLaunchKernelGGL(ncf_predict_wgrad_finish_kernel, dim3((2 * f + 1 + 255) / 256), dim3(256), 0, s, f, n_slabs, d.wgrad_part,
+                               d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
+            RK_CHECK_LAUNCH();
+        }
         // tower backward.  dY of the top layer is masked by its own ReLU here; for the layers below
         // the mask (x > 0, x = the previous layer's ReLU output) is applied in the dX GEMM's epilogue.
         for (int l = L - 1; l >= 0; --l) {
@@ -315,7 +417,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
             hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(1024), 0, s, nb, out, dy, d.grad[4 + L + l]);
             RK_CHECK_LAUNCH();
             // dX[nb,in] = dY W, masked by (x > 0) for l >= 1 (x is the previous layer's ReLU output)
-            rc = gemm(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, in, nullptr, 0, l >= 1 ? x : nullptr, in);
+            rc = gemm_auto(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, nullptr, 0, l >= 1 ? x : nullptr, d.gemm_scratch, d.gemm_scratch_floats);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(ncf_scatter_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, E, d.dacts, d.grad[2], d.grad[3]);

@@ -80,7 +80,9 @@ class NCF(BaseVictim):
                   "m": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["m"]],
                   "v": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["v"]],
                   "acts": torch.empty(mb * widths, device=dev), "dacts": torch.empty(mb * widths, device=dev),
-                  "d0": torch.empty(mb, device=dev), "max_batch": mb}
+                  "d0": torch.empty(mb, device=dev), "max_batch": mb,
+                  "gemm_scratch": torch.empty(8 << 20, device=dev),  # split-K slices of the dX GEMMs (rk_ncf_desc)
+                  "wgrad_part": torch.empty(((mb + 63) // 64) * (2 * f + 1), device=dev)}
             self._ws = ws
         ws = self._ws
         grp = self.optimizer.param_groups[0]
@@ -89,7 +91,8 @@ class NCF(BaseVictim):
                          beta1=float(b1), beta2=float(b2), eps=float(grp.get("eps", 1e-8)),
                          ug=_lib.ptr(ts[0].data), ig=_lib.ptr(ts[1].data), um=_lib.ptr(ts[2].data), im=_lib.ptr(ts[3].data),
                          pw=_lib.ptr(ts[-2].data), pb=_lib.ptr(ts[-1].data), acts=_lib.ptr(ws["acts"]), dacts=_lib.ptr(ws["dacts"]),
-                         d0=_lib.ptr(ws["d0"]), max_batch=ws["max_batch"])
+                         d0=_lib.ptr(ws["d0"]), max_batch=ws["max_batch"], gemm_scratch=_lib.ptr(ws["gemm_scratch"]),
+                         gemm_scratch_floats=ws["gemm_scratch"].numel(), wgrad_part=_lib.ptr(ws["wgrad_part"]))
         for l in range(L):
             d.W[l] = ts[4 + l].data.data_ptr()
             d.b[l] = ts[4 + L + l].data.data_ptr()

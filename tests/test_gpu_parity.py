@@ -334,8 +334,9 @@ def test_ncf_train_golden(gpu_device, name):
                 assert G.relerr(pick(nme, params[nme]), g["after1_" + nme].reshape(pick(nme, params[nme]).shape)) < 2e-5, nme
     steps = len(g["batch_len"])
     for nme in names:
-        # float-atomic scatter order varies run to run; Adam turns that into O(lr) noise on
-        # near-cancelling entries, so allow a few more outliers than the (deterministic) oracle check
+        # float-atomic summation order (embedding scatter, dW K-slices, bias column sums) varies run to run;
+        # Adam turns that into O(lr) noise on near-cancelling entries, so allow a few more outliers than the
+        # (deterministic) oracle check.  The activations themselves are deterministic (ordered K-slices).
         ok, info = G.adam_close(pick(nme, params[nme]), g["final_" + nme], 1e-3, steps, outlier_frac=5e-3, travel_frac=0.5)
         assert ok, (nme, info)
     if name == "ncf_dev_f8_l3":
