@@ -45,10 +45,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Stream-ordered zero fill by a kernel.  Used instead of hipMemsetAsync wherever the NEXT launch on the
-// stream accumulates into the buffer: on this stack a memset was twice observed to overlap its neighbours
-// (as the trailing node of a replayed hipGraph -- lightgcn.hip -- and in front of a split-K GEMM that
-// adds into the zeroed tile with atomics: intermittently ~1/3 of a weight gradient lost a slice).
+// Stream-ordered zero fill by a kernel.  Used instead of hipMemsetAsync where the NEXT launch on the stream
+// accumulates into the buffer with atomics: as the trailing node of a replayed hipGraph a memset node was
+// observed to overlap the next replay's first kernel on this stack (lightgcn.hip, launch_backward), so
+// buffers that are zeroed and then added into are cleared by a kernel.
 static __global__ void rk_zero_kernel(unsigned *p, long long n_words)
 {
     const long long stride = (long long)gridDim.x * blockDim.x, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -411,7 +411,7 @@ RK_EXPORT int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_tar
     if (n < 0 || !target_rank || !ks || !counts) RK_FAIL(RK_EINVAL, "rk_hit_counts: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)std::max<long long>(1, std::min<long long>(64, (n + 16383) / 16384));
-    if (grid > 1) RK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_targets * nk, s));
+    if (grid > 1) RK_HIP(rk_zero_async(counts, sizeof(int32_t) * (size_t)n_targets * nk, s));
     hipLaunchKernelGGL(hit_counts_kernel, dim3(grid), dim3(1024), 0, s, target_rank, (long long)n, n_targets, ks, nk, counts, grid > 1);
     RK_CHECK_LAUNCH();
     return RK_OK;
