@@ -62,11 +62,12 @@ def cpu_baseline(d, graph, dim, layers, batch, triplets, n_steps_req):
     user = (rng.standard_normal((U, dim), dtype=np.float32) * 0.1).astype(np.float32)
     item = (rng.standard_normal((I, dim), dtype=np.float32) * 0.1).astype(np.float32)
     st = orc.AdamState(user.shape, item.shape)
-    users, pos, neg = (t[: batch * 64] for t in triplets)
+    users, pos, neg = triplets
+    avail = len(users) // batch
     t0 = time.perf_counter()
     orc.lightgcn_step(csr, user, item, st, users[:batch], pos[:batch], neg[:batch], layers)
     one = time.perf_counter() - t0
-    n = n_steps_req or int(min(63, max(2, 15.0 / max(one, 1e-3))))
+    n = int(min(avail - 1, n_steps_req or max(2, 15.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     for s in range(1, n + 1):
         orc.lightgcn_step(csr, user, item, st, users[s * batch:(s + 1) * batch], pos[s * batch:(s + 1) * batch],
@@ -116,7 +117,7 @@ def main():
             c.append(ep[k])
         have += len(ep["users"])
     users, pos, neg = (torch.cat(c)[:need].contiguous() for c in cols)
-    host_triplets = tuple(t[: B * 64].cpu().numpy() for t in (users, pos, neg))
+    host_triplets = tuple(t[: B * 160].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline sample
 
     sharded = None
     if args.parallel == "rows":
