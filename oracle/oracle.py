@@ -31,6 +31,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.orc_lightgcn_step.restype = C.c_float
+        _LIB.orc_lightgcn_step_general.restype = C.c_float
         _LIB.orc_mf_step.restype = C.c_float
         _LIB.orc_ncf_grads.restype = C.c_float
     return _LIB
@@ -98,9 +99,11 @@ def adam(p, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
 
 
 def lightgcn_step(csr, user, item, state, users, pos, neg, L, lam=1e-4, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8,
-                  want_grads=False, apply_update=True):
-    """In-place on user/item/state.  Returns loss (and grads when asked)."""
+                  want_grads=False, apply_update=True, csr_t=None):
+    """In-place on user/item/state.  Returns loss (and grads when asked).  csr_t: the transpose of a
+    non-symmetric (dropped-out) forward graph, applied in the backward; None = symmetric."""
     rowptr, col, val = csr
+    rowptr_t, col_t, val_t = csr if csr_t is None else csr_t
     U, d = user.shape
     I = item.shape[0]
     users = np.ascontiguousarray(users, dtype=np.int64)
@@ -110,8 +113,9 @@ def lightgcn_step(csr, user, item, state, users, pos, neg, L, lam=1e-4, lr=1e-3,
     gi = np.empty_like(item) if want_grads else None
     if apply_update:
         state.t += 1
-    loss = lib().orc_lightgcn_step(
-        C.c_int32(U), C.c_int32(I), C.c_int32(d), C.c_int32(L), _p(rowptr), _p(col), _p(val), _p(user), _p(item),
+    loss = lib().orc_lightgcn_step_general(
+        C.c_int32(U), C.c_int32(I), C.c_int32(d), C.c_int32(L), _p(rowptr), _p(col), _p(val), _p(rowptr_t), _p(col_t),
+        _p(val_t), _p(user), _p(item),
         _p(state.m[0]), _p(state.v[0]), _p(state.m[1]), _p(state.v[1]), C.c_int32(max(state.t, 1)), _p(users), _p(pos),
         _p(neg), C.c_int32(len(users)), _f(lam), _f(lr), _f(b1), _f(b2), _f(eps), _p(gu), _p(gi),
         C.c_int32(1 if apply_update else 0))

@@ -144,8 +144,33 @@ API void orc_adam(int64_t n, float *p, const float *g, float *m, float *v, int32
  * forward propagate, 6 gathers (:122-130), reg (:149-157), BPR softplus (:158-163),
  * loss = mean softplus + lambda*reg (:165), backward, dense Adam on both tables (:168).
  * grad_user/grad_item (optional) receive dLoss/dE0.  Returns the step loss. */
+/* General form: the forward graph G (rowptr/col/val) and its transpose (rowptr_t/col_t/val_t) are given
+ * separately.  With graph dropout (lightgcn.py:62-80,91-95: every stored entry of the normalised adjacency is
+ * kept with probability keep_prob and divided by it, a fresh draw per training forward) the propagated
+ * graph is no longer symmetric, and autograd of torch.sparse.mm applies G^T in the backward. */
+API float orc_lightgcn_step_general(int32_t U, int32_t I, int32_t d, int32_t L,
+                            const int32_t *rowptr, const int32_t *col, const float *val,
+                            const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
+                            float *user, float *item, float *m_user, float *v_user, float *m_item, float *v_item,
+                            int32_t t, const int64_t *users, const int64_t *pos, const int64_t *neg, int32_t B,
+                            float lam, float lr, float b1, float b2, float eps,
+                            float *grad_user, float *grad_item, int32_t apply_update);
+
 API float orc_lightgcn_step(int32_t U, int32_t I, int32_t d, int32_t L,
                             const int32_t *rowptr, const int32_t *col, const float *val,
+                            float *user, float *item, float *m_user, float *v_user, float *m_item, float *v_item,
+                            int32_t t, const int64_t *users, const int64_t *pos, const int64_t *neg, int32_t B,
+                            float lam, float lr, float b1, float b2, float eps,
+                            float *grad_user, float *grad_item, int32_t apply_update)
+{
+    /* D^-1/2 A D^-1/2 is symmetric: G^T = G */
+    return orc_lightgcn_step_general(U, I, d, L, rowptr, col, val, rowptr, col, val, user, item, m_user, v_user, m_item, v_item,
+                                     t, users, pos, neg, B, lam, lr, b1, b2, eps, grad_user, grad_item, apply_update);
+}
+
+API float orc_lightgcn_step_general(int32_t U, int32_t I, int32_t d, int32_t L,
+                            const int32_t *rowptr, const int32_t *col, const float *val,
+                            const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
                             float *user, float *item, float *m_user, float *v_user, float *m_item, float *v_item,
                             int32_t t, const int64_t *users, const int64_t *pos, const int64_t *neg, int32_t B,
                             float lam, float lr, float b1, float b2, float eps,
@@ -186,11 +211,11 @@ API float orc_lightgcn_step(int32_t U, int32_t I, int32_t d, int32_t L,
         }
     }
     float floss = (float)(loss / B) + lam * (float)(0.5 * reg / B);
-    /* backward of mean-of-layers + L propagations (A symmetric): t = g; t = g + A t (L times) */
+    /* backward of mean-of-layers + L propagations: t = g; t = g + G^T t (L times) */
     float *tcur = (float *)malloc(sizeof(float) * nd), *tnxt = (float *)malloc(sizeof(float) * nd);
     memcpy(tcur, g, sizeof(float) * nd);
     for (int32_t l = 0; l < L; ++l) {
-        orc_spmm(N, rowptr, col, val, d, tcur, tnxt);
+        orc_spmm(N, rowptr_t, col_t, val_t, d, tcur, tnxt);
         for (size_t k = 0; k < nd; ++k) tnxt[k] += g[k];
         float *s = tcur; tcur = tnxt; tnxt = s;
     }
