@@ -147,6 +147,16 @@ typedef struct rk_lightgcn_desc {
     /* optional: device uint32[(N+31)/32] bitmap of the current minibatch's rows; when given (and
      * n_layers >= 2) the last forward layer computes only those rows of `light` */
     uint32_t *row_bits;
+    /* optional graph dropout of the TRAINING propagation (lightgcn.py:62-80,91-95; config keys dropout /
+     * keep_prob): keep_prob in (0,1) enables it (0 = off).  Every stored entry of the adjacency is kept with
+     * probability keep_prob and divided by it, one fresh mask per train step (counter-based RNG of drop_seed,
+     * the step index and the entry's position: the stream differs from torch.rand, the distribution does
+     * not).  The mask is drawn per stored entry, so the propagated graph is not symmetric and the backward
+     * applies its transpose: tpos[e] = position of the entry (col[e], row(e)) (device int32[nnz]). */
+    float keep_prob;
+    int32_t reserved3;
+    uint64_t drop_seed;
+    const int32_t *tpos;
 } rk_lightgcn_desc;
 #define RK_MAX_GRAPH_STEPS 64
 
@@ -158,6 +168,9 @@ int rk_lightgcn_destroy(rk_lightgcn_t h);
 /* LightGCN.computer(), recad/model/victim/lightgcn.py:82-113: desc.light[N,dim] =
  * mean_l(A^l [U;I]).  Users are rows [0,U), items rows [U,N). */
 int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream);
+/* The same through a dropped-out graph (computer() of a module in training mode with dropout > 0,
+ * lightgcn.py:91-95): mask_seed picks the mask; requires desc.keep_prob > 0. */
+int rk_lightgcn_propagate_dropout(rk_lightgcn_t h, uint64_t mask_seed, void *stream);
 
 /* One epoch of LightGCN.train_step, recad/model/victim/lightgcn.py:137-169, over the
  * pre-sampled triplets (device int64[n], the tensors ImplicitData.generate_batch yields,

@@ -42,6 +42,7 @@ class LightGCNDesc(C.Structure):
         ("hot_H", C.c_int32), ("max_items", C.c_int32), ("n_long", C.c_int32), ("two_classes", C.c_int32),
         ("hot_grid", C.c_int32), ("reserved2", C.c_int32),
         ("row_bits", C.c_void_p),
+        ("keep_prob", C.c_float), ("reserved3", C.c_int32), ("drop_seed", C.c_uint64), ("tpos", C.c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
     "rk_lightgcn_propagate": [_P, _P],
+    "rk_lightgcn_propagate_dropout": [_P, C.c_uint64, _P],
     "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],

@@ -93,4 +93,23 @@ __device__ __forceinline__ void adam_elem(float &p, float &m, float &v, float g,
 }
 
 // device state words (int32) shared by the kernels of a training epoch
-enum { ST_STEP_BASE = 0, ST_ADAM_T = 1, ST_NTRIP_LO = 2, ST_NTRIP_HI = 3, ST_BATCH = 4, ST_WORDS = 16 };
+enum { ST_STEP_BASE = 0, ST_ADAM_T = 1, ST_NTRIP_LO = 2, ST_NTRIP_HI = 3, ST_BATCH = 4, ST_DROP_LO = 5, ST_DROP_HI = 6, ST_WORDS = 16 };
+
+// splitmix64 finaliser: the counter-based RNG of the samplers and of the graph dropout
+__host__ __device__ __forceinline__ unsigned long long rk_mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// Graph dropout (lightgcn.py:62-71): stored entry `id` of the adjacency survives this step iff its 24-bit
+// uniform is below keep_prob * 2^24.  seed_step = rk_drop_step_seed(base seed, step index).
+__host__ __device__ __forceinline__ unsigned long long rk_drop_step_seed(unsigned long long base, unsigned long long step)
+{
+    return rk_mix64(base ^ rk_mix64(step));
+}
+__host__ __device__ __forceinline__ bool rk_drop_keep(unsigned long long seed_step, unsigned id, unsigned thresh24)
+{
+    return (unsigned)(rk_mix64(seed_step ^ ((unsigned long long)id * 0xD1342543DE82EF95ULL)) >> 40) < thresh24;
+}

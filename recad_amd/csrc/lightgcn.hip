@@ -152,6 +152,8 @@ static int check_desc(const rk_lightgcn_desc &d)
     if (d.item_emb != d.user_emb + ud || d.m_item != d.m_user + ud || d.v_item != d.v_user + ud)
         RK_FAIL(RK_EINVAL, "lightgcn: the item table/moments must directly follow the user table/moments in memory "
                            "(one [U+I, dim] allocation; the kernels address E0 with a single base)");
+    if (d.keep_prob != 0.f && (!(d.keep_prob > 0.f) || d.keep_prob > 1.f || !d.tpos))
+        RK_FAIL(RK_EINVAL, "lightgcn: graph dropout needs 0 < keep_prob <= 1 and the transpose index tpos");
     if (((size_t)d.n_users + d.n_items) * d.dim * sizeof(float) >= (1ULL << 32))
         RK_FAIL(RK_EINVAL, "lightgcn: (U+I)*dim*4 must be < 4 GiB (32-bit gather offsets)");
     return RK_OK;
@@ -194,6 +196,16 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
 }
 
 
+// graph dropout of one launch (spmm.h, SpmmArgs::drop_*): mode 1/2 = train step k (first forward layer /
+// every later launch of the step), mode 3 = explicit mask seed
+static void set_dropout(SpmmArgs &a, const rk_lightgcn_desc &d, int mode, int k, unsigned long long seed, bool transposed)
+{
+    a.drop_thresh24 = (unsigned)((double)d.keep_prob * 16777216.0);
+    a.drop_inv_keep = 1.0f / d.keep_prob;
+    a.drop_mode = mode; a.drop_k = k; a.drop_seed = seed; a.drop_state = d.state;
+    a.drop_tpos = transposed ? d.tpos : nullptr;
+}
+
 // forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
 struct BatchRef {
     const int64_t *users, *pos, *neg;
@@ -202,7 +214,9 @@ struct BatchRef {
 
 // forward: light = mean_l A^l E0.  With a BatchRef (training) the first layer marks the minibatch's
 // rows in d.row_bits and the last layer computes only those rows of `light`.
-static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchRef *batch = nullptr)
+// drop: 0 = none, 1 = the train step's mask (batch->k), 3 = the mask of mask_seed
+static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchRef *batch = nullptr, int drop = 0,
+                          unsigned long long mask_seed = 0ULL)
 {
     const int L = d.n_layers;
     const float inv = 1.0f / (float)(L + 1);
@@ -227,6 +241,8 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
             }
             if (l == L) a.row_filter = d.row_bits;
         }
+        if (drop == 1) set_dropout(a, d, l == 1 ? 1 : 2, batch ? batch->k : 0, d.drop_seed, false);
+        else if (drop == 3) set_dropout(a, d, 3, 0, rk_drop_step_seed(d.drop_seed, mask_seed), false);
         RK_HIP(spmm_launch(a, s));
     }
     return RK_OK;
@@ -256,6 +272,7 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
         if (d.row_bits && L >= 2) {
             if (last) { a.clear_bits = d.row_bits; a.n_words = (N + 31) / 32; }
         }
+        if (d.keep_prob > 0.f) set_dropout(a, d, 2, k, d.drop_seed, true);
         a.e.add = last ? d.gego : d.gprop;
         if (last) {
             a.e.zero1 = d.gego;
@@ -283,7 +300,7 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
                        float *loss_partials, int k, int apply_update, int bump, hipStream_t s)
 {
     const BatchRef br{users, pos, neg, k};
-    int rc = launch_forward(d, s, &br);
+    int rc = launch_forward(d, s, &br, d.keep_prob > 0.f ? 1 : 0);
     if (rc) return rc;
     BprArgs b;
     b.U = d.n_users; b.d = d.dim; b.L = d.n_layers; b.lam = d.lambda;
@@ -303,6 +320,13 @@ RK_EXPORT int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream)
 {
     if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate: null handle");
     return launch_forward(h->d, (hipStream_t)stream);
+}
+
+RK_EXPORT int rk_lightgcn_propagate_dropout(rk_lightgcn_t h, uint64_t mask_seed, void *stream)
+{
+    if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate_dropout: null handle");
+    if (!(h->d.keep_prob > 0.f)) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate_dropout: desc.keep_prob is 0");
+    return launch_forward(h->d, (hipStream_t)stream, nullptr, 3, (unsigned long long)mask_seed);
 }
 
 RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,

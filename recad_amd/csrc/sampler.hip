@@ -4,13 +4,7 @@
 // stream differs from numpy's (distributional parity is what the tests check).
 #include "common.h"
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
-{
-    z += 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) { return rk_mix64(z); }
 __device__ __forceinline__ unsigned long long rnd(unsigned long long seed, unsigned long long draw, unsigned k)
 {
     return mix64(mix64(seed ^ (draw * 0xD1342543DE82EF95ULL)) + k);

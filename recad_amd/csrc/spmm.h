@@ -62,8 +62,54 @@ struct SpmmArgs {
     int n_words, mark_U, mark_k;
     const int64_t *mark_users, *mark_pos, *mark_neg;
     const int *mark_state;
+    // Graph dropout of a training forward/backward (lightgcn.py:62-80): drop_thresh24 = keep_prob * 2^24
+    // (0 = off); every stored entry e is kept iff rk_drop_keep(seed_step, id, thresh) and scaled by
+    // drop_inv_keep.  id = e in the forward, drop_tpos[e] (the position of the transposed entry) in the
+    // backward, which applies G^T through the same symmetric-structure CSR.
+    // drop_mode 1: seed_step from the global step index drop_state[ST_ADAM_T] + drop_k (first forward layer;
+    // block 0 also stashes it in drop_state[ST_DROP_LO/HI]); 2: read the stash (the last backward launch of a
+    // chunk bumps ST_ADAM_T itself); 3: drop_seed is the step seed (inference call in training mode).
+    unsigned drop_thresh24;
+    float drop_inv_keep;
+    int drop_mode, drop_k;
+    unsigned long long drop_seed;
+    int *drop_state;
+    const int *drop_tpos;
     SpmmEpi e;
 };
+
+struct DropCtx {
+    unsigned long long seed_step;
+    unsigned thresh24;
+    float inv_keep;
+    const int *tpos;
+};
+__device__ __forceinline__ DropCtx drop_ctx(const SpmmArgs &a)
+{
+    DropCtx c;
+    c.thresh24 = a.drop_thresh24; c.inv_keep = a.drop_inv_keep; c.tpos = a.drop_tpos; c.seed_step = 0ULL;
+    if (a.drop_thresh24) {
+        if (a.drop_mode == 1) {
+            c.seed_step = rk_drop_step_seed(a.drop_seed, (unsigned long long)(unsigned)(a.drop_state[ST_ADAM_T] + a.drop_k));
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                a.drop_state[ST_DROP_LO] = (int)(unsigned)c.seed_step;
+                a.drop_state[ST_DROP_HI] = (int)(unsigned)(c.seed_step >> 32);
+            }
+        } else if (a.drop_mode == 2) {
+            c.seed_step = (unsigned long long)(unsigned)a.drop_state[ST_DROP_LO] | ((unsigned long long)(unsigned)a.drop_state[ST_DROP_HI] << 32);
+        } else {
+            c.seed_step = a.drop_seed;
+        }
+    }
+    return c;
+}
+// value of stored entry e under the step's dropout mask
+__device__ __forceinline__ float drop_val(const DropCtx &c, int e, float v)
+{
+    if (!c.thresh24) return v;
+    const unsigned id = (unsigned)(c.tpos ? c.tpos[e] : e);
+    return rk_drop_keep(c.seed_step, id, c.thresh24) ? v * c.inv_keep : 0.f;
+}
 
 static constexpr int kSpmmWavesMax = 16;
 // waves per workgroup (schedule and launch must agree); RK_SPMM_WAVES overrides for tuning
@@ -113,20 +159,20 @@ __device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n
 // cross-group reduction every lane holds the total for its float4 slot.
 template <int D, int UNMAX>
 __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, const float *__restrict__ val, int eb, int ee,
-                                               const float *__restrict__ x, int lane)
+                                               const float *__restrict__ x, int lane, const DropCtx &dc)
 {
     constexpr int G = D / 4, NG = 64 / G;
     const int grp = lane / G, sub = lane % G;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_next = 0;
     float a_next = 0.f;
-    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = val[eb + lane]; }
+    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = drop_val(dc, eb + lane, val[eb + lane]); }
     for (int base = eb; base < ee; base += 64) {
         const int n = min(64, ee - base);
         const int c = c_next;
         const float a = a_next;
         c_next = 0; a_next = 0.f;
-        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = val[base + 64 + lane]; }
+        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = drop_val(dc, base + 64 + lane, val[base + 64 + lane]); }
         const int iters = (n + NG - 1) / NG;
         int t = 0;
         for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
@@ -284,6 +330,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
             atomicOr(&a.mark_bits[r2 >> 5], 1u << (r2 & 31));
         }
     }
+    const DropCtx dc = drop_ctx(a);
     int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
     const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x);  // scalar loads, in flight under the gather
     if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
@@ -298,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         const int n = pk.x >= 0 ? pk.z - pk.y : 0;
         int c = 0;
         float av = 0.f;
-        if (sub < n) { c = a.col[pk.y + sub]; av = a.val[pk.y + sub]; }
+        if (sub < n) { c = a.col[pk.y + sub]; av = drop_val(dc, pk.y + sub, a.val[pk.y + sub]); }
         float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
         if (pk.x >= 0) {
             const size_t eoff = (size_t)pk.x * D + (size_t)sub * 4;
@@ -326,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         return;
     }
     if (ds.z > ds.y && !(a.dbg & 1)) {
-        acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane);
+        acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane, dc);
     }
     if (lane < G) part[w][lane] = acc;
     __syncthreads();
@@ -500,6 +547,7 @@ static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const Spm
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
+    const DropCtx dc = drop_ctx(a);
     const int4 ds = a.wave_desc[(size_t)blockIdx.x * kSpmmWaves + w];
     const int r = ds.x;
     float acc[kGenMaxC];
@@ -507,7 +555,7 @@ static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const Spm
     for (int k = 0; k < kGenMaxC; ++k) acc[k] = 0.f;
     for (int e = ds.y; e < ds.z; ++e) {
         const float *x = a.x + (size_t)a.col[e] * d;
-        const float av = a.val[e];
+        const float av = drop_val(dc, e, a.val[e]);
 #pragma unroll
         for (int k = 0; k < kGenMaxC; ++k)
             if (k * 64 + lane < d) acc[k] += av * x[k * 64 + lane];
@@ -575,7 +623,7 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     static const int hot_off = getenv("RK_SPMM_NO_HOT") ? atoi(getenv("RK_SPMM_NO_HOT")) : 0;
     static const int dbg0 = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
     a.dbg = dbg0;
-    const bool filtered = a.row_filter || a.mark_bits || a.clear_bits;  // segment kernel only
+    const bool filtered = a.row_filter || a.mark_bits || a.clear_bits || a.drop_thresh24;  // segment kernel only
     if (a.hot_H > 0 && !hot_off && !filtered && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
         static bool attr_set = false;
         if (!attr_set) {

@@ -22,6 +22,18 @@ class CsrGraph:
             self._sched[dim] = self._schedule(self.n_rows, self.rowptr, self.class_split, dim)
         return self._sched[dim]
 
+    def transpose_index(self):
+        """tpos[e] = position of the transposed entry (col[e], row(e)) in this CSR (int32 device tensor, cached).
+        The adjacency is structurally symmetric and sorted by (row, col), so listing the entries in
+        (col, row) order enumerates the transposed entries in CSR order: tpos = argsort(col*N + row).
+        Used by the graph dropout, whose per-entry mask makes the propagated graph non-symmetric."""
+        if getattr(self, "_tpos", None) is None:
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.rowptr.device),
+                                           (self.rowptr[1:] - self.rowptr[:-1]).long())
+            key = self.col.long() * self.n_rows + rows
+            self._tpos = torch.argsort(key).to(torch.int32).contiguous()
+        return self._tpos
+
     def hot_tables(self, dim, min_permille=150):
         """Tables of the persistent LDS hot-row SpMM (rk_spmm_hot_build/_upload), cached per dim.
         None when too few nonzeros would be served from LDS to pay for the staging."""

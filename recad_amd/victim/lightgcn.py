@@ -36,8 +36,12 @@ class LightGCN(BaseVictim):
         self.A_split = config["A_split"]
         if self.A_split:
             raise ValueError("A_split is not support in LightGCN yet")  # lightgcn.py:38-39
-        if config["dropout"]:
-            raise ValueError("graph dropout is not supported by the HIP path (reference default is 0.0)")
+        # graph dropout (lightgcn.py:62-80,91-95): `dropout` truthy switches it on, `keep_prob` is the rate
+        self.graph_dropout = bool(config["dropout"])
+        if self.graph_dropout and not (0.0 < float(self.keep_prob) <= 1.0):
+            raise ValueError(f"keep_prob must be in (0, 1], got {self.keep_prob}")
+        self._drop_seed = None     # drawn from torch's global RNG on first use (the reference draws torch.rand per step)
+        self._drop_calls = 0       # one fresh mask per computer() call outside train_step
         # same RNG consumption order as lightgcn.py:40-48
         self.embedding_user = nn.Embedding(self.num_users, self.latent_dim)
         self.embedding_item = nn.Embedding(self.num_items, self.latent_dim)
@@ -112,7 +116,8 @@ class LightGCN(BaseVictim):
         if dev.type != "cuda":
             raise _lib.HipCallError("LightGCN parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
         wu, wi, su, si = self._fuse_tables()
-        key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad))
+        key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
+               self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0)
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -126,7 +131,10 @@ class LightGCN(BaseVictim):
         ws["row_bits"] = torch.zeros((N + 31) // 32, device=dev, dtype=torch.int32) if self.use_batch_sparsity else None
         grp = self.optimizer.param_groups[0]
         betas = grp.get("betas", (0.9, 0.999))
-        hot = g.hot_tables(d) if (self.use_lds_hot_rows and d in (32, 64, 128, 256)) else None
+        hot = g.hot_tables(d) if (self.use_lds_hot_rows and not self.graph_dropout and d in (32, 64, 128, 256)) else None
+        if self.graph_dropout and self._drop_seed is None:
+            self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ws["tpos"] = g.transpose_index() if self.graph_dropout else None
         ws["hot"] = hot  # keeps the tables alive as long as the handle
         desc = _lib.LightGCNDesc(
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
@@ -146,7 +154,9 @@ class LightGCN(BaseVictim):
             partials=_lib.ptr(hot["partials"]) if hot else None, hot_H=hot["H"] if hot else 0,
             max_items=hot["max_items"] if hot else 0, n_long=hot["n_long"] if hot else 0,
             two_classes=hot["two_classes"] if hot else 0, hot_grid=hot["grid"] if hot else 0,
-            row_bits=_lib.ptr(ws["row_bits"]))
+            row_bits=_lib.ptr(ws["row_bits"]),
+            keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
+            drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]))
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         self._handle, self._handle_key, self._ws = h, key, ws
@@ -168,7 +178,14 @@ class LightGCN(BaseVictim):
     def computer(self):
         """lightgcn.py:82-113 -> (users[U,d], items[I,d]); views of the handle's workspace."""
         h = self._ensure_handle(want_grad=self._ws is not None and self._ws.get("grad") is not None)
-        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "rk_lightgcn_propagate")
+        if self.graph_dropout and self.training:
+            # lightgcn.py:91-95: a module in training mode propagates through a freshly dropped-out graph -- also
+            # when the workflows score under no_grad without calling .eval() (normal.py:61-67)
+            self._drop_calls += 1
+            _lib.check(_lib.lib().rk_lightgcn_propagate_dropout(h, (1 << 40) + self._drop_calls, _lib.stream_ptr()),
+                       "rk_lightgcn_propagate_dropout")
+        else:
+            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "rk_lightgcn_propagate")
         light = self._ws["light"]
         return light[: self.num_users], light[self.num_users:]
 

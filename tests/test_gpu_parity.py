@@ -546,6 +546,86 @@ def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source):
     assert np.allclose(out, ref, rtol=2e-4, atol=1e-6)
 
 
+def _mix64(z):
+    """numpy mirror of rk_mix64 (recad_amd/csrc/common.h), uint64 wrap-around arithmetic"""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(z, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _dropout_mask(base_seed, step, nnz, keep_prob):
+    """keep[e] of rk_drop_keep for every stored entry e under the step's seed (common.h)"""
+    with np.errstate(over="ignore"):
+        seed_step = _mix64(np.uint64(base_seed) ^ _mix64(np.uint64(step)))
+        ids = np.arange(nnz, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)
+        u24 = _mix64(seed_step ^ ids) >> np.uint64(40)
+    return u24 < np.uint64(int(float(np.float32(keep_prob)) * 16777216.0))
+
+
+@pytest.mark.parametrize("d,L,graph_source,graph_steps", [(64, 3, "train", 0), (64, 3, "train", 4), (32, 2, "reference", 4),
+                                                        (100, 1, "train", 0)])
+def test_lightgcn_graph_dropout_vs_oracle(gpu_device, d, L, graph_source, graph_steps):
+    """Graph dropout (lightgcn.py:62-80,91-95; config dropout=True, keep_prob): the HIP path draws one
+    counter-based mask per train step and applies the TRANSPOSE of the dropped-out graph in the backward.
+    The oracle gets the same masks as explicit forward / transposed CSR value arrays."""
+    from recad_amd import dataset, model, synth
+    keep, B, base_seed = 0.6, 512, 0x1234567
+    dd = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"],
+                             device=gpu_device, graph_source=graph_source, seed=d + L, pairwise_batch_size=B)
+    torch.manual_seed(d * 10 + L)
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=d, lightGCN_n_layers=L, dropout=True, keep_prob=keep).I(dataset=ds)
+    m._drop_seed = base_seed
+    m = m.to(gpu_device)
+    m.graph_steps = graph_steps
+    u0 = m.embedding_user.weight.detach().cpu().numpy().copy()
+    i0 = m.embedding_item.weight.detach().cpu().numpy().copy()
+    g = ds.graph_csr()
+    rowptr, col, val = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
+    tpos = g.transpose_index().cpu().numpy()
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    assert np.array_equal(col[tpos], rows) and np.array_equal(rows[tpos], col), "tpos is the transposed entry"
+    inv_keep = np.float32(1.0) / np.float32(keep)
+
+    def dropped(seed, step):
+        mk = _dropout_mask(seed, step, len(val), keep)
+        fwd = np.where(mk, val * inv_keep, np.float32(0)).astype(np.float32)
+        bwd = np.where(mk[tpos], val * inv_keep, np.float32(0)).astype(np.float32)
+        return mk, (rowptr, col, fwd), (rowptr, col, bwd)
+
+    st = orc.AdamState(u0.shape, i0.shape)
+    t = 0
+    fracs = []
+    for ep in range(2):
+        e = ds.generate_epoch()
+        users, pos, neg = (e[k] for k in LGN_KEYS)
+        part = m._run_epoch(users, pos, neg, B)
+        losses = part.sum(1).double().cpu().numpy()
+        un, pn, nn_ = users.cpu().numpy(), pos.cpu().numpy(), neg.cpu().numpy()
+        for s in range(len(losses)):
+            sl = slice(s * B, (s + 1) * B)
+            mk, cf, cb = dropped(base_seed, t)
+            fracs.append(mk.mean())
+            ref = orc.lightgcn_step(cf, u0, i0, st, un[sl], pn[sl], nn_[sl], L, csr_t=cb)
+            assert abs(losses[s] - ref) <= 2e-5 * abs(ref), (ep, s, losses[s], ref)
+            t += 1
+    assert abs(np.mean(fracs) - keep) < 0.01, "kept fraction"
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy(), u0) < TABLE_RTOL
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy(), i0) < TABLE_RTOL
+    # computer() of a module in training mode: a fresh mask per call; in eval mode: the full graph
+    m.train()
+    calls0 = m._drop_calls
+    lu, li = m.computer()
+    light = torch.cat([lu, li]).cpu().numpy()
+    _, cf, _ = dropped(base_seed, (1 << 40) + calls0 + 1)
+    assert G.relerr(light, orc.lightgcn_propagate(cf, u0, i0, L)) < 2e-5
+    m.eval()
+    lu, li = m.computer()
+    assert G.relerr(torch.cat([lu, li]).cpu().numpy(), orc.lightgcn_propagate((rowptr, col, val), u0, i0, L)) < 2e-5
+
+
 @pytest.mark.parametrize("dim", [16, 64, 100, 130])
 def test_mf_vs_oracle_shapes(gpu_device, dim):
     from recad_amd import dataset, model, synth
