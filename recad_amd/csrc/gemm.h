@@ -85,8 +85,8 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
     }
 }
 
-template <int BT>
-__device__ __forceinline__ void tile_store(const TileRegs<BT> &t, int mode, float (*dst)[kGLd])
+template <int BT, int LD>
+__device__ __forceinline__ void tile_store(const TileRegs<BT> &t, int mode, float (*dst)[LD])
 {
     const int tid = threadIdx.x;
     constexpr int NP = BT / 32;
@@ -94,7 +94,11 @@ __device__ __forceinline__ void tile_store(const TileRegs<BT> &t, int mode, floa
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
-            dst[r][c] = t.v[p * 4]; dst[r][c + 1] = t.v[p * 4 + 1]; dst[r][c + 2] = t.v[p * 4 + 2]; dst[r][c + 3] = t.v[p * 4 + 3];
+            if (LD % 4 == 0) {  // rows are 16-byte aligned: one ds_write_b128
+                *reinterpret_cast<float4 *>(&dst[r][c]) = make_float4(t.v[p * 4], t.v[p * 4 + 1], t.v[p * 4 + 2], t.v[p * 4 + 3]);
+            } else {
+                dst[r][c] = t.v[p * 4]; dst[r][c + 1] = t.v[p * 4 + 1]; dst[r][c + 2] = t.v[p * 4 + 2]; dst[r][c + 3] = t.v[p * 4 + 3];
+            }
         }
     } else if (mode == 2) {
         constexpr int RQ = BT / 4, KP = 256 / RQ;
@@ -295,6 +299,102 @@ inline int gemm_effective_splits(int K, int splits)
     return (chunks + per - 1) / per;
 }
 
+// ---- 64x64-tile form on v_mfma_f32_16x16x4_f32, for problems with too few 128-tiles to fill the chip (the NCF
+// tower at batch 1024).  Each wave owns a 32x32 sub-tile as 2x2 INDEPENDENT 16x16 accumulators: with one
+// 32x32 accumulator per wave every MFMA waits for the previous one's result (measured: the MFMA phase alone ran
+// at half rate -- 30 us of the 47 us layer-0 GEMM with loads and LDS stores switched off); four independent
+// chains issue back to back at the same 256 flop/clk/CU.  Same k-ordered accumulation, same operand layouts
+// (strided A/B, bounds-checked edges), same general epilogue (column bias, ReLU, mask, split-K by atomics or
+// parked slices) as gemm_f32_kernel.  LDS rows are padded to 36 floats: the operand read of a k-step touches
+// 16 rows x 4 k's = banks 4*row + k, each exactly twice (the minimum for 64 lanes), and rows stay 16-byte aligned.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static constexpr int kSLd = kGK + 4;
+static __global__ __launch_bounds__(256, 4) void gemm_f32_skinny_kernel(const GemmArgs g)
+{
+    constexpr int BT = 64;
+    __shared__ __attribute__((aligned(16))) float sA[BT][kSLd];
+    __shared__ __attribute__((aligned(16))) float sB[BT][kSLd];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int gx = (g.N + BT - 1) / BT;
+    const int m0 = ((int)blockIdx.x / gx) * BT, n0 = ((int)blockIdx.x % gx) * BT;
+    const int all_chunks = (g.K + kGK - 1) / kGK;
+    const int splits = g.split_k > 1 ? g.split_k : 1;
+    const int per = (all_chunks + splits - 1) / splits;
+    const int c_lo = (int)blockIdx.y * per, c_hi = min(all_chunks, c_lo + per);
+    if (c_lo >= c_hi) return;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l16 = lane & 15, lq = lane >> 4;
+    TileRegs<BT> ta, tb;
+    int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
+    tile_load(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs);
+    tile_load(tb, mb, g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
+    tile_store(ta, ma, sA);
+    tile_store(tb, mb, sB);
+    __syncthreads();
+    for (int c = c_lo; c < c_hi; ++c) {
+        const bool more = c + 1 < c_hi;
+        if (more) {  // the next chunk's global loads fly under this chunk's MFMAs
+            ma = tile_mode<BT>(g.A, g.M, g.K, m0, (c + 1) * kGK, g.a_rs, g.a_cs);
+            mb = tile_mode<BT>(g.B, g.N, g.K, n0, (c + 1) * kGK, g.b_rs, g.b_cs);
+            tile_load(ta, ma, g.A, g.M, g.K, m0, (c + 1) * kGK, g.a_rs, g.a_cs);
+            tile_load(tb, mb, g.B, g.N, g.K, n0, (c + 1) * kGK, g.b_rs, g.b_cs);
+        }
+        // a partial last chunk is zero-filled by the bounds-checked loads, so whole k-steps of 4 are safe
+        const int kc = (min(kGK, g.K - c * kGK) + 3) & ~3;
+        auto k_step = [&](const int kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i] = sA[wr * 32 + i * 16 + l16][kk + lq];
+                bv[i] = sB[wc * 32 + i * 16 + l16][kk + lq];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        };
+        if (kc == kGK) {
+#pragma unroll
+            for (int kk = 0; kk < kGK; kk += 4) k_step(kk);
+        } else {
+            for (int kk = 0; kk < kc; kk += 4) k_step(kk);
+        }
+        __syncthreads();  // everyone is done reading the buffer
+        if (more) {
+            tile_store(ta, ma, sA);
+            tile_store(tb, mb, sB);
+        }
+        __syncthreads();
+    }
+    // accumulator register r of a 16x16 block = row 4*(lane>>4) + r, column lane&15
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + i * 16 + 4 * lq + r, n = n0 + wc * 32 + j * 16 + l16;
+                if (m < g.M && n < g.N) {
+                    float s = acc[i][j][r];
+                    if (splits > 1) {
+                        if (g.sk_part) g.sk_part[(size_t)blockIdx.y * g.sk_stride + (size_t)m * g.ldc + n] = s;
+                        else unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s);
+                        continue;
+                    }
+                    if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
+                    else if (g.col_bias) s += g.col_bias[n];
+                    if (g.relu) s = s > 0.f ? s : 0.f;
+                    if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                    g.C[(size_t)m * g.ldc + n] = s;
+                }
+            }
+}
+
 // asynchronous launch; returns the hipError_t of the launch
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
@@ -311,7 +411,8 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         GemmArgs g2 = g;
         const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
+        if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
+        else hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(nwg, splits), dim3(256), 0, s, g2);
         return hipGetLastError();
     }
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
