@@ -54,7 +54,7 @@ class NCF(BaseVictim):
         self._E = E
         self._ws = None
         self._t = 0
-        self.max_batch = 4096
+        self.max_batch = 16384  # forward chunk of the full-catalog evaluation: large enough for the 128x128-tile GEMM
 
     # ------------------------------------------------------------------ C-ABI descriptor
     def _tensors(self):
