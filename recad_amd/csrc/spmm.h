@@ -157,7 +157,7 @@ __device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n
 
 // Partial sum of row segment [eb, ee) for the D/4 lanes that share `sub`; after the
 // cross-group reduction every lane holds the total for its float4 slot.
-template <int D, int UNMAX>
+template <int D, int UNMAX, bool DROP>
 __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, const float *__restrict__ val, int eb, int ee,
                                                const float *__restrict__ x, int lane, const DropCtx &dc)
 {
@@ -166,13 +166,13 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_next = 0;
     float a_next = 0.f;
-    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = drop_val(dc, eb + lane, val[eb + lane]); }
+    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = DROP ? drop_val(dc, eb + lane, val[eb + lane]) : val[eb + lane]; }
     for (int base = eb; base < ee; base += 64) {
         const int n = min(64, ee - base);
         const int c = c_next;
         const float a = a_next;
         c_next = 0; a_next = 0.f;
-        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = drop_val(dc, base + 64 + lane, val[base + 64 + lane]); }
+        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = DROP ? drop_val(dc, base + 64 + lane, val[base + 64 + lane]) : val[base + 64 + lane]; }
         const int iters = (n + NG - 1) / NG;
         int t = 0;
         for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
@@ -305,7 +305,9 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
     return true;
 }
 
-template <int D, int UNMAX, int WAVES, int MINW, bool PACKED = false>
+// DROP: graph dropout compiled in (a separate instantiation: carrying the mask state through the default
+// kernel cost 7 % of a train step even with dropout switched off at run time)
+template <int D, int UNMAX, int WAVES, int MINW, bool PACKED = false, bool DROP = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmArgs a)
 {
     constexpr int G = D / 4;
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
             atomicOr(&a.mark_bits[r2 >> 5], 1u << (r2 & 31));
         }
     }
-    const DropCtx dc = drop_ctx(a);
+    DropCtx dc{};
+    if (DROP) dc = drop_ctx(a);
     int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
     const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x);  // scalar loads, in flight under the gather
     if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         const int n = pk.x >= 0 ? pk.z - pk.y : 0;
         int c = 0;
         float av = 0.f;
-        if (sub < n) { c = a.col[pk.y + sub]; av = drop_val(dc, pk.y + sub, a.val[pk.y + sub]); }
+        if (sub < n) { c = a.col[pk.y + sub]; av = DROP ? drop_val(dc, pk.y + sub, a.val[pk.y + sub]) : a.val[pk.y + sub]; }
         float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
         if (pk.x >= 0) {
             const size_t eoff = (size_t)pk.x * D + (size_t)sub * 4;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         return;
     }
     if (ds.z > ds.y && !(a.dbg & 1)) {
-        acc = spmm_segment<D, UNMAX>(a.col, a.val, ds.y, ds.z, a.x, lane, dc);
+        acc = spmm_segment<D, UNMAX, DROP>(a.col, a.val, ds.y, ds.z, a.x, lane, dc);
     }
     if (lane < G) part[w][lane] = acc;
     __syncthreads();
@@ -660,6 +663,22 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
         if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, false>), grid, block, 0, s, a);  \
     } while (0)
+#define RK_SPMM_DROP(D)                                                                                \
+    do {                                                                                               \
+        if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, 8, 8, 6, true, true>), grid, block, 0, s, a);  \
+        else hipLaunchKernelGGL((spmm_csr_kernel<D, 8, 8, 6, false, true>), grid, block, 0, s, a);        \
+    } while (0)
+    if (a.drop_thresh24 && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
+        // graph dropout: one instantiation per dim (8-wave workgroups, the schedule's default)
+        if (W != 8) return hipErrorInvalidValue;
+        switch (a.d) {
+            case 32: RK_SPMM_DROP(32); break;
+            case 64: RK_SPMM_DROP(64); break;
+            case 128: RK_SPMM_DROP(128); break;
+            default: RK_SPMM_DROP(256); break;
+        }
+        return hipGetLastError();
+    }
 #define RK_SPMM_D(D)                                                                         \
     if (W == 16) { if (variant == 1) RK_SPMM_CASE(D, 16, 16, 4); else RK_SPMM_CASE(D, 8, 16, 8); } \
     else if (W == 8) { if (variant == 1) RK_SPMM_CASE(D, 8, 8, 8); else if (variant == 2) RK_SPMM_CASE(D, 16, 8, 4); else RK_SPMM_CASE(D, 8, 8, 6); } \
@@ -673,5 +692,6 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     }
 #undef RK_SPMM_D
 #undef RK_SPMM_CASE
+#undef RK_SPMM_DROP
     return hipGetLastError();
 }
