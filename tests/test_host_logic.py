@@ -264,3 +264,41 @@ def test_defense_workflow_plumbing_cpu(tiny):
     assert res["attacked"]["pred_shift"] == pytest.approx(50.0) and res["defended"]["pred_shift"] == pytest.approx(0.0)
     with pytest.raises(TypeError):
         workflow.from_config("defense", victim_data=ds, attack_data=None, victim=_StubVictim(), attacker=None)
+
+
+def test_ctypes_descriptors_match_the_header(tmp_path):
+    """The ctypes mirrors in recad_amd/_lib.py must have the C header's size and field offsets: a shorter or
+    shifted structure would hand the library garbage for the trailing fields."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from recad_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    probes = {
+        "rk_lightgcn_desc": ["n_users", "lambda", "rowptr", "n_blocks", "user_emb", "grad", "state", "col_tagged", "hot_H",
+                             "row_bits", "keep_prob", "drop_seed", "tpos"],
+        "rk_ncf_desc": ["n_users", "lr", "ug", "pw", "grad", "m", "v", "acts", "d0", "max_batch", "gemm_scratch",
+                        "gemm_scratch_floats", "wgrad_part"],
+        "rk_spmm_epilogue": [],
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "recad_hip.h"', 'int main(void) {']
+    for st, fields in probes.items():
+        lines.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for f in fields:
+            lines.append(f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    lines += ['return 0; }']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    mirrors = {"rk_lightgcn_desc": _lib.LightGCNDesc, "rk_ncf_desc": _lib.NCFDesc, "rk_spmm_epilogue": _lib.SpmmEpilogue}
+    rename = {"lambda": "lam"}
+    for st, fields in probes.items():
+        cls = mirrors[st]
+        assert C.sizeof(cls) == int(out[st]), (st, C.sizeof(cls), out[st])
+        for f in fields:
+            assert getattr(cls, rename.get(f, f)).offset == int(out[f"{st}.{f}"]), (st, f)
