@@ -102,7 +102,20 @@ __global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ 
                 f(4 * q, v.x); f(4 * q + 1, v.y); f(4 * q + 2, v.z); f(4 * q + 3, v.w);
             }
         } else {
-            for (int i = tid; i < n_items; i += NT) f(i, score_key(grow[i]));
+            // sixteen strided loads in flight per thread (the row is streamed from L2 / the Infinity Cache)
+            for (int i0 = tid; i0 < n_items; i0 += 16 * NT) {
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = i0 + j * NT;
+                    v[j] = i < n_items ? grow[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = i0 + j * NT;
+                    if (i < n_items) f(i, score_key(v[j]));
+                }
+            }
         }
     };
 
