@@ -5,6 +5,7 @@
 //   pass 2: one workgroup per user: mask seen items, rank of each target, radix-select of
 //           the K-th largest score, ordered collection, bitonic sort by (score desc, id asc).
 #include <algorithm>
+#include <climits>
 
 #include "gemm.h"
 
@@ -398,23 +399,33 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
 __global__ __launch_bounds__(1024) void hit_counts_kernel(const int *__restrict__ rank, long long n, int T, const int *__restrict__ ks,
                                                           int nk, int *__restrict__ counts, int use_atomics)
 {
-    __shared__ int wtot[16];
+    constexpr int KG = 4;  // thresholds counted per pass over the ranks
+    __shared__ int wtot[KG][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int p = 0; p < T * nk; ++p) {
-        const int t = p / nk, k = ks[p % nk];
-        int c = 0;
-        for (long long b = (long long)blockIdx.x * 1024 + tid; b < n; b += (long long)gridDim.x * 1024) c += rank[b * T + t] < k ? 1 : 0;
-        c = (int)wave_sum((float)c);  // per-wave partial < 2^24: exact in fp32
-        if (lane == 0) wtot[w] = c;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int q = 0; q < 16; ++q) tot += wtot[q];
-            if (use_atomics) atomicAdd(&counts[p], tot);
-            else counts[p] = tot;
+    for (int t = 0; t < T; ++t)
+        for (int q0 = 0; q0 < nk; q0 += KG) {
+            int kk[KG], c[KG];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) { kk[q] = q0 + q < nk ? ks[q0 + q] : INT_MIN; c[q] = 0; }
+            for (long long b = (long long)blockIdx.x * 1024 + tid; b < n; b += (long long)gridDim.x * 1024) {
+                const int r = rank[b * T + t];
+#pragma unroll
+                for (int q = 0; q < KG; ++q) c[q] += r < kk[q] ? 1 : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                const int s = (int)wave_sum((float)c[q]);  // per-wave partial < 2^24: exact in fp32
+                if (lane == 0) wtot[q][w] = s;
+            }
+            __syncthreads();
+            if (tid < KG && q0 + tid < nk) {
+                int tot = 0;
+                for (int i = 0; i < 16; ++i) tot += wtot[tid][i];
+                if (use_atomics) atomicAdd(&counts[t * nk + q0 + tid], tot);
+                else counts[t * nk + q0 + tid] = tot;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
 }
 
 RK_EXPORT int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_targets, const int32_t *ks, int32_t nk,
