@@ -204,7 +204,11 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
                 "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
-                "note": "working set is L2/MALL resident at this size; time includes the inter-kernel boundary"}
+                "note": "working set is L2/MALL resident at this size; time includes the inter-kernel boundary",
+                # what actually bounds the kernel: no-reuse row gathers served by L2 (MI355X_MICROARCH.md, 'Indexed rows':
+                # 16.8-18.8 TB/s chip-wide for L2-served row gathers; 7.4-8.6 TB/s from the Infinity Cache)
+                "gather_achieved_GBps": (8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim) / (spmm_ms * 1e-3) / 1e9,
+                "gather_ceiling_GBps": 18800.0 if 4 * N * args.dim <= 32 * 2 ** 20 else 8600.0}
 
     # ---------------- second half of the metric: full-catalog scoring + top-100 + HR@K
     ptr, idx = ds.train_csr_sorted()
