@@ -100,7 +100,7 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
         for (int32_t r = 0; r < n_rows; ++r) n_short += (rp[r + 1] - rp[r] <= pack_max) ? 1 : 0;
         if (4LL * n_short < n_rows) { pack_groups = 1; pack_max = -1; }
     }
-    const int kSpmmWaves = spmm_waves();
+    const int kSpmmWaves = spmm_waves_for((long long)rp[n_rows]);
     static const int seg_nnz = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : kSegNnz;
     rk_schedule *sc = new rk_schedule();
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  With
@@ -216,7 +216,7 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     sc->n_blocks = (int32_t)(d.size() / bw);
     sc->n_long = n_long; sc->n_slots = n_slots; sc->dim = dim;
     *out = sc;
-    *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag);  // opaque launch parameter
+    *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag) | sched_waves_code(kSpmmWaves);  // opaque launch parameter
     *n_words = (int64_t)sc->words();
     return RK_OK;
 }
