@@ -101,7 +101,17 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
         if (4LL * n_short < n_rows) { pack_groups = 1; pack_max = -1; }
     }
     const int kSpmmWaves = spmm_waves_for((long long)rp[n_rows]);
-    static const int seg_nnz = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : kSegNnz;
+    // Nonzeros per segment (= per wave).  A row of 65..128 nonzeros is two waves + an LDS combine at 64 but one
+    // wave at 128: when most of the nonzeros sit in such rows (ml1m's train graph: 97 per row on average) 128
+    // is worth 7 % of a train step (106.4 -> 99.2 us); on short-row graphs it only lengthens the tail (the
+    // reference's as-is graph: 46.7 -> 50.0 us), and above 8 M nonzeros it measured flat.  RK_SEG_NNZ overrides.
+    static const int seg_env = getenv("RK_SEG_NNZ") ? std::max(16, atoi(getenv("RK_SEG_NNZ"))) : 0;
+    int seg_nnz = seg_env ? seg_env : kSegNnz;
+    if (!seg_env && kSpmmWaves == 4) {
+        long long over = 0;
+        for (int32_t r = 0; r < n_rows; ++r) { const int32_t k = rp[r + 1] - rp[r]; if (k > kSegNnz) over += k; }
+        if (2 * over >= (long long)rp[n_rows]) seg_nnz = 2 * kSegNnz;
+    }
     rk_schedule *sc = new rk_schedule();
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  With
     // class_split > 0 the rows < split (users) and >= split (items) are scheduled into separate
