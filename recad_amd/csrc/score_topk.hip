@@ -353,7 +353,10 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     const size_t row_bytes = ((size_t)n_items * sizeof(float) + 15) & ~(size_t)15;
     // LDS staging only pays while several workgroups still fit per CU (measured: a 138 KB row in LDS
     // is 2.8x SLOWER than streaming it from L2 -- one 4-wave workgroup per CU); ml1m-size rows tie.
-    if (row_bytes <= 16 * 1024) {
+    // measured on 8192 rows: staging wins up to ~40 KB rows (6000 items: 90 vs 99 us, 9000: 132 vs 140), loses
+    // beyond (14000 items, 56 KB: 285 vs 202 us -- two workgroups per CU)
+    static const size_t lds_row_max = getenv("RK_TOPK_LDS_KB") ? (size_t)atoi(getenv("RK_TOPK_LDS_KB")) * 1024 : 40 * 1024;
+    if (row_bytes <= lds_row_max) {
         static bool attr_set = false;
         if (!attr_set) {
             RK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_rows_kernel<true>),

@@ -722,12 +722,12 @@ def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
     _topk_rows_vs_oracle(gpu_device, scores, seen, K, targets)
 
 
-@pytest.mark.parametrize("I", [50, 3702, 9000])
+@pytest.mark.parametrize("I", [50, 3702, 12000])
 @pytest.mark.parametrize("kind", ["const", "two_values", "tiny_spread", "signed_zero", "quantised", "mostly_seen"])
 def test_topk_rows_tie_heavy_rows(gpu_device, kind, I):
     """Rows whose candidates do not fit the first radix bin: constant rows (an untrained MF victim scores
     every item `mean`), a handful of distinct values, a spread of a few ulps, +-0, and rows with fewer
-    than K unseen items.  I = 9000 takes the row-in-L2 form of the kernel, the others the row-in-LDS form."""
+    than K unseen items.  I = 12000 (48 KB rows) takes the row-in-L2 form of the kernel, the others the row-in-LDS form."""
     rng = np.random.default_rng(I)
     nb, K = 12, 100
     if kind == "const":
