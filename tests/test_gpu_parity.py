@@ -290,6 +290,48 @@ def test_workflow_end_to_end_on_device(gpu_device):
             assert abs(rows[:, 2 + i].mean() - res[f"HR@{k}"]) < 1e-12, (name, k)
 
 
+def test_defense_workflow_on_device(gpu_device):
+    """Defense.execute()-style loop on the GPU (recad/workflow/defense.py:64-303): train, attack, inject, retrain,
+    flag users, delete them (`delete_data`), third retrain on the cleaned graph, evaluate attacked and defended."""
+    from recad_amd import dataset, model, synth, workflow
+
+    class FlagInjected:  # stands in for the PCA defender: flags the injected profiles and one genuine user
+        model_name = "flag-injected"
+
+        def __init__(self, n_clean):
+            self.n_clean = n_clean
+
+        def I(self, **kw):
+            return self
+
+        def to(self, device):
+            return self
+
+        def input_describe(self):
+            return {}
+
+        def defense_step(self, **kw):
+            return list(range(self.n_clean, self.n_clean + 15)) + [7]
+
+    d = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                             device=gpu_device, graph_source="train", seed=5)
+    wf = workflow.from_config("defense", victim_data=ds, attack_data=None, victim=model.from_config("victim", "lightgcn", latent_dim_rec=32),
+                              attacker=workflow.RandomAttack(ds.n_items, attack_num=15, filler_num=8, seed=3),
+                              defender=FlagInjected(ds.n_users), rec_epoch=2, attack_epoch=0, device=gpu_device)
+    res = wf.execute()
+    assert res["n_flagged"] == 16 and set(res) == {"attacked", "defended", "n_flagged"}
+    assert all(np.isfinite(v) for part in ("attacked", "defended") for v in res[part].values())
+    deg = np.diff(wf.cleaned_dataset._csr["train"][0])
+    assert deg[7] == 0 and deg[ds.n_users:].sum() == 0
+    # the cleaned graph was rebuilt on the device: it equals the oracle's normalisation of the cleaned train set
+    ptr, idx = wf.cleaned_dataset.train_csr_sorted()
+    g = wf.cleaned_dataset.graph_csr()
+    orp, oc, ov = orc.build_norm_adj(wf.cleaned_dataset.n_users, wf.cleaned_dataset.n_items, ptr.astype(np.int32), idx.astype(np.int32))
+    assert np.array_equal(g.rowptr.cpu().numpy(), orp) and np.array_equal(g.col.cpu().numpy(), oc)
+    assert np.allclose(g.val.cpu().numpy(), ov, rtol=4e-7, atol=0)
+
+
 @pytest.mark.parametrize("name", ["ncf_dev_f8_l3", "ncf_game_f32_l5"])
 def test_ncf_train_golden(gpu_device, name):
     from recad_amd import model
