@@ -802,3 +802,16 @@ def test_hit_counts(gpu_device, n, T):
     got = hit_counts(torch.from_numpy(rank).to(gpu_device), topks).cpu().numpy()
     ref = np.array([[(rank[:, t] < k).sum() for k in topks] for t in range(T)])
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("which,n_cases", [("spmm_stress", 25), ("topk_stress", 25), ("gemm_stress", 12)])
+def test_randomised_stress(gpu_device, which, n_cases):
+    """A slice of the randomised sweeps in scripts/ (shapes, degree / score distributions, dims, gathered ids):
+    SpMM within the accumulation-order tolerance, selection and scoring GEMM bit-exact against the oracle."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", which + ".py")
+    spec = importlib.util.spec_from_file_location(which, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(seed=1234, n_cases=n_cases)
