@@ -806,11 +806,11 @@ def test_hit_counts(gpu_device, n, T):
 
 @pytest.mark.parametrize("which,n_cases", [("spmm_stress", 25), ("topk_stress", 25), ("gemm_stress", 12)])
 def test_randomised_stress(gpu_device, which, n_cases):
-    """A slice of the randomised sweeps in scripts/ (shapes, degree / score distributions, dims, gathered ids):
+    """A slice of the randomised sweeps in tests/tools/ (shapes, degree / score distributions, dims, gathered ids):
     SpMM within the accumulation-order tolerance, selection and scoring GEMM bit-exact against the oracle."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", which + ".py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", which + ".py")
     spec = importlib.util.spec_from_file_location(which, path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
