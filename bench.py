@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its config[1]: LightGCN victim, ml1m-shaped synthetic
-interactions (5950 x 3702, ~470K train edges, intended train graph), dim=64, 3 layers, B=1024.
-
-A "step" = one pass of the hot path over one minibatch: forward propagation (3 SpMM),
-gather + BPR softplus + L2 reg, backward (3 SpMM), dense Adam -- K steps are timed with the
-pre-sampled triplets already resident in HBM.  After the timed region the full-catalog
-scoring + top-100 + HR@K pass is timed too (the second half of the metric) and reported in
-the same JSON line under "topk".
+"""bench.py -- BASELINE.json's metric: BPR train interactions/s (+ full-catalog top-K scorings/s) of the
+LightGCN victim on synthetic interaction matrices, on N MI355X of one node.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-N>1: every rank retrains its own victim replica on its own poisoned copy of the dataset
-(the unit the perturb-retrain loop parallelises at ml1m scale; no data-path collective), so
-scaling is "weak"; value = triplets of all ranks / max-over-ranks time.  DESIGN.md "Multi-GPU".
+N = 1 (default): BASELINE.json config[1] -- ml1m-shaped (5950 x 3702, ~470K train edges, intended train
+graph), dim=64, 3 layers, B=1024.  A "step" = one pass of the hot path over one minibatch: forward
+propagation (L SpMM), gather + BPR softplus + L2 reg, backward (L SpMM), dense Adam; K steps are timed with
+the pre-sampled triplets already resident in HBM, after W untimed steps on the SAME buffers and the SAME
+captured hipGraph (victim.reserve(): nothing is allocated, captured or instantiated inside the timed
+region).  The full-catalog scoring + top-100 + HR@K pass is timed after it ("topk").
+
+N > 1: `python bench.py --gpus N` starts its own N worker processes (one per GPU, before anything touches a
+GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is a worker itself.
+Default mode `--parallel rows`: ONE training job whose node rows (embedding tables, Adam state, CSR slab)
+are sharded over the N GPUs with RCCL all-gathers between the propagation layers (recad_amd/sharded.py),
+on the largest shardable workload (config-4-shaped: 1M x 500K x 100M edges; `--workload yelp` for the
+yelp-shaped one) => "scaling": "strong".  Rank 0 also times the single-GPU fused path on the same workload
+("same_workload_1gpu") so that the line carries its own like-for-like reference, and `--parallel replicas`
+(one independent retrain job per GPU, no data-path collective) is kept as a labelled extra mode.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,36 +35,107 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # same guide: v_mfma_f32_32x32x2_f32 dense peak
+METRIC = "BPR train interactions/sec + full-catalog top-K scorings/sec, LightGCN ml1m dim=64"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=458)   # one ml1m epoch = ceil(468649/1024)
-    ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "yelp", "tiny", "c4s", "config4"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: one ml1m epoch = 458 at N=1, 20 at N>1)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None, choices=["ml1m", "yelp", "tiny", "c4s", "config4"],
+                    help="default: ml1m at N=1, config4 at N>1")
     ap.add_argument("--graph", default="train", choices=["train", "reference"],
                     help="adjacency from the train edges (BASELINE '~470K edges') or the reference's as-is test-edge graph")
-    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--dim", type=int, default=None, help="default 64 (128 for --workload yelp, BASELINE config 3)")
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--graph-steps", type=int, default=8, help="train steps per hipGraph replay (0 = plain launches)")
-    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto, ~15 s)")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-topk", action="store_true", help="skip the evaluation leg")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "rows"],
-                    help="N>1: one victim replica per GPU (weak) or node rows sharded over the GPUs with RCCL all-gathers (strong)")
-    return ap.parse_args()
+    ap.add_argument("--parallel", default=None, choices=["rows", "replicas"],
+                    help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default) or one "
+                         "independent victim replica per GPU (weak scaling, no data-path collective)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the workers")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
+    a = ap.parse_args(argv)
+    if a.workload is None:
+        a.workload = "ml1m" if a.gpus == 1 else "config4"
+    if a.parallel is None:
+        a.parallel = "rows" if a.gpus > 1 else "replicas"
+    if a.dim is None:
+        a.dim = 128 if a.workload == "yelp" else 64
+    if a.steps is None:
+        a.steps = 458 if (a.gpus == 1 and a.workload in ("ml1m", "tiny")) else 20
+    if a.warmup is None:
+        a.warmup = 32 if (a.gpus == 1 and a.workload in ("ml1m", "tiny")) else 5
+    return a
 
 
-def cpu_baseline(d, graph, dim, layers, batch, triplets, n_steps_req):
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_workers(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N workers (fresh interpreters, so no
+    process that has touched a GPU is ever re-executed), one per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    stdout (the JSON line) is passed through; the exit code is the first non-zero worker code."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "LOCAL_WORLD_SIZE": str(args.gpus)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:      # one worker failed: the others would wait in a collective forever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run_worker(args, rank, world):
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "parallel": args.parallel,
+                          "workload": args.workload}))
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline_port(d, graph, dim, layers, batch, triplets, n_steps_req, budget_s=10.0):
     """The CPU oracle (a 1-thread C port of the reference path) on a bounded sample of the same
     workload: the first few train steps of the same epoch.  Checker code, timed -- not shipped."""
     from oracle import oracle as orc
 
     U, I = d["n_users"], d["n_items"]
     ptr, idx = d["train"] if graph == "train" else d["test"]
-    csr = orc.build_norm_adj(U, I, ptr.astype(np.int32), idx.astype(np.int32))
+    csr = orc.build_norm_adj(U, I, np.asarray(ptr).astype(np.int32), np.asarray(idx).astype(np.int32))
     rng = np.random.default_rng(2023)
     user = (rng.standard_normal((U, dim), dtype=np.float32) * 0.1).astype(np.float32)
     item = (rng.standard_normal((I, dim), dtype=np.float32) * 0.1).astype(np.float32)
@@ -67,7 +145,7 @@ def cpu_baseline(d, graph, dim, layers, batch, triplets, n_steps_req):
     t0 = time.perf_counter()
     orc.lightgcn_step(csr, user, item, st, users[:batch], pos[:batch], neg[:batch], layers)
     one = time.perf_counter() - t0
-    n = int(min(avail - 1, n_steps_req or max(2, 15.0 / max(one, 1e-3))))
+    n = int(max(1, min(avail - 1, n_steps_req or max(2, budget_s / max(one, 1e-3)))))
     t0 = time.perf_counter()
     for s in range(1, n + 1):
         orc.lightgcn_step(csr, user, item, st, users[s * batch:(s + 1) * batch], pos[s * batch:(s + 1) * batch],
@@ -77,37 +155,117 @@ def cpu_baseline(d, graph, dim, layers, batch, triplets, n_steps_req):
             "sample": f"{n} train steps of {batch} triplets on the same graph (oracle/recad_oracle.c, 1 thread, {el:.1f} s)"}
 
 
-def main():
-    args = parse()
+def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
+    """the reference's own op sequence (recad/model/victim/lightgcn.py:82-113,137-169) written
+    against ATen on the host cores -- torch.sparse.mm on the coalesced COO graph, index gathers, softplus,
+    autograd, torch.optim.Adam -- timed with k = all host threads.  Baseline only; never on the product path."""
     import torch
-    import torch.distributed as dist
 
+    k = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(k)
+    try:
+        U, I = d["n_users"], d["n_items"]
+        ptr, idx = (np.asarray(a) for a in (d["train"] if graph == "train" else d["test"]))
+        deg_u = np.diff(ptr).astype(np.float64)
+        uu = np.repeat(np.arange(U, dtype=np.int64), np.diff(ptr))
+        ii = idx.astype(np.int64) + U
+        deg = np.zeros(U + I)
+        deg[:U] = deg_u
+        np.add.at(deg, ii, 1.0)
+        dinv = np.where(deg > 0, (deg + 1e-14) ** -0.5, 0.0)
+        rows = np.concatenate([uu, ii])
+        cols = np.concatenate([ii, uu])
+        vals = (dinv[rows] * dinv[cols]).astype(np.float32)
+        G = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (U + I, U + I)).coalesce()
+        g = torch.Generator().manual_seed(2023)
+        eu = torch.nn.Parameter(torch.randn(U, dim, generator=g) * 0.1)
+        ei = torch.nn.Parameter(torch.randn(I, dim, generator=g) * 0.1)
+        opt = torch.optim.Adam([eu, ei], lr=1e-3)
+        users, pos, neg = (torch.from_numpy(np.asarray(t)) for t in triplets)
+
+        def step(s):
+            sl = slice(s * batch, (s + 1) * batch)
+            u, p, n = users[sl], pos[sl], neg[sl]
+            all_emb = torch.cat([eu, ei])
+            embs = [all_emb]
+            for _ in range(layers):
+                all_emb = torch.sparse.mm(G, all_emb)
+                embs.append(all_emb)
+            light = torch.mean(torch.stack(embs, dim=1), dim=1)
+            lu, li = torch.split(light, [U, I])
+            ue, pe, ne = lu[u], li[p], li[n]
+            reg = 0.5 * (eu[u].norm(2).pow(2) + ei[p].norm(2).pow(2) + ei[n].norm(2).pow(2)) / float(len(u))
+            loss = torch.mean(torch.nn.functional.softplus((ue * ne).sum(1) - (ue * pe).sum(1))) + 1e-4 * reg
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return float(loss.item())
+
+        avail = len(users) // batch
+        t0 = time.perf_counter()
+        step(0)
+        one = time.perf_counter() - t0
+        n = int(max(1, min(avail - 1, budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for s in range(1, n + 1):
+            last = step(s)
+        el = time.perf_counter() - t0
+        return {"value": n * batch / el, "unit": "interactions/s", "cores": k, "kind": "port",
+                "sample": f"{n} train steps of {batch} triplets, the reference's ATen op sequence (torch.sparse.mm COO, "
+                          f"autograd, torch.optim.Adam) on {k} host threads, {el:.1f} s; last loss {last:.5f}"}
+    finally:
+        torch.set_num_threads(prev)
+
+
+# ------------------------------------------------------------------------------------------------ worker
+def worker(args):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch `python bench.py --gpus N` "
+                         "(self-launching) or torch.distributed.run with --nproc-per-node equal to --gpus")
+    if args.dry_run:
+        return dry_run_worker(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    # gloo workers may share one GPU (the 1-GPU box check of the sharded path); nccl needs one GPU per rank
+    n_dev = torch.cuda.device_count()
+    local_dev = local % max(n_dev, 1) if args.backend == "gloo" else local
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import recad_amd  # noqa: F401
     from recad_amd import _lib, dataset, model, synth
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 
+    rows_mode = world > 1 and args.parallel == "rows"
+    B = args.batch
+
     # ---------------- workload: synthetic interactions of the named shape, resident on the GPU
-    d = synth.make(args.workload)
+    big = args.workload in ("c4s", "config4")
+    if big:
+        dd = synth.make_device(args.workload, dev)     # same seed => identical on every rank
+        d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+        del dd
+    else:
+        d = synth.make(args.workload)
     ds = dataset.from_config("implicit", args.workload, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
-                             need_graph=True, device=dev, graph_source=args.graph, pairwise_batch_size=args.batch,
-                             seed=1234 + rank)
+                             need_graph=True, device=dev, graph_source=args.graph, pairwise_batch_size=B,
+                             seed=1234 + (0 if rows_mode else rank))
     torch.manual_seed(2023)
     victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers).I(dataset=ds).to(dev)
     victim.graph_steps = args.graph_steps
     g = ds.graph_csr()
     N, nnz = g.n_rows, g.nnz
-    B = args.batch
     need = (args.steps + args.warmup) * B
     cols = [[], [], []]
     have = 0
@@ -117,21 +275,21 @@ def main():
             c.append(ep[k])
         have += len(ep["users"])
     users, pos, neg = (torch.cat(c)[:need].contiguous() for c in cols)
-    host_triplets = tuple(t[: B * 160].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline sample
+    host_triplets = tuple(t[: B * 64].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline sample
 
     sharded = None
-    if args.parallel == "rows":
+    if rows_mode:
         # every rank must see the same triplets and start from the same tables
         from recad_amd.sharded import ShardedLightGCN
-        if world > 1:
-            for t in (users, pos, neg):
-                dist.broadcast(t, src=0)
-            for p_ in victim.parameters():
-                dist.broadcast(p_.data, src=0)
-        gg = ds.graph_csr()
-        sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers,
-                                  (gg.rowptr.cpu().numpy(), gg.col.cpu().numpy(), gg.val.cpu().numpy()),
+        for t in (users, pos, neg):
+            dist.broadcast(t, src=0)
+        for p_ in victim.parameters():
+            dist.broadcast(p_.data, src=0)
+        sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
                                   victim.embedding_user.weight, victim.embedding_item.weight, device=dev)
+        sharded.reserve(max(args.steps, args.warmup) * B, B)
+    else:
+        victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
 
     def run(lo, n_steps):
         sl = slice(lo * B, (lo + n_steps) * B)
@@ -157,12 +315,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last_loss = float(partials[-1].sum().item()) if sharded is None else float(partials[-1])
-    if sharded is not None:  # hand the trained tables back to the victim for the evaluation leg
-        tu, ti = sharded.tables()
-        victim.embedding_user.weight.data.copy_(tu)
-        victim.embedding_item.weight.data.copy_(ti)
-    work_ranks = 1 if sharded is not None else world  # rows: all ranks work on ONE training job
     assert np.isfinite(last_loss), "training diverged"
+    work_ranks = 1 if sharded is not None else world  # rows: all ranks work on ONE training job
+
+    # ---------------- rows mode: like-for-like single-GPU reference on rank 0 (others wait), then evaluation
+    same_1gpu = None
+    sharded_eval = None
+    if sharded is not None:
+        if not args.no_topk:
+            ptr, idx = ds.train_csr_sorted()
+            sharded_eval = sharded.evaluate(ptr, idx, np.array([0], dtype=np.int32), K=100, topks=(10, 20, 50, 100), reps=2)
+        if rank == 0:
+            victim.reserve(max(args.steps, args.warmup) * B, B)
+            s1 = min(args.steps, 10)
+            victim._run_epoch(users[: min(args.warmup, 3) * B or B], pos[: min(args.warmup, 3) * B or B], neg[: min(args.warmup, 3) * B or B], B)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            victim._run_epoch(users[: s1 * B], pos[: s1 * B], neg[: s1 * B], B)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            same_1gpu = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
+                         "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait"}
+        barrier()
 
     # ---------------- secondary: one whole train_step() epoch, the build's device sampler included
     epoch_obj = None
@@ -179,95 +353,115 @@ def main():
             epoch_obj.update({"value": world * n_ep / te, "unit": "interactions/s", "triplets": n_ep})
 
     # ---------------- dominant kernel: the CSR SpMM; per-launch time by HIP events on its stream
-    stream = torch.cuda.current_stream()
-    reps = 200
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    h = victim._ensure_handle()
-    for _ in range(10):
-        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
-    ev0.record(stream)
-    for _ in range(reps):
-        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    spmm_ms = ev0.elapsed_time(ev1) / (reps * args.layers)
-    spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
-    achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{args.workload}_{args.graph}_d{args.dim}")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": f"spmm_csr_kernel<{args.dim}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
-                "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
-                "note": "working set is L2/MALL resident at this size; time includes the inter-kernel boundary",
-                # what actually bounds the kernel: no-reuse row gathers served by L2 (MI355X_MICROARCH.md, 'Indexed rows':
-                # 16.8-18.8 TB/s chip-wide for L2-served row gathers; 7.4-8.6 TB/s from the Infinity Cache)
-                "gather_achieved_GBps": (8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim) / (spmm_ms * 1e-3) / 1e9,
-                "gather_ceiling_GBps": 18800.0 if 4 * N * args.dim <= 32 * 2 ** 20 else 8600.0}
+    roofline = None
+    if sharded is None or rank == 0:
+        stream = torch.cuda.current_stream()
+        reps = 200 if nnz < 20_000_000 else 10
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h = victim._ensure_handle()
+        for _ in range(3):
+            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+        ev0.record(stream)
+        for _ in range(reps):
+            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        spmm_ms = ev0.elapsed_time(ev1) / (reps * args.layers)
+        spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
+        achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
+        traffic = None
+        for tname in ("r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(f"{args.workload}_{args.graph}_d{args.dim}")
+                except Exception:
+                    traffic = None
+        roofline = {"bound": "hbm", "kernel": f"spmm_csr_kernel<{args.dim}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
+                    "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
+                    "note": "per-launch time from HIP events around back-to-back propagate calls (includes the inter-kernel boundary)"}
 
     # ---------------- second half of the metric: full-catalog scoring + top-100 + HR@K
-    ptr, idx = ds.train_csr_sorted()
-    targets = np.array([0], dtype=np.int32)
-    ev_users = eligible_users(ptr, idx, targets)
-    if args.eval_users:
-        ev_users = ev_users[: args.eval_users]
-    # inputs (eligible users, seen-item CSR, targets) and outputs (top-100 lists, target ranks) stay in HBM
-    ev_dev = torch.as_tensor(ev_users, dtype=torch.int32, device=dev)
-    ptr_dev, idx_dev = torch.as_tensor(ptr, dtype=torch.int32, device=dev), torch.as_tensor(idx, dtype=torch.int32, device=dev)
-    tg_dev = torch.as_tensor(targets, dtype=torch.int32, device=dev)
-    ev_chunk = max(256, min(8192, (1 << 31) // max(ds.n_items, 1)))
-    warm = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)  # warm (allocator, torch kernels)
-    int(hit_counts(warm["target_rank"], (10, 20, 50, 100))[0, 2].item())
-    del warm
-    # EV_REPS complete evaluations back to back (each: propagate + GEMM + select + HR reduction), one sync at the end
-    EV_REPS = 8
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(EV_REPS):
+    topk = None
+    if sharded is not None:
+        topk = sharded_eval
+    elif not args.no_topk:
+        ptr, idx = ds.train_csr_sorted()
+        targets = np.array([0], dtype=np.int32)
+        ev_users = eligible_users(ptr, idx, targets)
+        if args.eval_users:
+            ev_users = ev_users[: args.eval_users]
+        # inputs (eligible users, seen-item CSR, targets) and outputs (top-100 lists, target ranks) stay in HBM
+        ev_dev = torch.as_tensor(ev_users, dtype=torch.int32, device=dev)
+        ptr_dev, idx_dev = torch.as_tensor(ptr, dtype=torch.int32, device=dev), torch.as_tensor(idx, dtype=torch.int32, device=dev)
+        tg_dev = torch.as_tensor(targets, dtype=torch.int32, device=dev)
+        ev_chunk = max(256, min(8192, (1 << 31) // max(ds.n_items, 1)))
+        warm = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
+        int(hit_counts(warm["target_rank"], (10, 20, 50, 100))[0, 2].item())
+        del warm
+        # EV_REPS complete evaluations back to back (each: propagate + GEMM + select + HR reduction), one sync at the end
+        EV_REPS = 8 if nnz < 20_000_000 else 2
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(EV_REPS):
+            res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
+            hits_t = hit_counts(res["target_rank"], (10, 20, 50, 100))
+        torch.cuda.synchronize()
+        ev_el = (time.perf_counter() - t1) / EV_REPS
+        hr50 = float(hits_t[0, 2].item()) / max(len(ev_users), 1)
+        t1 = time.perf_counter()  # one evaluation on an idle device, host enqueue included (latency, not throughput)
         res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
-        hits_t = hit_counts(res["target_rank"], (10, 20, 50, 100))
-    torch.cuda.synchronize()
-    ev_el = (time.perf_counter() - t1) / EV_REPS
-    hr50 = float(hits_t[0, 2].item()) / max(len(ev_users), 1)
-    t1 = time.perf_counter()  # one evaluation on an idle device, host enqueue included (latency, not throughput)
-    res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
-    hit_counts(res["target_rank"], (10, 20, 50, 100)).cpu()
-    ev_single = time.perf_counter() - t1
-    deg = np.diff(ptr)
-    pairs = float((ds.n_items - deg[ev_users]).sum())
-    flops = 2.0 * len(ev_users) * ds.n_items * args.dim
-    topk = {"value": world * len(ev_users) / ev_el, "unit": "users/s", "pair_scorings_per_s": world * pairs / ev_el,
-            "eligible_users": int(len(ev_users)), "seconds": ev_el, "evaluations_timed": EV_REPS,
-            "single_evaluation_seconds": ev_single, "hr@50": hr50,
-            "gemm_tflops_e2e": flops / ev_el / 1e12,
-            "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@{10,20,50,100} counts; inputs and outputs resident in HBM"}
+        hit_counts(res["target_rank"], (10, 20, 50, 100)).cpu()
+        ev_single = time.perf_counter() - t1
+        deg = np.diff(ptr)
+        pairs = float((ds.n_items - deg[ev_users]).sum())
+        flops = 2.0 * len(ev_users) * ds.n_items * args.dim
+        topk = {"value": world * len(ev_users) / ev_el, "unit": "users/s", "pair_scorings_per_s": world * pairs / ev_el,
+                "eligible_users": int(len(ev_users)), "seconds": ev_el, "evaluations_timed": EV_REPS,
+                "single_evaluation_seconds": ev_single, "hr@50": hr50,
+                "gemm_tflops_e2e": flops / ev_el / 1e12,
+                "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@{10,20,50,100} counts; inputs and outputs resident in HBM"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(d, args.graph, args.dim, args.layers, B, host_triplets, args.cpu_steps)
+    cpu = cpu_aten = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
+        cpu = cpu_baseline_port(d, args.graph, args.dim, args.layers, B, host_triplets, args.cpu_steps)
+        cpu_aten = cpu_baseline_aten(d, args.graph, args.dim, args.layers, B, host_triplets)
 
     if rank == 0:
+        if world == 1:
+            par = "single GPU"
+        elif sharded is None:
+            par = "1 independent victim replica per GPU (no data-path collective)"
+        else:
+            par = sharded.describe()
         out = {
-            "metric": "BPR train interactions/sec + full-catalog top-K scorings/sec, LightGCN ml1m dim=64",
+            "metric": METRIC,
             "value": work_ranks * args.steps * B / elapsed, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if sharded is None else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if sharded is None else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": f"LightGCN victim, {args.workload}-shaped synthetic {ds.n_users}x{ds.n_items}, "
                                    f"{ds.traindataSize} train edges, graph={args.graph} (nnz {nnz}), dim={args.dim}, "
                                    f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
-                       "parallelism": ("single GPU" if world == 1 else "1 victim replica per GPU" if sharded is None
-                                       else f"node rows sharded over {world} GPUs, 2L all-gathers/step (RCCL)"),
+                       "parallelism": par, "mode": "single" if world == 1 else args.parallel, "backend": args.backend if world > 1 else None,
                        "graph_steps": args.graph_steps},
-            "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu, "last_step_loss": last_loss,
+            "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
+            "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_workers(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

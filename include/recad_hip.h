@@ -183,6 +183,13 @@ int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t
                             int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,
                             int32_t apply_update, int32_t graph_steps, void *stream);
 
+/* Optional: capture, instantiate and upload the hipGraph of `graph_steps` train steps for these (stable)
+ * triplet / loss buffers ahead of the first rk_lightgcn_train_epoch call, so that no epoch pays for it.
+ * The graph bakes the four pointers in; train_epoch re-captures by itself when they change.  The
+ * reference has no counterpart (its step is eager ATen, lightgcn.py:137-169). */
+int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                        float *loss_partials, int32_t apply_update, int32_t graph_steps, void *stream);
+
 /* ---------------------------------------------------------------- shared ops ------- */
 /* out[b] = <utab[users[b]], itab[items[b]]> (+ ubias[users[b]] + ibias[items[b]] + mean when
  * ubias != NULL).  LightGCN.forward tail (lightgcn.py:179-182) and MF.forward (mf.py:40-47). */

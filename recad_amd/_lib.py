@@ -96,6 +96,7 @@ _SIGNATURES = {
     "rk_lightgcn_propagate": [_P, _P],
     "rk_lightgcn_propagate_dropout": [_P, C.c_uint64, _P],
     "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],
+    "rk_lightgcn_prepare": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],

@@ -316,6 +316,47 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     return launch_backward(d, k, apply_update, bump, s);
 }
 
+// hipGraph of `graph_steps` train steps with users/pos/neg/loss_partials baked in; (re)captured when any of
+// them, the chunk length or the update flag changed.
+static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
+                       int apply_update, int graph_steps)
+{
+    const rk_lightgcn_desc &d = h->d;
+    const void **cap_key = h->cap_key;
+    const bool same = h->exec && h->exec_steps == graph_steps && h->exec_update == apply_update &&
+                      cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials;
+    if (same) return RK_OK;
+    if (h->exec) { (void)hipGraphExecDestroy(h->exec); h->exec = nullptr; }
+    if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = RK_OK;
+    for (int k = 0; k < graph_steps && rc == RK_OK; ++k)
+        rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0, h->cap_stream);
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    RK_HIP(e);
+    RK_HIP(hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    h->exec_steps = graph_steps; h->exec_update = apply_update;
+    cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                  float *loss_partials, int32_t apply_update, int32_t graph_steps, void *stream)
+{
+    if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: null handle");
+    if (!users || !pos || !neg || !loss_partials) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: bad arguments");
+    if (!apply_update && !h->d.grad) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: apply_update=0 needs desc.grad");
+    if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
+    if (graph_steps <= 1) return RK_OK;
+    int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps);
+    if (rc) return rc;
+    RK_HIP(hipGraphUpload(h->exec, (hipStream_t)stream));
+    return RK_OK;
+}
+
 RK_EXPORT int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream)
 {
     if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate: null handle");
@@ -351,27 +392,8 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     int done = 0;
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
     if (graph_steps > 1 && n_steps >= graph_steps) {
-        // NOTE: users/pos/neg/loss_partials are baked into the graph; re-capture when they move.
-        const void **cap_key = h->cap_key;
-        const bool same = h->exec && h->exec_steps == graph_steps && h->exec_update == apply_update &&
-                          cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials;
-        if (!same) {
-            if (h->exec) { (void)hipGraphExecDestroy(h->exec); h->exec = nullptr; }
-            if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-            hipGraph_t g = nullptr;
-            RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = RK_OK;
-            for (int k = 0; k < graph_steps && rc == RK_OK; ++k)
-                rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0,
-                                 h->cap_stream);
-            hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
-            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-            RK_HIP(e);
-            RK_HIP(hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
-            h->exec_steps = graph_steps; h->exec_update = apply_update;
-            cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
-        }
+        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps);
+        if (rc) return rc;
         for (; done + graph_steps <= n_steps; done += graph_steps) RK_HIP(hipGraphLaunch(h->exec, s));
     }
     for (; done < n_steps; ++done) {

@@ -79,3 +79,58 @@ def make(name):
     ptr, idx = user_item_edges(U, I, tr + va + te, seed)
     train, valid, test = split_edges(ptr, idx, (tr, va, te), seed)
     return {"name": name, "n_users": U, "n_items": I, "train": train, "valid": valid, "test": test}
+
+
+def make_device(name, device):
+    """The same family of shapes generated ON the device with torch (seconds instead of minutes for
+    the 25 M / 100 M-edge shapes; same degree / popularity model, a different -- torch Philox -- random
+    stream, identical on every rank that uses the same seed).  Returns the dict `make` returns, with
+    CSRs as (ptr int64, idx int32) device tensors."""
+    import torch
+
+    U, I, tr, va, te, seed = SHAPES[name]
+    n_edges = tr + va + te
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    deg = torch.exp(4.0 + torch.randn(U, device=dev, generator=g, dtype=torch.float64))
+    deg = torch.clamp(torch.round(deg * (n_edges / float(deg.sum()))), min=10).to(torch.int64)
+    deg = torch.minimum(deg, torch.full_like(deg, I // 2))
+    pop = torch.arange(1, I + 1, device=dev, dtype=torch.float64) ** (-0.8)
+    cdf = torch.cumsum(pop / pop.sum(), 0)
+    perm = torch.randperm(I, device=dev, generator=g)
+    have = torch.zeros(0, dtype=torch.int64, device=dev)
+    need = deg.clone()
+    for _ in range(12):
+        todo = torch.nonzero(need > 0).view(-1)
+        if todo.numel() == 0:
+            break
+        draws = (need[todo].double() * 1.3 + 4).to(torch.int64)
+        u = torch.repeat_interleave(todo, draws)
+        r = torch.rand(u.numel(), device=dev, generator=g, dtype=torch.float64)
+        it = perm[torch.clamp(torch.searchsorted(cdf, r), max=I - 1)]
+        have = torch.unique(torch.cat([have, u * I + it]))
+        del u, r, it
+        cnt = torch.bincount(have // I, minlength=U)
+        need = torch.clamp(deg - cnt, min=0)
+    users = have // I
+    cnt = torch.bincount(users, minlength=U)
+    # trim users that overshot: keep a random subset of deg[u] of their items
+    prio = torch.rand(have.numel(), device=dev, generator=g, dtype=torch.float64)
+    order = torch.argsort(users.double() + prio * 0.999999)     # by user, random inside a user
+    start = torch.cumsum(cnt, 0) - cnt
+    rank_in_user = torch.arange(have.numel(), device=dev) - start[users[order]]
+    keep = order[rank_in_user < deg[users[order]]]
+    have = torch.sort(have[keep]).values
+    users, items = have // I, (have % I).to(torch.int32)
+    part_r = torch.rand(have.numel(), device=dev, generator=g, dtype=torch.float64)
+    edges = torch.cumsum(torch.tensor([tr, va, te], dtype=torch.float64, device=dev) / float(n_edges), 0)
+    part = torch.clamp(torch.searchsorted(edges, part_r, right=True), max=2)
+    out = {"name": name, "n_users": U, "n_items": I}
+    for k, key in enumerate(("train", "valid", "test")):
+        m = part == k
+        c = torch.bincount(users[m], minlength=U)
+        p = torch.zeros(U + 1, dtype=torch.int64, device=dev)
+        p[1:] = torch.cumsum(c, 0)
+        out[key] = (p, items[m].contiguous())
+    return out

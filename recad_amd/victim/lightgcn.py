@@ -198,18 +198,35 @@ class LightGCN(BaseVictim):
         return (all_users[users], all_items[pos_items], all_items[neg_items], self.embedding_user(users),
                 self.embedding_item(pos_items), self.embedding_item(neg_items))
 
+    def _staging(self, n, batch, device):
+        """Stable staging buffers: the hipGraph bakes the triplet / loss pointers in, so copying each
+        epoch's indices into the same allocations lets one captured graph serve every epoch."""
+        st = self._ws.get("staging")
+        n_steps = (n + batch - 1) // batch
+        if (st is None or st["idx"].shape[1] < n or st["loss"].numel() < (n_steps + 1) * _lib.RK_LOSS_PARTIALS
+                or st["idx"].device != device):
+            cap = max(n, int(1.25 * n) if st is not None else n)
+            st = {"idx": torch.empty(3, cap, device=device, dtype=torch.int64),
+                  "loss": torch.empty(((cap + batch - 1) // batch + 1) * _lib.RK_LOSS_PARTIALS, device=device, dtype=torch.float32)}
+            self._ws["staging"] = st
+        return st
+
+    def reserve(self, n_triplets, batch, want_grad=False):
+        """Size the staging buffers for epochs of up to n_triplets and capture + upload the train-step
+        hipGraph now, so that no later epoch (or timed region) pays for either."""
+        h = self._ensure_handle(want_grad=want_grad)
+        st = self._staging(int(n_triplets), int(batch), self.embedding_user.weight.device)
+        if self._fused_adam and int(self.graph_steps) > 1 and self.n_layers > 0:
+            _lib.check(_lib.lib().rk_lightgcn_prepare(
+                h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), _lib.ptr(st["loss"]), 1,
+                int(self.graph_steps), _lib.stream_ptr()), "rk_lightgcn_prepare")
+        return st
+
     def _run_epoch(self, users, pos, neg, batch, apply_update=True, want_grad=False):
         h = self._ensure_handle(want_grad=want_grad)
         n = users.numel()
         n_steps = (n + batch - 1) // batch
-        # Stable staging buffers: the hipGraph bakes the triplet / loss pointers in, so copying each
-        # epoch's indices into the same allocations lets one captured graph serve every epoch.
-        st = self._ws.get("staging")
-        if st is None or st["idx"].shape[1] < n or st["loss"].numel() < n_steps * _lib.RK_LOSS_PARTIALS or st["idx"].device != users.device:
-            cap = max(n, int(1.25 * n) if st is not None else n)
-            st = {"idx": torch.empty(3, cap, device=users.device, dtype=torch.int64),
-                  "loss": torch.empty(((cap + batch - 1) // batch + 1) * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)}
-            self._ws["staging"] = st
+        st = self._staging(n, batch, users.device)
         st["idx"][0, :n].copy_(users)
         st["idx"][1, :n].copy_(pos)
         st["idx"][2, :n].copy_(neg)
