@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 2
+#define RK_ABI_VERSION 3
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -112,10 +112,14 @@ int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, co
                    const rk_spmm_epilogue *epi, void *stream);
 
 /* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
- * index light/emb/gprop/gego directly (item rows already offset).  gprop += dL/dlight / (L+1),
- * gego += that + the L2-reg gradient; loss_partials: device float[RK_LOSS_PARTIALS]. */
-int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb,
-                float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
+ * index emb/gprop/gego directly (item rows already offset), and light too unless light_compact != 0:
+ * then light is a compact [3*nb, dim] block holding the propagated rows of the minibatch in the order
+ * users, positives, negatives (triplet b reads rows b, nb+b, 2nb+b) -- what the row-sharded trainer
+ * assembles with one small all-reduce instead of all-gathering the whole light table.
+ * gprop += dL/dlight / (L+1), gego += that + the L2-reg gradient; loss_partials: device
+ * float[RK_LOSS_PARTIALS] (every entry is written). */
+int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, int32_t light_compact,
+                const float *emb, float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
                 const int64_t *rows_n, int32_t nb, float *loss_partials, void *stream);
 
 /* ---------------------------------------------------------------- LightGCN --------- */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryMissing(RuntimeError):
@@ -90,7 +90,7 @@ _SIGNATURES = {
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
     "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
-    "rk_bpr_rows": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
+    "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
     "rk_lightgcn_propagate": [_P, _P],

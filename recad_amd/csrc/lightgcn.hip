@@ -36,6 +36,7 @@ struct BprArgs {
     int k;
     float lr, b1, b2;
     int nb_direct;  // state == nullptr: one batch of nb_direct triplets starting at users[0]
+    int light_compact;  // light is a compact [3*nb, d] block: rows b, nb+b, 2nb+b of triplet b (row-sharded trainer)
 };
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     for (int b = wave_id; b < nb; b += n_waves) {
         const long long u = a.users[off + b], p = a.pos[off + b], n = a.neg[off + b];
         const float *lu = a.light + (size_t)u * d, *lp = a.light + (size_t)(a.U + p) * d, *ln = a.light + (size_t)(a.U + n) * d;
+        if (a.light_compact) { lu = a.light + (size_t)b * d; lp = a.light + (size_t)(nb + b) * d; ln = a.light + (size_t)(2 * nb + b) * d; }
         const float *eu = a.emb + (size_t)u * d, *ep = a.emb + (size_t)(a.U + p) * d, *en = a.emb + (size_t)(a.U + n) * d;
         float ps = 0.f, ns = 0.f, r = 0.f;
         for (int k = lane; k < d; k += 64) {
@@ -310,7 +312,7 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     b.loss_partials = loss_partials;
     b.state = d.state; b.coef = d.coef; b.k = k;
     b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
-    b.nb_direct = 0;
+    b.nb_direct = 0; b.light_compact = 0;
     hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
     RK_CHECK_LAUNCH();
     return launch_backward(d, k, apply_update, bump, s);
@@ -439,7 +441,7 @@ RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_
     return RK_OK;
 }
 
-RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb,
+RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, int32_t light_compact, const float *emb,
                           float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
                           const int64_t *rows_n, int32_t nb, float *loss_partials, void *stream)
 {
@@ -450,7 +452,7 @@ RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const flo
     b.U = 0; b.d = dim; b.L = n_layers; b.lam = lambda;
     b.light = light; b.emb = emb; b.gprop = gprop; b.gego = gego;
     b.users = rows_u; b.pos = rows_p; b.neg = rows_n;
-    b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb;
+    b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb; b.light_compact = light_compact ? 1 : 0;
     hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, (hipStream_t)stream, b);
     RK_CHECK_LAUNCH();
     return RK_OK;

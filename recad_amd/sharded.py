@@ -1,24 +1,39 @@
-"""Row-sharded LightGCN training over the GPUs of one node (north_star).
+"""Row-sharded LightGCN training + evaluation over the GPUs of one node (north_star).
 
-One process per GPU (torch.distributed: backend "nccl" = RCCL over xGMI; "gloo" in the CPU
-tests).  The N = U+I node rows are dealt round-robin to the W ranks (row r -> rank r % W, local
-row r // W), which balances nonzeros for power-law graphs without a reordering pass.  Rank g
-owns rows R_g of E0 and of Adam's moments and the CSR slab A[R_g, :] (columns re-labelled to
-the gathered layout).  Per train step:
+One process per GPU (torch.distributed: backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests and in
+the 2-ranks-on-one-GPU box check).  The N = U+I node rows are dealt round-robin to the W ranks (row r ->
+rank r % W, local row q = r // W), which balances nonzeros of power-law graphs without a reordering pass.
+Rank g owns rows R_g of E0 and of Adam's moments, and the CSR slab A[R_g, :] whose columns are re-labelled
+to the *gathered layout* below.  The local rows are cut into C contiguous chunks (M = C * Mc rows per rank,
+padded): chunk c of every rank is all-gathered as ONE contiguous block, so the gathered position of node r is
 
-    forward   l = 1..L : all-gather X_{l-1}  ->  local SpMM on the slab (fused layer sum)
-              all-gather light
-    BPR       replicated on every rank (B is tiny next to the graph): gprop/gego are full
-              and identical everywhere, so the backward needs NO reduce-scatter
-    backward  j = 1..L : local SpMM (A symmetric: the same row slab serves the transpose),
-              all-gather t_j between layers; the last one fuses Adam on the owned rows
+    pos(r) = c * (W * Mc) + (r % W) * Mc + o,      q = r // W,  c = q // Mc,  o = q % Mc.
 
-=> 2L all-gathers of (N/W)*d*4 bytes per rank and step, each rank sending its shard to the
-other W-1 ranks over its own xGMI links.  Results are identical for every W (fixed summation
-order inside a row; tests/test_sharded_gloo.py checks W=2 against W=1 and the oracle).
+Per train step:
 
-The compute calls go through an `ops` object: `HipOps` (the C-ABI) in the product; the CPU
-tests inject an oracle-backed stand-in -- this module never imports it.
+    forward   l = 1..L : for c in chunks:  local SpMM on slab chunk c (fused layer sum)
+                                           -> async all-gather of Y_l chunk c on the collective's own stream,
+                                              overlapping the SpMM of chunk c+1            (l < L only)
+              light rows of the minibatch: every rank contributes the rows it owns to a [3B, d] buffer,
+              one small all-reduce (768 KB at B=1024, d=64) -- NOT an all-gather of the [N, d] light table
+    BPR       replicated on every rank (B is tiny next to the graph): the gradients w.r.t. light / E0 are
+              scattered into full-size, identical gprop / gego buffers on every rank
+    backward  j = 1..L : chunked local SpMM (A symmetric: the same row slab serves the transpose), the
+              all-gathers of t_j overlapped the same way; the last layer fuses Adam on the owned rows
+
+=> 2L-1 all-gathers of (N/W)*d*4 bytes per rank and one 3B*d*4-byte all-reduce per step.  north_star's
+"reduce-scatter on the item gradients" is what a batch-SPLIT BPR would need (each rank holding a partial
+gradient over all rows); with the minibatch replicated every rank already holds the complete gradient rows,
+so the reduce-scatter -- and L more collectives of the same volume per step -- drop out.  The price: every
+rank runs the (B-sized) BPR kernel, keeps two full-size [N, d] gradient buffers and gathers from a
+locally-held full copy of gprop in the first backward layer.
+
+Evaluation (normal.py:57-160) is user-sharded: one propagation (L-1 all-gathers), ONE all-gather of the
+light table from which the item block is taken, then every rank scores the users it owns against the whole
+catalogue (fp32-MFMA GEMM + top-K, no further exchange) and the HR@K numerators are all-reduced (a few ints).
+
+The compute calls go through an `ops` object: `HipOps` (the C-ABI) in the product; the CPU tests inject an
+oracle-backed stand-in -- this module never imports it.
 """
 import ctypes as C
 
@@ -29,16 +44,78 @@ import torch.distributed as dist
 from . import _lib
 
 
+# ------------------------------------------------------------------------------------------------ layout
+class RowLayout:
+    """Round-robin row partition with C chunks per rank (see the module docstring)."""
+
+    def __init__(self, n_rows, world, chunks=1):
+        self.N, self.W = int(n_rows), int(world)
+        per = (self.N + self.W - 1) // self.W
+        self.C = max(1, min(int(chunks), per))
+        self.Mc = (per + self.C - 1) // self.C
+        self.M = self.Mc * self.C
+
+    def pos(self, r):
+        """gathered position of node ids r (numpy array or torch tensor, any integer dtype)."""
+        q = r // self.W
+        return (q // self.Mc) * (self.W * self.Mc) + (r % self.W) * self.Mc + q % self.Mc
+
+    def owner(self, r):
+        return r % self.W
+
+    def local(self, r):
+        return r // self.W
+
+    def own_rows(self, rank):
+        return np.arange(rank, self.N, self.W)
+
+    def chunk_range(self, rank, c):
+        """(first, last+1) gathered positions of chunk c's rows owned by `rank`."""
+        lo = c * (self.W * self.Mc) + rank * self.Mc
+        return lo, lo + self.Mc
+
+
+def build_slab_chunks(rowptr, col, val, rank, layout):
+    """CSR slabs (one per chunk) of the rows owned by `rank`, columns in the gathered layout, entry order
+    inside a row unchanged.  Inputs: host arrays or torch tensors (any device); the work is vectorised
+    (repeat / cumsum / gather), on the inputs' device.  Returns a list of (rowptr int32[Mc+1], col int32,
+    val float32) torch tensors."""
+    rp = torch.as_tensor(rowptr).long()
+    cl = torch.as_tensor(col)
+    vl = torch.as_tensor(val)
+    dev = rp.device
+    L = layout
+    rows = torch.arange(rank, L.N, L.W, device=dev)
+    deg_own = (rp[rows + 1] - rp[rows])
+    deg = torch.zeros(L.M, dtype=torch.long, device=dev)
+    deg[: rows.numel()] = deg_own
+    lp = torch.zeros(L.M + 1, dtype=torch.long, device=dev)
+    lp[1:] = torch.cumsum(deg, 0)
+    total = int(lp[-1].item())
+    # source position of every slab entry: start of its row + offset inside the row
+    row_of = torch.repeat_interleave(torch.arange(L.M, device=dev), deg)
+    starts = torch.zeros(L.M, dtype=torch.long, device=dev)
+    starts[: rows.numel()] = rp[rows]
+    src = starts[row_of] + (torch.arange(total, device=dev) - lp[row_of])
+    c_new = L.pos(cl[src].long()).to(torch.int32)
+    v_new = vl[src].to(torch.float32)
+    out = []
+    for c in range(L.C):
+        a, b = int(lp[c * L.Mc].item()), int(lp[(c + 1) * L.Mc].item())
+        out.append(((lp[c * L.Mc:(c + 1) * L.Mc + 1] - a).to(torch.int32).contiguous(), c_new[a:b].contiguous(), v_new[a:b].contiguous()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ops (product)
 class HipOps:
     """The product implementation: librecad_hip.so through include/recad_hip.h."""
 
     name = "hip"
 
     def make_slab(self, rowptr, col, val, device):
-        return {"n_rows": len(rowptr) - 1, "rowptr": torch.as_tensor(rowptr, dtype=torch.int32, device=device).contiguous(),
-                "col": torch.as_tensor(col, dtype=torch.int32, device=device).contiguous(),
-                "val": torch.as_tensor(val, dtype=torch.float32, device=device).contiguous(), "sched": {},
-                "coef": torch.zeros(2, device=device)}
+        t = lambda a, dt: torch.as_tensor(a).to(device=device, dtype=dt).contiguous()
+        return {"n_rows": len(rowptr) - 1, "rowptr": t(rowptr, torch.int32), "col": t(col, torch.int32),
+                "val": t(val, torch.float32), "sched": {}, "coef": torch.zeros(2, device=device)}
 
     @staticmethod
     def _sched(slab, dim):
@@ -55,6 +132,8 @@ class HipOps:
         return slab["sched"][dim]
 
     def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None):
+        if slab["col"].numel() == 0 and slab["n_rows"] == 0:
+            return
         e = _lib.SpmmEpilogue(add=_lib.ptr(add), y=_lib.ptr(y), sum_in=_lib.ptr(sum_in), sum_out=_lib.ptr(sum_out),
                               sum_scale=float(sum_scale))
         if adam is not None:
@@ -66,121 +145,294 @@ class HipOps:
                                              _lib.ptr(desc), n_blocks, x.shape[1], _lib.ptr(x), x.shape[0],
                                              C.byref(e), _lib.stream_ptr()), "rk_spmm_csr_ex")
 
-    def bpr(self, dim, n_layers, lam, light, emb, gprop, gego, ru, rp, rn, loss_partials):
-        _lib.check(_lib.lib().rk_bpr_rows(dim, n_layers, float(lam), _lib.ptr(light), _lib.ptr(emb), _lib.ptr(gprop),
+    def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials):
+        """light_rows: compact [3*nb, d] (users, positives, negatives of the minibatch, in that order);
+        emb / gprop / gego are indexed by the gathered positions ru / rp / rn."""
+        _lib.check(_lib.lib().rk_bpr_rows(dim, n_layers, float(lam), _lib.ptr(light_rows), 1, _lib.ptr(emb), _lib.ptr(gprop),
                                           _lib.ptr(gego), _lib.ptr(ru), _lib.ptr(rp), _lib.ptr(rn), ru.numel(),
                                           _lib.ptr(loss_partials), _lib.stream_ptr()), "rk_bpr_rows")
 
+    def score_topk(self, utab, user_rows, itab, seen_ptr, seen_idx, targets, K):
+        """-> (target_score [n,T] float32, target_rank [n,T] int32, top_ids [n,K] int32) for the users whose
+        rows in utab are user_rows; seen_ptr/seen_idx are indexed by those same row numbers."""
+        from .evaluate import full_catalog_topk
 
-def shard_rows(n_rows, world):
-    """rows-per-rank M and the round-robin relabelling: new id = (r % W) * M + r // W."""
-    M = (n_rows + world - 1) // world
-    return M, (lambda r: (r % world) * M + r // world)
+        class _Tables:
+            def scoring_tables(self_inner):
+                return utab, itab, None, None, 0.0
 
-
-def build_slab(rowptr, col, val, rank, world):
-    """CSR slab of the rows owned by `rank` (local order), columns in the gathered layout."""
-    rowptr, col, val = (np.asarray(a) for a in (rowptr, col, val))
-    N = len(rowptr) - 1
-    M, relabel = shard_rows(N, world)
-    rows = np.arange(rank, N, world)
-    deg = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
-    lp = np.zeros(M + 1, dtype=np.int64)
-    lp[1:len(rows) + 1] = np.cumsum(deg)
-    lp[len(rows) + 1:] = lp[len(rows)]
-    take = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in rows]) if len(rows) else np.zeros(0, dtype=np.int64)
-    return lp.astype(np.int32), relabel(col[take].astype(np.int64)).astype(np.int32), val[take].astype(np.float32)
+        chunk = max(256, min(8192, (1 << 31) // max(itab.shape[0], 1)))
+        res = full_catalog_topk(_Tables(), user_rows, seen_ptr, seen_idx, targets, K=K, chunk=chunk, to_host=False)
+        return res["target_score"], res["target_rank"], res["top_ids"]
 
 
+# ------------------------------------------------------------------------------------------------ trainer
 class ShardedLightGCN:
-    """Trains a LightGCN victim's tables with the node rows sharded over the process group."""
+    """Trains / evaluates a LightGCN victim's tables with the node rows sharded over the process group.
+
+    csr: (rowptr, col, val) host arrays / tensors, or a recad_amd.graph.CsrGraph (device tensors are used
+    in place: the slab is cut on the device)."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, group=None, ops=None, device=None):
+                 eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective"):
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
         self.ops = ops or HipOps()
-        self.U, self.I, self.d, self.L = n_users, n_items, dim, n_layers
+        self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(dim), int(n_layers)
+        if self.L < 1:
+            raise ValueError("ShardedLightGCN needs n_layers >= 1")
         self.lam, self.lr, self.betas, self.eps = lam, lr, betas, eps
-        self.N = n_users + n_items
-        self.M, self.relabel = shard_rows(self.N, self.world)
-        self.device = device if device is not None else user_emb.device
-        rowptr, col, val = csr
-        self.slab = self.ops.make_slab(*build_slab(rowptr, col, val, self.rank, self.world), self.device)
-        dev, M, W, d = self.device, self.M, self.world, dim
+        self.N = self.U + self.I
+        if chunks is None:  # overlap only pays when there is a collective to hide and the slab is big
+            chunks = 2 if (self.world > 1 and self.N // self.world >= 4096) else 1
+        self.layout = RowLayout(self.N, self.world, chunks)
+        self.gather_mode = gather
+        self.device = torch.device(device) if device is not None else user_emb.device
+        if hasattr(csr, "rowptr"):
+            rowptr, col, val = csr.rowptr, csr.col, csr.val
+        else:
+            rowptr, col, val = csr
+        self.slabs = [self.ops.make_slab(rp, c, v, self.device) for rp, c, v in build_slab_chunks(rowptr, col, val, self.rank, self.layout)]
+        dev, M, W, d = self.device, self.layout.M, self.world, self.d
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.e0, self.m, self.v = z(M, d), z(M, d), z(M, d)
-        self.full = [z(W * M, d) for _ in range(2)]     # gathered X / t buffers (ping-pong)
-        self.e0_full, self.light_full = z(W * M, d), z(W * M, d)
+        self.xfull = [z(W * M, d) for _ in range(2)]      # gathered X_l / t_j (ping-pong)
+        self.e0_full = z(W * M, d)
         self.y, self.s = z(M, d), z(M, d)
-        self.gprop, self.gego = z(W * M, d), z(W * M, d)
+        self.gprop, self.gego = z(W * M, d), z(W * M, d)  # replicated, zero outside a step
         self.t = 0
+        self._plan = None
         self.load_tables(user_emb, item_emb)
 
-    # ------------------------------------------------------------------ table movement
-    def _own_rows(self):
-        return torch.arange(self.rank, self.N, self.world, device=self.device)
+    def describe(self):
+        L = self.layout
+        return (f"node rows sharded round-robin over {self.world} GPUs ({L.M} rows/rank in {L.C} chunk(s)); per step "
+                f"{2 * self.L - 1} all-gathers of {L.M * self.d * 4 / 1e6:.1f} MB/rank ({self.gather_mode}) overlapped chunk-wise "
+                f"with the local SpMM + one [3B,d] all-reduce; BPR replicated, no reduce-scatter")
 
+    # ------------------------------------------------------------------ table movement
     def load_tables(self, user_emb, item_emb):
         full = torch.cat([user_emb.detach().to(self.device), item_emb.detach().to(self.device)])
-        own = self._own_rows()
+        own = torch.arange(self.rank, self.N, self.world, device=self.device)
         self.e0.zero_()
-        self.e0[: len(own)] = full[own]
+        self.e0[: own.numel()] = full[own]
 
-    def _gather(self, local, out):
+    def _host_staged(self):
+        """gloo with device tensors (the 2-ranks-on-one-GPU box check): collectives go through host copies."""
+        return self.world > 1 and self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+
+    def _all_reduce(self, t):
         if self.world == 1:
-            out.copy_(local)
+            return
+        if self._host_staged():
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
         else:
-            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
-        return out
+            dist.all_reduce(t, group=self.group)
+
+    def _all_gather_chunk(self, local_chunk, out_full, c, async_op):
+        """all-gather chunk c (rows [c*Mc, (c+1)*Mc) of a local [M,d] buffer) into its block of out_full."""
+        L, W = self.layout, self.world
+        blk = out_full[c * W * L.Mc:(c + 1) * W * L.Mc]
+        if W == 1:
+            blk.copy_(local_chunk)
+            return None
+        if self._host_staged():
+            h = torch.empty(blk.shape, dtype=blk.dtype)
+            dist.all_gather_into_tensor(h, local_chunk.cpu().contiguous(), group=self.group)
+            blk.copy_(h)
+            return None
+        if self.gather_mode == "direct":
+            # one-shot: every rank sends its shard to each peer and receives theirs, all pairs at once
+            # (one RCCL group of 2(W-1) point-to-point ops: each rides its own xGMI link)
+            blk[self.rank * L.Mc:(self.rank + 1) * L.Mc].copy_(local_chunk)
+            ops_ = []
+            for k in range(1, W):
+                dst, src = (self.rank + k) % W, (self.rank - k) % W
+                ops_.append(dist.P2POp(dist.isend, local_chunk, dst, self.group))
+                ops_.append(dist.P2POp(dist.irecv, blk[src * L.Mc:(src + 1) * L.Mc], src, self.group))
+            works = dist.batch_isend_irecv(ops_)
+            if not async_op:
+                for w_ in works:
+                    w_.wait()
+                return None
+            return works
+        work = dist.all_gather_into_tensor(blk, local_chunk, group=self.group, async_op=async_op)
+        return [work] if async_op else None
+
+    @staticmethod
+    def _wait(pending):
+        for works in pending:
+            if works:
+                for w_ in works:
+                    w_.wait()   # nccl: the current stream waits for the collective's stream; gloo: host wait
+        pending.clear()
+
+    def _gather_full(self, local, out_full):
+        for c in range(self.layout.C):
+            self._all_gather_chunk(local[c * self.layout.Mc:(c + 1) * self.layout.Mc], out_full, c, False)
+        return out_full
 
     def tables(self):
         """(users[U,d], items[I,d]) in the original order, on every rank."""
-        g = self._gather(self.e0, torch.empty_like(self.e0_full))
-        idx = self.relabel(torch.arange(self.N, device=self.device))
-        full = g[idx]
+        g = self._gather_full(self.e0, torch.empty_like(self.e0_full))
+        full = g[self.layout.pos(torch.arange(self.N, device=self.device))]
         return full[: self.U].contiguous(), full[self.U:].contiguous()
 
-    # ------------------------------------------------------------------ one step
-    def step(self, users, pos, neg):
-        ops, L, M, r = self.ops, self.L, self.M, self.rank
+    # ------------------------------------------------------------------ propagation (shared by train / eval)
+    def _forward(self):
+        """L chunked SpMM layers with the all-gathers of layers < L in flight under the next chunk;
+        leaves light rows (owned) in self.s."""
+        ops, L, lay = self.ops, self.L, self.layout
         inv = 1.0 / (L + 1)
-        lo = slice(r * M, (r + 1) * M)
-        # forward
-        x = self._gather(self.e0, self.e0_full)
+        x = self._gather_full(self.e0, self.e0_full)
         for l in range(1, L + 1):
             last = l == L
-            ops.spmm(self.slab, x, y=None if last else self.y, sum_in=self.e0 if l == 1 else self.s, sum_out=self.s,
-                     sum_scale=inv if last else 1.0)
-            if not last:
-                x = self._gather(self.y, self.full[l & 1])
-        light = self._gather(self.s, self.light_full)
-        # BPR, replicated (rows in the gathered layout)
-        ru = self.relabel(users)
-        rp = self.relabel(pos + self.U)
-        rn = self.relabel(neg + self.U)
-        lp = torch.zeros(_lib.RK_LOSS_PARTIALS, device=self.device, dtype=torch.float32)
-        ops.bpr(self.d, L, self.lam, light, self.e0_full, self.gprop, self.gego, ru.contiguous(), rp.contiguous(), rn.contiguous(), lp)
+            nxt = self.xfull[l & 1]
+            pending = []
+            for c in range(lay.C):
+                rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
+                ops.spmm(self.slabs[c], x, y=None if last else self.y[rs], sum_in=(self.e0 if l == 1 else self.s)[rs],
+                         sum_out=self.s[rs], sum_scale=inv if last else 1.0)
+                if not last:
+                    pending.append(self._all_gather_chunk(self.y[rs], nxt, c, True))
+            self._wait(pending)
+            x = nxt
+
+    # ------------------------------------------------------------------ training
+    def reserve(self, n_triplets, batch):
+        """Preallocate the per-epoch index plan and loss buffers for epochs of up to n_triplets."""
+        n_steps = (int(n_triplets) + batch - 1) // batch
+        dev = self.device
+        if self._plan is None or self._plan["cap_steps"] < n_steps or self._plan["batch"] != batch:
+            self._plan = {"cap_steps": n_steps, "batch": batch,
+                          "loss": torch.zeros(n_steps, _lib.RK_LOSS_PARTIALS, device=dev, dtype=torch.float32),
+                          "rows": torch.zeros(3 * batch, self.d, device=dev, dtype=torch.float32)}
+        return self._plan
+
+    def _epoch_plan(self, users, pos, neg, batch):
+        """Everything index-shaped a step needs, for the whole epoch at once (no per-step host arithmetic):
+        gathered positions of the minibatch nodes, and which compact rows this rank owns."""
+        lay, dev = self.layout, self.device
+        nodes = torch.stack([users.to(dev).long(), pos.to(dev).long() + self.U, neg.to(dev).long() + self.U])  # [3, n]
+        posn = lay.pos(nodes).contiguous()                                                        # gathered positions
+        own = (nodes % self.world) == self.rank
+        local = (nodes // self.world)
+        return {"pos": posn, "own": own, "local": local}
+
+    def step(self, plan, ep, s0, nb, k):
+        """One train step on triplets [s0, s0+nb) of the epoch plan; writes its loss partials to plan['loss'][k]."""
+        ops, L, lay, r = self.ops, self.L, self.layout, self.rank
+        self._forward()
+        # light rows of the minibatch: own rows in place, zeros elsewhere, summed over the ranks (x + 0 is exact)
+        rows = plan["rows"][: 3 * nb]
+        own = ep["own"][:, s0:s0 + nb].reshape(-1)
+        loc = ep["local"][:, s0:s0 + nb].reshape(-1)
+        if self.world == 1:
+            torch.index_select(self.s, 0, loc, out=rows)
+        else:
+            rows.zero_()
+            sel = torch.nonzero(own).view(-1)
+            rows.index_copy_(0, sel, self.s.index_select(0, loc[sel]))
+            self._all_reduce(rows)
+        ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
+        lp = plan["loss"][k]
+        ops.bpr(self.d, L, self.lam, rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp)
         # backward + Adam on the owned rows
         self.t += 1
-        adam = {"t": self.t, "p": self.e0, "m": self.m, "v": self.v, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1],
-                "eps": self.eps}
+        adam = {"t": self.t, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}
         x = self.gprop
         for j in range(1, L + 1):
             last = j == L
-            ops.spmm(self.slab, x, add=(self.gego if last else self.gprop)[lo], y=None if last else self.y,
-                     adam=adam if last else None)
-            if not last:
-                x = self._gather(self.y, self.full[j & 1])
-        self.gprop.zero_()
-        self.gego.zero_()
+            nxt = self.xfull[j & 1]
+            pending = []
+            for c in range(lay.C):
+                rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
+                lo, hi = lay.chunk_range(r, c)
+                a = dict(adam, p=self.e0[rs], m=self.m[rs], v=self.v[rs]) if last else None
+                ops.spmm(self.slabs[c], x, add=(self.gego if last else self.gprop)[lo:hi], y=None if last else self.y[rs], adam=a)
+                if not last:
+                    pending.append(self._all_gather_chunk(self.y[rs], nxt, c, True))
+            self._wait(pending)
+            x = nxt
+        # only the minibatch's rows of the replicated gradient buffers are non-zero
+        touched = ep["pos"][:, s0:s0 + nb].reshape(-1)
+        self.gprop.index_fill_(0, touched, 0.0)
+        self.gego.index_fill_(0, touched, 0.0)
         return lp
 
     def train_epoch(self, users, pos, neg, batch):
         """All ranks pass the SAME triplets.  Returns the per-step losses (float64 tensor, host)."""
         n = users.numel()
-        parts = []
-        for s in range(0, n, batch):
-            parts.append(self.step(users[s:s + batch], pos[s:s + batch], neg[s:s + batch]))
-        return torch.stack(parts).sum(dim=1).double().cpu()
+        plan = self.reserve(n, batch)
+        ep = self._epoch_plan(users, pos, neg, batch)
+        k = 0
+        for s0 in range(0, n, batch):
+            self.step(plan, ep, s0, min(batch, n - s0), k)
+            k += 1
+        return plan["loss"][:k].sum(dim=1).double().cpu()
+
+    # ------------------------------------------------------------------ evaluation (user-sharded)
+    def evaluate(self, seen_ptr, seen_idx, targets, K=100, topks=(10, 20, 50, 100), reps=1):
+        """Full-catalog scoring + top-K + HR@K (normal.py:57-160) with the users sharded like the rows:
+        one propagation, one all-gather of the light table, local scoring of the owned users, all-reduced
+        hit counts.  seen_ptr/seen_idx: host CSR user -> sorted train items; users whose list is empty or
+        holds a target are skipped (normal.py:133-143).  Returns a dict (identical on every rank)."""
+        import time
+
+        lay, dev, W, r = self.layout, self.device, self.world, self.rank
+        seen_ptr = np.asarray(seen_ptr).astype(np.int64)
+        seen_idx = np.asarray(seen_idx).astype(np.int32)
+        targets = np.asarray(targets, dtype=np.int32)
+        mine = np.arange(r, self.U, W)                                  # global user ids owned by this rank
+        deg = seen_ptr[mine + 1] - seen_ptr[mine]
+        # local seen CSR indexed by the LOCAL row number q = u // W (utab is this rank's light rows)
+        lptr = np.zeros(lay.M + 1, dtype=np.int64)
+        lptr[1:len(mine) + 1] = np.cumsum(deg)
+        lptr[len(mine) + 1:] = lptr[len(mine)]
+        take = np.repeat(seen_ptr[mine], deg) + (np.arange(int(deg.sum())) - np.repeat(lptr[:len(mine)], deg))
+        lidx = seen_idx[take]
+        has_t = np.zeros(len(mine), dtype=bool)
+        if len(lidx):
+            hit = np.isin(lidx, targets)
+            has_t[np.repeat(np.arange(len(mine)), deg)[hit]] = True
+        q_elig = np.nonzero((deg > 0) & ~has_t)[0].astype(np.int32)
+        t_ = lambda a, dt: torch.as_tensor(a).to(device=dev, dtype=dt).contiguous()
+        q_dev, lptr_dev, lidx_dev, tg_dev = t_(q_elig, torch.int32), t_(lptr, torch.int32), t_(lidx if len(lidx) else np.zeros(1, np.int32), torch.int32), t_(targets, torch.int32)
+        ks = torch.as_tensor(list(topks), device=dev, dtype=torch.int32)
+        item_pos = lay.pos(torch.arange(self.U, self.N, device=dev))
+        light_full = torch.empty_like(self.e0_full)
+        out = None
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if W > 1:
+            dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(max(1, reps)):
+            self._forward()
+            self._gather_full(self.s, light_full)
+            itab = light_full.index_select(0, item_pos)
+            stats = torch.zeros(1 + len(targets) * (1 + len(topks)), device=dev, dtype=torch.float64)
+            if len(q_elig):
+                tscore, trank, _ = self.ops.score_topk(self.s, q_dev, itab, lptr_dev, lidx_dev, tg_dev, K)
+                hits = (trank.unsqueeze(2) < ks.view(1, 1, -1)).sum(dim=0).double()        # [T, nk]
+                stats[0] = float(len(q_elig))
+                stats[1:1 + len(targets)] = tscore.double().sum(dim=0)
+                stats[1 + len(targets):] = hits.reshape(-1)
+            self._all_reduce(stats)
+            out = stats
+        host = out.cpu().numpy()
+        el = (time.perf_counter() - t0) / max(1, reps)
+        n_users = int(host[0])
+        T = len(targets)
+        hits = host[1 + T:].reshape(T, len(topks))
+        res = {"value": n_users / el, "unit": "users/s", "eligible_users": n_users, "seconds": el, "evaluations_timed": max(1, reps),
+               "target_score_mean": [float(x) / max(n_users, 1) for x in host[1:1 + T]],
+               "includes": "sharded propagate + light all-gather + per-rank fp32-MFMA GEMM / top-K over the owned users + all-reduced HR counts"}
+        for qi, k in enumerate(topks):
+            res[f"hr@{k}"] = float(hits[0, qi]) / max(n_users, 1)
+        res["hit_counts"] = hits.tolist()
+        return res

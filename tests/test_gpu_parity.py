@@ -385,16 +385,17 @@ def test_ncf_train_golden(gpu_device, name):
         _eval_against_golden(g, m, gpu_device)
 
 
-@pytest.mark.parametrize("name", ["lightgcn_game_d64_tg", "lightgcn_dev_d128_l2_tg"])
-def test_sharded_trainer_single_rank_hip(gpu_device, name):
-    """The row-sharded trainer with the real HIP ops (rk_spmm_csr_ex / rk_bpr_rows), world = 1:
-    same losses and tables as the goldens (the multi-rank logic is covered on CPU with gloo)."""
+@pytest.mark.parametrize("name,chunks", [("lightgcn_game_d64_tg", 1), ("lightgcn_game_d64_tg", 3), ("lightgcn_dev_d128_l2_tg", 2)])
+def test_sharded_trainer_single_rank_hip(gpu_device, name, chunks):
+    """The row-sharded trainer with the real HIP ops (rk_spmm_csr_ex / rk_bpr_rows with compact light rows),
+    world = 1, one or several row chunks: same losses and tables as the goldens, and the sharded evaluation
+    equals the oracle's (the multi-rank logic is also covered on CPU with gloo)."""
     from recad_amd.sharded import ShardedLightGCN
     g = G.load(name)
     U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u0, i0 = G.lightgcn_init(g)
-    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device))
+    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device), chunks=chunks)
     for s in range(len(g["batch_len"])):
         n = int(g["batch_len"][s])
         u, p, ng = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)).to(gpu_device) for k in range(3))
@@ -404,6 +405,72 @@ def test_sharded_trainer_single_rank_hip(gpu_device, name):
     rs = int(g["row_stride"])
     assert G.relerr(users.cpu().numpy()[::rs], g["final_user"]) < TABLE_RTOL
     assert G.relerr(items.cpu().numpy()[::rs], g["final_item"]) < TABLE_RTOL
+    _check_sharded_eval(tr.evaluate(g["train_ptr"], g["train_idx"], g["target_ids"], K=100, topks=(10, 20, 50, 100)), g, csr,
+                        users.cpu().numpy(), items.cpu().numpy())
+
+
+def _check_sharded_eval(ev, g, csr, users, items):
+    U, I, L = int(g["n_users"]), int(g["n_items"]), int(g["layers"])
+    topks = (10, 20, 50, 100)
+    light = orc.lightgcn_propagate(csr, users, items, L)
+    rows, _ = orc.evaluate(lambda uu: orc.score_rows(light[uu:uu + 1], light[U:])[0], I, g["train_ptr"], g["train_idx"],
+                           g["target_ids"], topks, K=100)
+    T = len(g["target_ids"])
+    assert ev["eligible_users"] == len(rows) // T
+    ref_hits = rows[:, 2:].reshape(-1, T, len(topks)).sum(axis=0)
+    assert np.abs(np.asarray(ev["hit_counts"]) - ref_hits).max() <= 1
+    assert abs(ev["target_score_mean"][0] - rows[0::T, 1].mean()) <= 1e-5 * max(1e-3, abs(rows[0::T, 1].mean()))
+
+
+def _sharded_two_rank_worker(rank, world, port, name, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recad_amd.sharded import ShardedLightGCN
+    dev = torch.device("cuda:0")  # both ranks share the box's one GPU; collectives are host-staged over gloo
+    g = G.load(name)
+    U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(dev), torch.from_numpy(i0).to(dev), chunks=2)
+    losses = []
+    for s in range(len(g["batch_len"])):
+        n = int(g["batch_len"][s])
+        u, p, ng = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)).to(dev) for k in range(3))
+        losses.append(float(tr.train_epoch(u, p, ng, n)[0]))
+    users, items = tr.tables()
+    ev = tr.evaluate(g["train_ptr"], g["train_idx"], g["target_ids"], K=100, topks=(10, 20, 50, 100))
+    if rank == 0:
+        np.savez(out_path, losses=np.asarray(losses), users=users.cpu().numpy(), items=items.cpu().numpy(),
+                 hits=np.asarray(ev["hit_counts"]), n_users=ev["eligible_users"], tmean=np.asarray(ev["target_score_mean"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_trainer_two_ranks_hip(gpu_device, tmp_path):
+    """World size 2 with the REAL HIP ops: two processes share the box's GPU (gloo, host-staged collectives),
+    so the relabelled column slabs, the chunked gathers, the compact-row BPR and the user-sharded evaluation
+    all run through librecad_hip.so with world > 1."""
+    import socket
+    import torch.multiprocessing as mp
+    name = "lightgcn_game_d64_tg"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "w2.npz")
+    mp.spawn(_sharded_two_rank_worker, args=(2, port, name, out), nprocs=2, join=True)
+    res = np.load(out)
+    g = G.load(name)
+    for s in range(len(res["losses"])):
+        assert abs(res["losses"][s] - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, res["losses"][s], g["losses"][s])
+    rs = int(g["row_stride"])
+    assert G.relerr(res["users"][::rs], g["final_user"]) < TABLE_RTOL
+    assert G.relerr(res["items"][::rs], g["final_item"]) < TABLE_RTOL
+    U, I = int(g["n_users"]), int(g["n_items"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    _check_sharded_eval({"eligible_users": int(res["n_users"]), "hit_counts": res["hits"], "target_score_mean": res["tmean"]}, g, csr,
+                        res["users"], res["items"])
 
 
 def test_device_samplers(gpu_device):

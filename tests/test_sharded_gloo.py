@@ -1,7 +1,11 @@
-"""N>1 path on CPU: world_size-2 gloo run of the row-sharded LightGCN trainer (oracle ops
-injected) must reproduce the single-process oracle."""
+"""N>1 path on CPU: world_size 1/2/3 gloo runs of the row-sharded LightGCN trainer + user-sharded
+evaluation (oracle ops injected) must reproduce the single-process oracle and the goldens; and the
+self-launching `bench.py --gpus N` front end must rendezvous N workers."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +16,9 @@ import torch.multiprocessing as mp
 from oracle import oracle as orc
 from tests import _golden as G
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOPKS = (10, 20, 50, 100)
+
 
 def _free_port():
     with socket.socket() as s:
@@ -19,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, out_path):
+def _worker(rank, world, port, name, out_path, chunks, gather):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,27 +36,38 @@ def _worker(rank, world, port, name, out_path):
     U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u0, i0 = G.lightgcn_init(g)
-    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"))
+    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"),
+                         chunks=chunks, gather=gather)
+    assert tr.layout.C == chunks
     losses = []
     for s in range(min(4, len(g["batch_len"]))):
         n = int(g["batch_len"][s])
         u, p, ng = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)) for k in range(3))
         losses.append(float(tr.train_epoch(u, p, ng, n)[0]))
+    # two steps in ONE epoch call with a short last batch (the per-epoch index plan)
+    n = int(g["batch_len"][0])
+    u, p, ng = (torch.from_numpy(g["batches"][0, k, :n].astype(np.int64)) for k in range(3))
+    two = tr.train_epoch(u, p, ng, (n + 1) // 2 + 1)
+    assert two.numel() == 2 and bool(torch.isfinite(two).all())
     users, items = tr.tables()
+    ev = tr.evaluate(g["train_ptr"], g["train_idx"], g["target_ids"], K=100, topks=TOPKS)
     if rank == 0:
-        np.savez(out_path, losses=np.asarray(losses), users=users.numpy(), items=items.numpy())
+        np.savez(out_path, losses=np.asarray(losses), users=users.numpy(), items=items.numpy(), hits=np.asarray(ev["hit_counts"]),
+                 n_users=ev["eligible_users"], tmean=np.asarray(ev["target_score_mean"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_matches_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,chunks,gather", [(1, 1, "collective"), (2, 1, "collective"), (2, 3, "collective"),
+                                                 (3, 2, "collective"), (3, 2, "direct")])
+def test_sharded_matches_oracle(tmp_path, world, chunks, gather):
     name = "lightgcn_game_d64_tg"
     out = str(tmp_path / f"w{world}.npz")
-    mp.spawn(_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, out, chunks, gather), nprocs=world, join=True)
     res = np.load(out)
     g = G.load(name)
     U, I, L = int(g["n_users"]), int(g["n_items"]), int(g["layers"])
+    assert (U + I) % world != 0 or world == 1   # the ragged case (N % W != 0) is the one exercised
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u, i = G.lightgcn_init(g)
     st = orc.AdamState(u.shape, i.shape)
@@ -58,28 +76,70 @@ def test_sharded_matches_oracle(tmp_path, world):
         ref = orc.lightgcn_step(csr, u, i, st, *(g["batches"][s, k, :n] for k in range(3)), L)
         assert abs(res["losses"][s] - ref) <= 1e-5 * abs(ref), (s, res["losses"][s], ref)
         assert abs(res["losses"][s] - g["losses"][s]) <= 1e-5 * abs(g["losses"][s])
+    # the extra two-step epoch of the worker
+    n = int(g["batch_len"][0])
+    b = (n + 1) // 2 + 1
+    for lo in (0, b):
+        orc.lightgcn_step(csr, u, i, st, *(g["batches"][0, k, lo:min(n, lo + b)] for k in range(3)), L)
     assert G.relerr(res["users"], u) < 1e-5 and G.relerr(res["items"], i) < 1e-5
+    # user-sharded evaluation == single-process oracle evaluation of the same tables
+    light = orc.lightgcn_propagate(csr, u, i, L)
+    rows, _ = orc.evaluate(lambda uu: orc.score_rows(light[uu:uu + 1], light[U:])[0], I, g["train_ptr"], g["train_idx"],
+                           g["target_ids"], TOPKS, K=100)
+    T = len(g["target_ids"])
+    assert int(res["n_users"]) == len(rows) // T
+    ref_hits = rows[:, 2:].reshape(-1, T, len(TOPKS)).sum(axis=0) if T > 1 else rows[:, 2:].sum(axis=0, keepdims=True)
+    # a rank flip needs two scores within summation noise of each other: allow one per threshold
+    assert np.abs(res["hits"] - ref_hits).max() <= 1, (res["hits"], ref_hits)
+    assert abs(res["tmean"][0] - rows[0::T, 1].mean()) <= 1e-5 * max(1e-3, abs(rows[0::T, 1].mean()))
 
 
 def test_slab_partition_covers_graph():
-    from recad_amd.sharded import build_slab, shard_rows
+    from recad_amd.sharded import RowLayout, build_slab_chunks
     rng = np.random.default_rng(0)
     n = 101
     deg = rng.integers(0, 9, n)
     rowptr = np.zeros(n + 1, dtype=np.int32); rowptr[1:] = np.cumsum(deg)
     col = rng.integers(0, n, rowptr[-1]).astype(np.int32)
     val = rng.random(rowptr[-1]).astype(np.float32)
-    for W in (1, 2, 4, 8):
-        M, relabel = shard_rows(n, W)
+    for W, Cc in ((1, 1), (2, 1), (4, 3), (8, 2), (3, 5)):
+        lay = RowLayout(n, W, Cc)
+        inv = {int(lay.pos(np.int64(r))): r for r in range(n)}
+        assert len(inv) == n and max(inv) < W * lay.M and lay.M == lay.C * lay.Mc
         seen = 0
-        inv = {int(relabel(r)): r for r in range(n)}
-        assert len(inv) == n and max(inv) < W * M
         for g in range(W):
-            lp, lc, lv = build_slab(rowptr, col, val, g, W)
-            assert len(lp) == M + 1
-            for k, r in enumerate(range(g, n, W)):
-                a, b = lp[k], lp[k + 1]
-                assert [inv[int(c)] for c in lc[a:b]] == col[rowptr[r]:rowptr[r + 1]].tolist()
-                assert np.array_equal(lv[a:b], val[rowptr[r]:rowptr[r + 1]])
-                seen += b - a
+            chunks = build_slab_chunks(rowptr, col, val, g, lay)
+            assert len(chunks) == lay.C
+            own = list(range(g, n, W))
+            for c, (lp, lc, lv) in enumerate(chunks):
+                lp, lc, lv = lp.numpy(), lc.numpy(), lv.numpy()
+                assert len(lp) == lay.Mc + 1 and lp[0] == 0
+                lo, hi = lay.chunk_range(g, c)
+                for k in range(lay.Mc):
+                    q = c * lay.Mc + k
+                    a, b = lp[k], lp[k + 1]
+                    if q >= len(own):
+                        assert a == b
+                        continue
+                    r = own[q]
+                    assert int(lay.pos(np.int64(r))) == lo + k
+                    assert [inv[int(x)] for x in lc[a:b]] == col[rowptr[r]:rowptr[r + 1]].tolist()
+                    assert np.array_equal(lv[a:b], val[rowptr[r]:rowptr[r + 1]])
+                    seen += b - a
         assert seen == rowptr[-1]
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` must start its own two workers (no torchrun) and print one JSON object."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "rows"
+    # a world that disagrees with --gpus is refused
+    env2 = dict(env, RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env2)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
