@@ -44,38 +44,29 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
                   float *val /*[nnz]*/, void *stream);
 
 /* Work schedule for rk_spmm_csr (load balance for power-law rows): every row is cut into
- * segments of <= 64 nonzeros; whole rows are packed into workgroups of 8 waves (best-fit
- * decreasing), one segment per wave; a row with more than 8 segments is cut into pieces of 8
- * segments, one workgroup each, whose partial sums meet in scratch slots -- the last workgroup
+ * segments of <= 64 (or 128, chosen per graph) nonzeros; whole rows are packed into workgroups of 4 or 8
+ * waves (best-fit decreasing), one segment per wave; a row with more segments than a workgroup has waves
+ * is cut into pieces, one workgroup each, whose partial sums meet in scratch slots -- the last workgroup
  * of a row to arrive (agent-scope ticket) adds them in piece order and runs the epilogue.
  * Rows that fit one lane-group chunk (<= dim/4 nonzeros, dim in {32,64,128}) are packed 256/dim per
  * wave, one row per lane group.  Built on the host once per (graph, dim) (reads rowptr back:
- * synchronous) and only valid for SpMMs of that `dim`.  _build returns `n_blocks`, an opaque launch
- * parameter (workgroup count plus a flag bit) to hand back to the SpMM entry points unchanged,
- * and the size in int32 words of the device buffer `wave_desc` that _upload fills: wave
- * descriptors, workgroup metas, packed-row table, arrival counters and the partial-sum slots.
+ * synchronous) and only valid for SpMMs of that `dim`.  _build returns
+ *   n_blocks       an opaque launch parameter (workgroup count plus flag bits) to hand back to the SpMM
+ *                  entry points unchanged,
+ *   n_words        the size in int32 words of the READ-ONLY device buffer `wave_desc` that _upload fills
+ *                  (wave descriptors, workgroup metas, packed-row table): shareable by any number of
+ *                  handles, models and streams,
+ *   scratch_words  the size in int32 words (0 when the graph has no long row) of the MUTABLE scratch block
+ *                  the SpMM entry points take: arrival counters + partial-sum slots of the long rows.
+ *                  Caller-allocated, zero-filled once (the counters reset themselves), one block per
+ *                  stream / handle: two SpMMs in flight on one schedule must not share it.
  * class_split > 0 (= n_users for the bipartite adjacency): rows < split and rows >= split are
  * scheduled separately and interleaved 4:4 over the 8 XCDs so each XCD L2 holds one table. */
 typedef struct rk_schedule *rk_schedule_t;
 int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim, void *stream,
-                          rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words);
+                          rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words);
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);
-
-/* Tables for the persistent LDS hot-row SpMM: one 16-wave workgroup per CU stages the
- * 128 KiB / (4*dim) most frequently gathered X rows of its row class in LDS, and every wave walks
- * a host-balanced list of work items (whole rows, or <= 256-nonzero pieces of long rows whose
- * partial sums a second tiny launch combines).  Host-built once per (graph, dim); synchronous.
- * _build fills meta (host int32[8]) = {H, max_items, n_long_rows, two_classes, n_pieces, grid,
- * permille of nonzeros served from LDS, 0}; _upload writes (device) col_tagged int32[nnz] and
- * val_hot float[nnz] (every item reordered cold-first), hot_rows int32[2*H],
- * witems int32[grid*16*max_items*4], long_rows int32[max(1,n_long)*4]. */
-typedef struct rk_hot *rk_hot_t;
-int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
-                      int32_t class_split, int32_t dim, void *stream, rk_hot_t *out, int32_t *meta);
-int rk_spmm_hot_upload(rk_hot_t h, int32_t *col_tagged, float *val_hot, int32_t *hot_rows, int32_t *witems,
-                       int32_t *long_rows, void *stream);
-int rk_spmm_hot_destroy(rk_hot_t h);
 
 /* D^-1/2 A D^-1/2 of the bipartite user-item graph straight into CSR, on device.
  * Replaces ImplicitData.getSparseGraph, recad/dataset/implicit.py:243-298 (scipy dok/lil).
@@ -86,9 +77,10 @@ int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t *r_ptr, co
                       int32_t *rowptr, int32_t *col, float *val, int32_t *tmp, void *stream);
 
 /* Y = A.X (+ add).  Replaces torch.sparse.mm(g, all_emb), recad/model/victim/lightgcn.py:107.
- * X, add (nullable), Y: device float[n_rows*dim], row-major; n_rows*dim*4 < 4 GiB. */
+ * X, add (nullable), Y: device float[n_rows*dim], row-major; n_rows*dim*4 < 4 GiB.
+ * scratch: device int32[scratch_words] of rk_csr_schedule_build (NULL when that was 0). */
 int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
+                const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
                 const float *add, float *y, void *stream);
 
 /* rk_spmm_csr with every fused epilogue the LightGCN step uses, for callers that compose a step
@@ -108,8 +100,8 @@ typedef struct rk_spmm_epilogue {
     float lr, beta1, beta2, eps;
 } rk_spmm_epilogue;
 int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                   const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x, int64_t x_rows,
-                   const rk_spmm_epilogue *epi, void *stream);
+                   const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
+                   int64_t x_rows, const rk_spmm_epilogue *epi, void *stream);
 
 /* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
  * index emb/gprop/gego directly (item rows already offset), and light too unless light_compact != 0:
@@ -143,11 +135,8 @@ typedef struct rk_lightgcn_desc {
     float *grad;                              /* nullable: receives dLoss/dE0 [N*dim] */
     int32_t *state;                           /* device int32[16], owned by the handle's user */
     float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] */
-    /* optional LDS hot-row tables from rk_spmm_hot_build/_upload (hot_H = 0: plain gather kernel) */
-    const int32_t *col_tagged, *hot_rows, *witems, *long_rows;
-    const float *val_hot;
-    float *partials;                          /* float[max(1,n_pieces)*dim] scratch */
-    int32_t hot_H, max_items, n_long, two_classes, hot_grid, reserved2;
+    int32_t *spmm_scratch;                    /* int32[scratch_words] of rk_csr_schedule_build, zero-filled, owned by this
+                                               * handle's user (NULL when scratch_words == 0) */
     /* optional: device uint32[(N+31)/32] bitmap of the current minibatch's rows; when given (and
      * n_layers >= 2) the last forward layer computes only those rows of `light` */
     uint32_t *row_bits;

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librecad_hip.so")
+# RECAD_HIP_LIB: A/B runs against a variant build of the same ABI (tuning only)
+LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
 ABI_VERSION = 3
@@ -37,10 +38,7 @@ class LightGCNDesc(C.Structure):
         ("m_user", C.c_void_p), ("v_user", C.c_void_p), ("m_item", C.c_void_p), ("v_item", C.c_void_p),
         ("buf_a", C.c_void_p), ("buf_b", C.c_void_p), ("light", C.c_void_p), ("gprop", C.c_void_p), ("gego", C.c_void_p),
         ("grad", C.c_void_p), ("state", C.c_void_p), ("coef", C.c_void_p),
-        ("col_tagged", C.c_void_p), ("hot_rows", C.c_void_p), ("witems", C.c_void_p), ("long_rows", C.c_void_p),
-        ("val_hot", C.c_void_p), ("partials", C.c_void_p),
-        ("hot_H", C.c_int32), ("max_items", C.c_int32), ("n_long", C.c_int32), ("two_classes", C.c_int32),
-        ("hot_grid", C.c_int32), ("reserved2", C.c_int32),
+        ("spmm_scratch", C.c_void_p),
         ("row_bits", C.c_void_p),
         ("keep_prob", C.c_float), ("reserved3", C.c_int32), ("drop_seed", C.c_uint64), ("tpos", C.c_void_p),
     ]
@@ -81,15 +79,12 @@ _SIGNATURES = {
     "rk_last_error": [],
     "rk_device_info": [C.c_char_p, _I32, C.POINTER(_I32)],
     "rk_coo_to_csr": [_I32, _I64, _P, _P, _P, _P, _P, _P, _P],
-    "rk_csr_schedule_build": [_I32, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32), C.POINTER(_I64)],
+    "rk_csr_schedule_build": [_I32, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)],
     "rk_csr_schedule_upload": [_P, _P, _P],
     "rk_csr_schedule_destroy": [_P],
-    "rk_spmm_hot_build": [_I32, _I64, _P, _P, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32)],
-    "rk_spmm_hot_upload": [_P, _P, _P, _P, _P, _P, _P],
-    "rk_spmm_hot_destroy": [_P],
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
-    "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
-    "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
+    "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P],
+    "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
     "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],

@@ -127,6 +127,30 @@ __global__ void adam_kernel(long long n, float *p, const float *g, float *m, flo
     }
 }
 
+// n_layers == 0 (valid in the reference: light = E0, lightgcn.py:97-113 with an empty layer loop): the whole
+// gradient is gego.  Dense Adam with the step's device-resident coefficients, the gradient buffers cleaned for the
+// next step, optional copy of the gradient, state bump -- the epilogue work the last backward SpMM does when L >= 1.
+__global__ void adam_l0_kernel(long long n, float *p, float *gego, float *gprop, float *m, float *v, const float *coef,
+                               float b1, float b2, float eps, int apply_update, float *grad_out, int *state, int bump)
+{
+    if (bump && blockIdx.x == 0 && threadIdx.x == 0) {
+        state[ST_STEP_BASE] += bump;
+        state[ST_ADAM_T] += bump;
+    }
+    const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float g = gego[i];
+        gego[i] = 0.f;
+        gprop[i] = 0.f;
+        if (grad_out) grad_out[i] = g;
+        if (apply_update) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            adam_elem(pp, mm, vv, g, w1, b2, w2, coef[0], coef[1], eps);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
 RK_EXPORT int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
                            float beta1, float beta2, float eps, void *stream)
 {
@@ -146,6 +170,7 @@ static int check_desc(const rk_lightgcn_desc &d)
     if (d.n_users <= 0 || d.n_items <= 0 || d.dim <= 0 || d.n_layers < 0) RK_FAIL(RK_EINVAL, "lightgcn: bad sizes");
     if (d.dim > 256) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 256 unsupported (long-row scratch slots are 256 floats)", d.dim);
     if (!d.rowptr || !d.col || !d.val || !d.wave_desc || d.n_blocks <= 0) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
+    if ((d.n_blocks & kSchedLongFlag) && !d.spmm_scratch) RK_FAIL(RK_EINVAL, "lightgcn: the schedule has long rows: desc.spmm_scratch is required");
     if (!d.user_emb || !d.item_emb || !d.m_user || !d.v_user || !d.m_item || !d.v_item)
         RK_FAIL(RK_EINVAL, "lightgcn: parameter/moment pointers missing");
     if (!d.buf_a || !d.buf_b || !d.light || !d.gprop || !d.gego || !d.state || !d.coef)
@@ -188,12 +213,7 @@ static SpmmArgs base_args(const rk_lightgcn_desc &d)
     a.n_rows = d.n_users + d.n_items;
     a.rowptr = d.rowptr; a.col = d.col; a.val = d.val; a.wave_desc = reinterpret_cast<const int4 *>(d.wave_desc); a.n_blocks = d.n_blocks;
     a.d = d.dim;
-    if (d.hot_H > 0 && d.col_tagged && d.val_hot && d.hot_rows && d.witems && d.long_rows && d.partials && d.hot_grid > 0) {
-        a.col_tagged = d.col_tagged; a.val_hot = d.val_hot; a.hot_rows = d.hot_rows;
-        a.witems = reinterpret_cast<const int4 *>(d.witems); a.long_rows = reinterpret_cast<const int4 *>(d.long_rows);
-        a.partials = d.partials;
-        a.hot_H = d.hot_H; a.max_items = d.max_items; a.n_long = d.n_long; a.two_classes = d.two_classes; a.hot_grid = d.hot_grid;
-    }
+    a.scratch = d.spmm_scratch;
     return a;
 }
 
@@ -266,7 +286,13 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
         e.state = d.state;
         e.bump = bump;
     };
-    if (L == 0) RK_FAIL(RK_EINVAL, "lightgcn: n_layers == 0 training is not supported by the fused path");
+    if (L == 0) {
+        const long long n = (long long)N * d.dim;
+        hipLaunchKernelGGL(adam_l0_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, n, d.user_emb, d.gego,
+                           d.gprop, d.m_user, d.v_user, d.coef + 2 * k, d.beta1, d.beta2, d.eps, apply_update, d.grad, d.state, bump);
+        RK_CHECK_LAUNCH();
+        return RK_OK;
+    }
     for (int j = 1; j <= L; ++j) {
         SpmmArgs a = base_args(d);
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
@@ -415,8 +441,8 @@ __global__ void set_coef_kernel(float *coef, float step_size, float bc2s)
 }
 
 RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                             const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x, int64_t x_rows,
-                             const rk_spmm_epilogue *epi, void *stream)
+                             const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
+                             int64_t x_rows, const rk_spmm_epilogue *epi, void *stream)
 {
     if (n_rows <= 0 || dim <= 0 || dim > 256 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !epi)
         RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: bad arguments");
@@ -426,6 +452,8 @@ RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_
     memset(&a, 0, sizeof(a));
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val;
     a.wave_desc = reinterpret_cast<const int4 *>(wave_desc); a.n_blocks = n_blocks; a.d = dim; a.x = x;
+    if ((n_blocks & kSchedLongFlag) && !scratch) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: this schedule has long rows and needs its scratch block");
+    a.scratch = scratch;
     a.e.add = epi->add; a.e.y = epi->y; a.e.sum_in = epi->sum_in; a.e.sum_out = epi->sum_out; a.e.sum_scale = epi->sum_scale;
     a.e.zero1 = epi->zero1; a.e.zero2 = epi->zero2;
     if (epi->sum_out && !epi->sum_in) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: sum_out needs sum_in");

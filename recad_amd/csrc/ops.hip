@@ -66,16 +66,15 @@ struct rk_schedule {
     std::vector<int32_t> bmeta;  // int4 per workgroup: {n_pieces, piece index, first slot, counter index}; zeros = whole rows
     std::vector<int32_t> packed; // int4 per packed short row: {row, e_begin, e_end, 0}
     int32_t n_blocks = 0, n_long = 0, n_slots = 0, dim = 0;
-    size_t words() const
-    {
-        return desc.size() + 4 + bmeta.size() + packed.size() + (size_t)((n_long + 3) & ~3) + (size_t)n_slots * (size_t)dim;
-    }
+    size_t words() const { return desc.size() + 4 + bmeta.size() + packed.size(); }
+    // per-stream scratch of the long rows: arrival counters (padded to 16 bytes) + partial-sum slots
+    size_t scratch_words() const { return n_long ? (size_t)((n_long + 3) & ~3) + (size_t)n_slots * (size_t)dim : 0; }
 };
 
 RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim, void *stream,
-                                    rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words)
+                                    rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words)
 {
-    if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || class_split < 0 || class_split > n_rows || dim <= 0 || dim > 256)
+    if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || !scratch_words || class_split < 0 || class_split > n_rows || dim <= 0 || dim > 256)
         RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: bad arguments");
     // short rows are packed one per lane group (dim/4 lanes): only the vector kernels with >= 2 groups do that
     static const int no_pack = getenv("RK_SPMM_NO_PACK") ? atoi(getenv("RK_SPMM_NO_PACK")) : 0;  // tuning only
@@ -226,8 +225,10 @@ RK_EXPORT int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32
     sc->n_blocks = (int32_t)(d.size() / bw);
     sc->n_long = n_long; sc->n_slots = n_slots; sc->dim = dim;
     *out = sc;
-    *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag) | sched_waves_code(kSpmmWaves);  // opaque launch parameter
+    *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag) | sched_waves_code(kSpmmWaves) |
+                (n_long ? kSchedLongFlag : 0);  // opaque launch parameter
     *n_words = (int64_t)sc->words();
+    *scratch_words = (int64_t)sc->scratch_words();
     return RK_OK;
 }
 
@@ -235,13 +236,12 @@ RK_EXPORT int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, vo
 {
     if (!sched || !wave_desc) RK_FAIL(RK_EINVAL, "rk_csr_schedule_upload: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    // layout: [wave descriptors][header {n_long, n_slots, dim, n_packed}][workgroup metas][packed rows][counters][partial slots]
+    // layout: [wave descriptors][header {n_long, n_slots, dim, n_packed}][workgroup metas][packed rows]  (read-only)
     std::vector<int32_t> head(sched->desc);
     const int32_t hdr[4] = {sched->n_long, sched->n_slots, sched->dim, (int32_t)(sched->packed.size() / 4)};
     head.insert(head.end(), hdr, hdr + 4);
     head.insert(head.end(), sched->bmeta.begin(), sched->bmeta.end());
     head.insert(head.end(), sched->packed.begin(), sched->packed.end());
-    head.resize(head.size() + (size_t)((sched->n_long + 3) & ~3), 0);  // arrival counters start at zero
     RK_HIP(hipMemcpyAsync(wave_desc, head.data(), sizeof(int32_t) * head.size(), hipMemcpyHostToDevice, s));
     RK_HIP(hipStreamSynchronize(s));
     return RK_OK;
@@ -250,153 +250,6 @@ RK_EXPORT int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, vo
 RK_EXPORT int rk_csr_schedule_destroy(rk_schedule_t sched)
 {
     delete sched;
-    return RK_OK;
-}
-
-// ---- tables for the persistent LDS hot-row SpMM (spmm_csr_hot_kernel), host-built per (graph, dim)
-struct rk_hot {
-    std::vector<int32_t> tagged, hot, witems, long_rows;
-    std::vector<float> val;
-};
-
-RK_EXPORT int rk_spmm_hot_build(int32_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
-                                int32_t class_split, int32_t dim, void *stream, rk_hot_t *out, int32_t *meta)
-{
-    if (n_rows <= 0 || nnz < 0 || !rowptr || !col || !val || dim <= 0 || !out || !meta) RK_FAIL(RK_EINVAL, "rk_spmm_hot_build: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    RK_HIP(hipGetDevice(&dev));
-    RK_HIP(hipGetDeviceProperties(&prop, dev));
-    const int grid = std::max(8, (prop.multiProcessorCount / 8) * 8);
-    const int H = hot_rows_for_dim(dim);
-    std::vector<int32_t> rp((size_t)n_rows + 1), c((size_t)nnz);
-    RK_HIP(hipMemcpyAsync(rp.data(), rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, s));
-    std::vector<float> v((size_t)nnz);
-    if (nnz) RK_HIP(hipMemcpyAsync(c.data(), col, sizeof(int32_t) * c.size(), hipMemcpyDeviceToHost, s));
-    if (nnz) RK_HIP(hipMemcpyAsync(v.data(), val, sizeof(float) * v.size(), hipMemcpyDeviceToHost, s));
-    RK_HIP(hipStreamSynchronize(s));
-    const bool two = class_split > 0 && class_split < n_rows;
-    auto cls_of = [&](int r) { return (two && r >= class_split) ? 1 : 0; };
-    rk_hot *h = new rk_hot();
-    // hot set per row class = the most frequently gathered columns of that class's rows
-    std::vector<int32_t> freq[2] = {std::vector<int32_t>((size_t)n_rows, 0), std::vector<int32_t>(two ? (size_t)n_rows : 0, 0)};
-    for (int32_t r = 0; r < n_rows; ++r) {
-        std::vector<int32_t> &f = freq[cls_of(r)];
-        for (int32_t e = rp[r]; e < rp[r + 1]; ++e) f[(size_t)c[e]]++;
-    }
-    h->hot.assign((size_t)2 * H, -1);
-    std::vector<int32_t> slot[2];
-    long long hot_nnz = 0;
-    for (int k = 0; k < (two ? 2 : 1); ++k) {
-        std::vector<int32_t> ids;
-        for (int32_t n = 0; n < n_rows; ++n)
-            if (freq[k][(size_t)n] > 1) ids.push_back(n);  // a row gathered once gains nothing from LDS
-        const size_t take = std::min(ids.size(), (size_t)H);
-        std::partial_sort(ids.begin(), ids.begin() + (long)take, ids.end(), [&](int32_t x, int32_t y) {
-            return freq[k][(size_t)x] != freq[k][(size_t)y] ? freq[k][(size_t)x] > freq[k][(size_t)y] : x < y;
-        });
-        slot[k].assign((size_t)n_rows, -1);
-        for (size_t q = 0; q < take; ++q) {
-            h->hot[(size_t)k * H + q] = ids[q];
-            slot[k][(size_t)ids[q]] = (int32_t)q;
-            hot_nnz += freq[k][(size_t)ids[q]];
-        }
-    }
-    if (!two) for (int q = 0; q < H; ++q) h->hot[(size_t)H + q] = h->hot[(size_t)q];
-    // work items: whole rows (<= kPieceNnz nonzeros) or pieces of long rows; inside an item the
-    // entries are reordered cold-first (node ids), then hot (LDS slots), each group in column order
-    h->tagged.resize((size_t)nnz);
-    h->val.resize((size_t)nnz);
-    struct Item { int32_t row, eb, ee, flag, nnz; };
-    std::vector<Item> items[2];
-    int32_t n_pieces = 0;
-    auto emit = [&](int32_t r, int32_t pb, int32_t pe, int32_t piece) {
-        const std::vector<int32_t> &sl = slot[cls_of(r)];
-        int32_t w = pb;
-        for (int32_t e = pb; e < pe; ++e)
-            if (sl[(size_t)c[e]] < 0) { h->tagged[(size_t)w] = c[e]; h->val[(size_t)w] = v[e]; ++w; }
-        const int32_t n_cold = w - pb;
-        for (int32_t e = pb; e < pe; ++e)
-            if (sl[(size_t)c[e]] >= 0) { h->tagged[(size_t)w] = sl[(size_t)c[e]]; h->val[(size_t)w] = v[e]; ++w; }
-        items[cls_of(r)].push_back({r, pb, pe, (piece << 9) | n_cold, pe - pb});
-    };
-    for (int32_t r = 0; r < n_rows; ++r) {
-        const int32_t b = rp[r], e = rp[r + 1], nz = e - b;
-        if (nz <= kPieceNnz) { emit(r, b, e, 0); continue; }
-        const int32_t np = (nz + kPieceNnz - 1) / kPieceNnz;
-        h->long_rows.insert(h->long_rows.end(), {r, n_pieces, np, 0});
-        for (int32_t p = 0; p < np; ++p) {
-            const int32_t pb = b + p * kPieceNnz;
-            emit(r, pb, std::min(e, pb + kPieceNnz), 1 + n_pieces);
-            ++n_pieces;
-        }
-    }
-    const int n_waves = grid * kHotWaves;
-    std::vector<std::vector<Item>> lists((size_t)n_waves);
-    for (int k = 0; k < 2; ++k) {
-        // waves of the workgroups of class k (blockIdx % 8 < 4 -> class 0 when two classes)
-        std::vector<int> waves;
-        for (int b = 0; b < grid; ++b) {
-            const int bc = two ? ((b & 7) >= 4) : 0;
-            if (bc != k) continue;
-            for (int w = 0; w < kHotWaves; ++w) waves.push_back(b * kHotWaves + w);
-        }
-        if (waves.empty() || items[k].empty()) continue;
-        std::stable_sort(items[k].begin(), items[k].end(), [](const Item &x, const Item &y) { return x.nnz > y.nnz; });
-        // longest-processing-time first on (load, wave) min-heap; +16 per item models the fixed per-item cost
-        std::vector<std::pair<long long, int>> heap;
-        for (int wv : waves) heap.push_back({0LL, wv});
-        auto cmp = [](const std::pair<long long, int> &x, const std::pair<long long, int> &y) { return x > y; };
-        std::make_heap(heap.begin(), heap.end(), cmp);
-        for (const Item &it : items[k]) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            std::pair<long long, int> &top = heap.back();
-            lists[(size_t)top.second].push_back(it);
-            top.first += it.nnz + 16;
-            std::push_heap(heap.begin(), heap.end(), cmp);
-        }
-    }
-    size_t max_items = 1;
-    for (const auto &l : lists) max_items = std::max(max_items, l.size());
-    h->witems.assign((size_t)n_waves * max_items * 4, 0);
-    for (int wv = 0; wv < n_waves; ++wv)
-        for (size_t k = 0; k < max_items; ++k) {
-            int32_t *d = &h->witems[((size_t)wv * max_items + k) * 4];
-            if (k < lists[(size_t)wv].size()) {
-                const Item &it = lists[(size_t)wv][k];
-                d[0] = it.row; d[1] = it.eb; d[2] = it.ee; d[3] = it.flag;
-            } else d[0] = -1;
-        }
-    *out = h;
-    meta[0] = H;
-    meta[1] = (int32_t)max_items;
-    meta[2] = (int32_t)(h->long_rows.size() / 4);
-    meta[3] = two ? 1 : 0;
-    meta[4] = n_pieces;
-    meta[5] = grid;
-    meta[6] = nnz ? (int32_t)(1000 * hot_nnz / nnz) : 0;  // permille of nonzeros served from LDS
-    meta[7] = 0;
-    return RK_OK;
-}
-
-RK_EXPORT int rk_spmm_hot_upload(rk_hot_t h, int32_t *col_tagged, float *val_hot, int32_t *hot_rows, int32_t *witems, int32_t *long_rows,
-                                 void *stream)
-{
-    if (!h || !col_tagged || !val_hot || !hot_rows || !witems || !long_rows) RK_FAIL(RK_EINVAL, "rk_spmm_hot_upload: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    if (!h->tagged.empty()) RK_HIP(hipMemcpyAsync(col_tagged, h->tagged.data(), sizeof(int32_t) * h->tagged.size(), hipMemcpyHostToDevice, s));
-    if (!h->val.empty()) RK_HIP(hipMemcpyAsync(val_hot, h->val.data(), sizeof(float) * h->val.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipMemcpyAsync(hot_rows, h->hot.data(), sizeof(int32_t) * h->hot.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipMemcpyAsync(witems, h->witems.data(), sizeof(int32_t) * h->witems.size(), hipMemcpyHostToDevice, s));
-    if (!h->long_rows.empty()) RK_HIP(hipMemcpyAsync(long_rows, h->long_rows.data(), sizeof(int32_t) * h->long_rows.size(), hipMemcpyHostToDevice, s));
-    RK_HIP(hipStreamSynchronize(s));
-    return RK_OK;
-}
-
-RK_EXPORT int rk_spmm_hot_destroy(rk_hot_t h)
-{
-    delete h;
     return RK_OK;
 }
 
@@ -553,7 +406,7 @@ RK_EXPORT int rk_pair_scores(int32_t dim, const float *utab, const float *itab, 
 }
 
 RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
-                          const int32_t *wave_desc, int32_t n_blocks, int32_t dim, const float *x,
+                          const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
                           const float *add, float *y, void *stream)
 {
     if (n_rows <= 0 || dim <= 0 || dim > 256 || !rowptr || !col || !val || !wave_desc || n_blocks <= 0 || !x || !y)
@@ -562,6 +415,8 @@ RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *
     memset(&a, 0, sizeof(a));
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.wave_desc = reinterpret_cast<const int4 *>(wave_desc); a.n_blocks = n_blocks; a.d = dim;
     if ((size_t)n_rows * dim * sizeof(float) >= (1ULL << 32)) RK_FAIL(RK_EINVAL, "rk_spmm_csr: n_rows*dim*4 must be < 4 GiB");
+    if ((n_blocks & kSchedLongFlag) && !scratch) RK_FAIL(RK_EINVAL, "rk_spmm_csr: this schedule has long rows and needs its scratch block");
+    a.scratch = scratch;
     a.x = x;
     a.e.add = add;
     a.e.y = y;

@@ -18,6 +18,15 @@ __device__ __forceinline__ int lower_bound(const int *__restrict__ a, int lo, in
     return lo;
 }
 
+// r-th (0-based) item NOT in the sorted list idx[b, e): exact, O(log deg).  idx[b+k] - k is the number of free
+// items below positive k and is non-decreasing in k, so j = #{k : idx[b+k] - k <= r} positives precede the answer.
+__device__ __forceinline__ int rth_free_item(const int *__restrict__ idx, int b, int e, int r)
+{
+    int lo = 0, hi = e - b;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[b + mid] - mid <= r) lo = mid + 1; else hi = mid; }
+    return r + lo;
+}
+
 // pairwise_sample (implicit.py:50-74): uniform user with replacement, skipped when the user has no
 // positives (valid=0), uniform positive, negative rejection-sampled outside the positives.
 __global__ void bpr_sample_kernel(int n_users, int n_items, const int *__restrict__ ptr, const int *__restrict__ idx,
@@ -39,12 +48,7 @@ __global__ void bpr_sample_kernel(int n_users, int n_items, const int *__restric
         }
         if (!ok) {  // dense user: pick the r-th free item directly
             const int r = (int)bounded(rnd(seed, (unsigned long long)t, 66), (unsigned)(n_items - deg));
-            ng = r;
-            for (int it = 0; it < 64; ++it) {
-                const int c = lower_bound(idx, b, e, ng + 1) - b;  // positives <= ng
-                if (r + c == ng) break;
-                ng = r + c;
-            }
+            ng = rth_free_item(idx, b, e, r);
         }
         neg[t] = ng;
         valid[t] = 1;
@@ -87,12 +91,7 @@ __global__ void pointwise_sample_kernel(int n_users, int n_items, const int *__r
         int ng = 0;
         if (free_items > 0) {
             const int r = (int)bounded(rnd(seed, (unsigned long long)t, 0), (unsigned)free_items);
-            ng = r;
-            for (int it = 0; it < 64; ++it) {
-                const int c = lower_bound(idx, b, en, ng + 1) - b;
-                if (r + c == ng) break;
-                ng = r + c;
-            }
+            ng = rth_free_item(idx, b, en, r);
         }
         items[t] = ng;
         labels[t] = 0;

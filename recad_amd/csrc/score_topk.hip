@@ -165,6 +165,9 @@ __global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ 
         if (seen_first >= 0) lds_keys[seen_first] = 0u;
         for (int k = seen_b + NT + tid; k < seen_e; k += NT) lds_keys[seen_idx[k]] = 0u;
     } else {
+        // every thread's reads of the target scores (above) must have completed before any thread overwrites a
+        // seen item in place: a target may itself be in the user's seen list (full_catalog_topk takes any users)
+        __syncthreads();
         if (seen_first >= 0) grow[seen_first] = -INFINITY;
         for (int k = seen_b + NT + tid; k < seen_e; k += NT) grow[seen_idx[k]] = -INFINITY;
         __threadfence_block();

@@ -44,14 +44,10 @@ struct SpmmArgs {
     int d;
     const float *x;  // [n_rows, d] row-major; n_rows*d*4 < 4 GiB (32-bit byte offsets)
     int dbg;
-    // LDS hot-row variant (spmm_csr_hot_kernel); hot_H == 0 disables it
-    const int *col_tagged;  // per item: cold entries (node ids) first, then hot entries (LDS slots of the row's class)
-    const float *val_hot;   // values in the same (reordered) order
-    const int *hot_rows;    // [2][hot_H] node ids staged in LDS by class-0 / class-1 workgroups
-    const int4 *witems;     // [n_cu*16 waves][max_items] {row, e_begin, e_end, 0 | 1 + piece slot}; row -1 ends a list
-    const int4 *long_rows;  // [n_long] {row, first piece slot, n pieces, 0}
-    float *partials;        // [n_pieces][d] scratch
-    int hot_H, max_items, n_long, two_classes, hot_grid;
+    // long rows (> waves-per-workgroup segments): arrival counters int[n_long] (zero between launches: the last
+    // arriver resets its counter) followed, 16-byte aligned, by the partial-sum slots float[n_slots][d].
+    // Caller-owned and PER STREAM: two SpMMs in flight on the same schedule need two scratch blocks.
+    int *scratch;
     // Batch sparsity of a train step (bitmap over node rows, bit r = row r is a user/pos/neg row of
     // this step's minibatch): the last forward layer only needs those rows of `light`.  (Skipping
     // the gathers of all-zero gradient rows in the first backward layer was measured too: the
@@ -125,8 +121,9 @@ inline int spmm_waves_for(long long nnz)
 }
 
 // bit 30 of the opaque `n_blocks` launch parameter: the schedule contains packed short-row waves;
-// bits 28-29: waves per workgroup (0 = 8, 1 = 4, 2 = 16)
+// bits 28-29: waves per workgroup (0 = 8, 1 = 4, 2 = 16); bit 27: long rows present
 static constexpr int kSchedPackedFlag = 1 << 30;
+static constexpr int kSchedLongFlag = 1 << 27;  // the schedule has long rows: SpmmArgs::scratch is required
 static constexpr int kSchedWavesShift = 28, kSchedWavesMask = 3 << 28;
 inline int sched_waves_code(int waves) { return (waves == 4 ? 1 : waves == 16 ? 2 : 0) << kSchedWavesShift; }
 inline int sched_waves(int n_blocks_param) { const int c = (n_blocks_param & kSchedWavesMask) >> kSchedWavesShift; return c == 1 ? 4 : c == 2 ? 16 : 8; }
@@ -138,6 +135,15 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc)
     return acc;
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// RK_NT_STREAMS (tuning build): the once-read col / val streams bypass the cache hierarchy's retention
+#ifdef RK_NT_STREAMS
+__device__ __forceinline__ int ld_col(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ld_val(const float *p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ int ld_col(const int *p) { return *p; }
+__device__ __forceinline__ float ld_val(const float *p) { return *p; }
+#endif
 
 template <int D, int UN>
 __device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n, int t0, const float *__restrict__ x,
@@ -175,13 +181,13 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_next = 0;
     float a_next = 0.f;
-    if (eb + lane < ee) { c_next = col[eb + lane]; a_next = DROP ? drop_val(dc, eb + lane, val[eb + lane]) : val[eb + lane]; }
+    if (eb + lane < ee) { c_next = ld_col(col + eb + lane); a_next = DROP ? drop_val(dc, eb + lane, val[eb + lane]) : ld_val(val + eb + lane); }
     for (int base = eb; base < ee; base += 64) {
         const int n = min(64, ee - base);
         const int c = c_next;
         const float a = a_next;
         c_next = 0; a_next = 0.f;
-        if (base + 64 + lane < ee) { c_next = col[base + 64 + lane]; a_next = DROP ? drop_val(dc, base + 64 + lane, val[base + 64 + lane]) : val[base + 64 + lane]; }
+        if (base + 64 + lane < ee) { c_next = ld_col(col + base + 64 + lane); a_next = DROP ? drop_val(dc, base + 64 + lane, val[base + 64 + lane]) : ld_val(val + base + 64 + lane); }
         const int iters = (n + NG - 1) / NG;
         int t = 0;
         for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
@@ -195,30 +201,6 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
         acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
         acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
     }
-    return acc;
-}
-
-// ---- LDS hot-row variant: tagged columns (bit 31) are served from the workgroup's LDS copy of the
-// hottest X rows ("LDS staging of embedding tiles"), everything else is gathered from L2 as above.
-// LDS-only gather round for the hot part of an item (col holds LDS slots there)
-template <int D, int UN>
-__device__ __forceinline__ float4 gather_round_lds(float4 acc, int c, float a, int n, int t0, const float *hot, int grp, int sub)
-{
-    constexpr int NG = 64 / (D / 4);
-    float4 xv[UN];
-    float av[UN];
-#pragma unroll
-    for (int j = 0; j < UN; ++j) {
-        const int src = (t0 + j) * NG + grp;
-        int cc = __shfl(c, src & 63, 64);
-        float aa = __shfl(a, src & 63, 64);
-        const bool ok = src < n;
-        cc = ok ? cc : 0;
-        av[j] = ok ? aa : 0.f;
-        xv[j] = *reinterpret_cast<const float4 *>(hot + (unsigned)(cc * D + sub * 4));
-    }
-#pragma unroll
-    for (int j = 0; j < UN; ++j) acc = f4_fma(av[j], xv[j], acc);
     return acc;
 }
 
@@ -263,16 +245,15 @@ struct PieceRef {
     int stride;
 };
 
-__device__ __forceinline__ PieceRef piece_ref(const int4 *wave_desc, int n_blocks, int waves, int block)
+__device__ __forceinline__ PieceRef piece_ref(const int4 *wave_desc, int n_blocks, int waves, int block, int *scratch)
 {
     const int4 *hdr = wave_desc + (size_t)n_blocks * waves;  // {n_long, n_slots, dim, n_packed}
     PieceRef p;
     p.meta = hdr[1 + block];
     const int4 h = hdr[0];
     p.packed = hdr + 1 + n_blocks;
-    int *cnt = reinterpret_cast<int *>(const_cast<int4 *>(hdr + 1 + n_blocks + h.w));
-    p.counters = cnt;
-    p.partials = reinterpret_cast<float *>(cnt + ((h.x + 3) & ~3));
+    p.counters = scratch;
+    p.partials = reinterpret_cast<float *>(scratch + ((h.x + 3) & ~3));
     p.stride = h.z;
     return p;
 }
@@ -344,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     DropCtx dc{};
     if (DROP) dc = drop_ctx(a);
     int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
-    const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x);  // scalar loads, in flight under the gather
+    const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x, a.scratch);  // scalar loads, in flight under the gather
     if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PACKED && ds.w < 0) {
@@ -404,148 +385,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     }
 }
 
-// Persistent, barrier-free form ("LDS staging of embedding tiles"): one 16-wave workgroup per CU
-// stages the hot X rows of its row class in LDS once (the only barrier), then every wave walks its
-// OWN list of work items (a whole row, or a <= 256-nonzero piece of a long row) that the host
-// balanced by nonzeros.  Inside a wave the next item's descriptor, first column/value chunk and
-// epilogue operands are loaded while the current item's gathers are in flight, so the wave's
-// memory stream never drains.  Pieces of long rows store partial sums; spmm_long_combine_kernel
-// (second, tiny launch) adds them in fixed order and runs the row's epilogue.
-static constexpr int kHotWaves = 16;
-static constexpr int kHotLdsBytes = 128 * 1024;
-static constexpr int kPieceNnz = 256;
-__host__ __device__ inline int hot_rows_for_dim(int d) { return kHotLdsBytes / (4 * d); }
-
-template <int D>
-__global__ __launch_bounds__(kHotWaves * 64, 4) void spmm_csr_hot_kernel(const SpmmArgs a)
-{
-    constexpr int G = D / 4, NG = 64 / G;
-    extern __shared__ __attribute__((aligned(16))) float hot[];  // [hot_H][D]
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = lane / G, sub = lane % G;
-    if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.e.state[ST_STEP_BASE] += a.e.bump;
-        a.e.state[ST_ADAM_T] += a.e.bump;
-    }
-    // class of this workgroup: XCD halves (blockIdx % 8 < 4 -> class 0), as the host assumed
-    const int cls = a.two_classes ? ((blockIdx.x & 7) >= 4) : 0;
-    if (!(a.dbg & 16)) {
-        // hot_H / (16 waves * NG rows per wave step) == 8 for every D: issue all 8 index loads, then
-        // all 8 row loads, then the LDS writes -- one latency, not eight
-        const int *hr = a.hot_rows + (size_t)cls * a.hot_H;
-        int rid[8];
-        float4 rv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int h = q * kHotWaves * NG + w * NG + grp;
-            rid[q] = h < a.hot_H ? hr[h] : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rid[q] >= 0) rv[q] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(rid[q] * D + sub * 4));
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int h = q * kHotWaves * NG + w * NG + grp;
-            if (h < a.hot_H) *reinterpret_cast<float4 *>(hot + (size_t)h * D + sub * 4) = rv[q];
-        }
-    }
-    __syncthreads();
-    const int4 *items = a.witems + ((size_t)blockIdx.x * kHotWaves + w) * a.max_items;
-    // item = {row, e_begin, e_end, (piece slot + 1) << 9 | n_cold}: nonzeros [e_begin, e_begin + n_cold)
-    // are gathered from global memory, the rest of the item from the LDS copy (the host reordered
-    // every item cold-first in col_tagged / val_hot).  Pipeline registers hold the NEXT item.
-    int4 nd = items[0];
-    int nc = 0;
-    float na = 0.f;
-    float4 naddv = make_float4(0.f, 0.f, 0.f, 0.f), nsumv = naddv;
-    auto prefetch = [&](const int4 &d) {
-        nc = 0; na = 0.f;
-        if (d.x >= 0) {
-            if (d.y + lane < d.z) { nc = a.col_tagged[d.y + lane]; na = a.val_hot[d.y + lane]; }
-            if ((d.w >> 9) == 0 && lane < G) {  // whole row: epilogue operands
-                const size_t eoff = (size_t)d.x * D + (size_t)sub * 4;
-                if (a.e.add) naddv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
-                if (a.e.sum_out) nsumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
-            }
-        }
-    };
-    if (!(a.dbg & 32)) prefetch(nd);
-    for (int k = 0; k < a.max_items; ++k) {
-        const int4 ds = nd;
-        if (ds.x < 0 || (a.dbg & 32)) break;
-        const int c0 = nc;
-        const float a0 = na;
-        const float4 addv = naddv, sumv = nsumv;
-        nd = (k + 1 < a.max_items) ? items[k + 1] : make_int4(-1, 0, 0, 0);
-        prefetch(nd);
-        const int em = ds.y + (ds.w & 511), piece = ds.w >> 9;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // (c0, a0) hold entries [ds.y, ds.y + 64) of the item, cold and hot alike
-        for (int base = ds.y; base < ds.z; base += 64) {
-            int c = c0;
-            float av = a0;
-            if (base != ds.y) {
-                c = 0; av = 0.f;
-                if (base + lane < ds.z) { c = a.col_tagged[base + lane]; av = a.val_hot[base + lane]; }
-            }
-            // cold entries of this chunk: [base, min(base+64, em)); hot: the rest up to ds.z
-            const int n_all = min(64, ds.z - base);
-            const int n_cold = max(0, min(64, em - base));
-            if (n_cold > 0) {
-                const int iters = (n_cold + NG - 1) / NG;
-                int t = 0;
-                for (; t + 8 <= iters; t += 8) acc = gather_round<D, 8>(acc, c, av, n_cold, t, a.x, grp, sub);
-                const int rem = iters - t;
-                if (rem > 4) acc = gather_round<D, 8>(acc, c, av, n_cold, t, a.x, grp, sub);
-                else if (rem > 0) acc = gather_round<D, 4>(acc, c, av, n_cold, t, a.x, grp, sub);
-            }
-            if (n_all > n_cold) {
-                // hot entries sit at chunk positions [n_cold, n_all): rotate so they start at lane 0
-                const int hc = __shfl(c, (lane + n_cold) & 63, 64);
-                const float ha = __shfl(av, (lane + n_cold) & 63, 64);
-                const int n_hot = n_all - n_cold;
-                const int iters = (n_hot + NG - 1) / NG;
-                int t = 0;
-                for (; t + 8 <= iters; t += 8) acc = gather_round_lds<D, 8>(acc, hc, ha, n_hot, t, hot, grp, sub);
-                const int rem = iters - t;
-                if (rem > 4) acc = gather_round_lds<D, 8>(acc, hc, ha, n_hot, t, hot, grp, sub);
-                else if (rem > 0) acc = gather_round_lds<D, 4>(acc, hc, ha, n_hot, t, hot, grp, sub);
-            }
-        }
-#pragma unroll
-        for (int o = G; o < 64; o <<= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-        }
-        if (lane < G) {
-            if (piece == 0) spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
-            else *reinterpret_cast<float4 *>(a.partials + (size_t)(piece - 1) * D + (size_t)sub * 4) = acc;
-        }
-    }
-}
-
-// long rows: one wave per row adds the pieces' partial sums in piece order, then the epilogue
-template <int D>
-__global__ __launch_bounds__(256) void spmm_long_combine_kernel(const SpmmArgs a)
-{
-    constexpr int G = D / 4;
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.n_long || lane >= G) return;
-    const int4 lr = a.long_rows[i];  // {row, first piece slot, n pieces, -}
-    const size_t eoff = (size_t)lr.x * D + (size_t)lane * 4;
-    float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
-    if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
-    if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
-    float4 acc = *reinterpret_cast<const float4 *>(a.partials + (size_t)lr.y * D + (size_t)lane * 4);
-    for (int p = 1; p < lr.z; ++p) acc = f4_add(acc, *reinterpret_cast<const float4 *>(a.partials + (size_t)(lr.y + p) * D + (size_t)lane * 4));
-    SpmmEpi e = a.e;
-    e.bump = 0;
-    spmm_epilogue<D>(e, lr.x, lane, acc, addv, sumv);
-}
-
 // Any d (<= 512): one X row per wave step, lanes stride over the row.  Same schedule and
 // epilogue semantics; used for dims without a vector instantiation.
 static constexpr int kGenMaxC = 8;
@@ -580,7 +419,7 @@ static __global__ __launch_bounds__(1024) void spmm_csr_generic_kernel(const Spm
     for (int k = 0; k < kGenMaxC; ++k)
         for (int ww = 1; ww < ds.w; ++ww) acc[k] += part[w + ww][k * 64 + lane];
     {
-        const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, kSpmmWaves, blockIdx.x);
+        const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, kSpmmWaves, blockIdx.x, a.scratch);
         if (pr.meta.x > 0) {  // piece of a long row: same hand-off as the vector kernel, 4 bytes per lane and k
             float *slot = pr.partials + (size_t)(pr.meta.z + pr.meta.y) * pr.stride;
 #pragma unroll
@@ -631,38 +470,8 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     SpmmArgs a = a_in;
     const bool packed = (a.n_blocks & kSchedPackedFlag) != 0;
     const int W = sched_waves(a.n_blocks);
-    a.n_blocks &= ~(kSchedPackedFlag | kSchedWavesMask);
-    static const int hot_off = getenv("RK_SPMM_NO_HOT") ? atoi(getenv("RK_SPMM_NO_HOT")) : 0;
-    static const int dbg0 = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
-    a.dbg = dbg0;
-    const bool filtered = a.row_filter || a.mark_bits || a.clear_bits || a.drop_thresh24;  // segment kernel only
-    if (a.hot_H > 0 && !hot_off && !filtered && (a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            const int lim = 160 * 1024 - 256;
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_hot_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return hipErrorUnknown;
-            attr_set = true;
-        }
-        const size_t lds = (size_t)a.hot_H * a.d * 4;
-        const dim3 cg((a.n_long + 3) / 4);
-#define RK_HOT_CASE(D)                                                                                     \
-    {                                                                                                      \
-        hipLaunchKernelGGL(spmm_csr_hot_kernel<D>, dim3(a.hot_grid), dim3(kHotWaves * 64), lds, s, a);     \
-        if (a.n_long > 0) hipLaunchKernelGGL(spmm_long_combine_kernel<D>, cg, dim3(256), 0, s, a);         \
-    }
-        switch (a.d) {
-            case 32: RK_HOT_CASE(32) break;
-            case 64: RK_HOT_CASE(64) break;
-            case 128: RK_HOT_CASE(128) break;
-            default: RK_HOT_CASE(256) break;
-        }
-#undef RK_HOT_CASE
-        return hipGetLastError();
-    }
+    if ((a.n_blocks & kSchedLongFlag) && !a.scratch) return hipErrorInvalidValue;  // long rows need their scratch block
+    a.n_blocks &= ~(kSchedPackedFlag | kSchedWavesMask | kSchedLongFlag);
     const dim3 grid(a.n_blocks), block(W * 64);
     static const int variant = getenv("RK_SPMM_VARIANT") ? atoi(getenv("RK_SPMM_VARIANT")) : 0;
     static const int dbg = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;

@@ -280,16 +280,13 @@ class ImplicitData:
         # k-th free item of user u: draw a rank in the complement and skip over the sorted positives
         free = (self.n_items - deg)[nu]
         r = (rng.random(len(nu)) * free).astype(np.int64)
-        ni = r.copy()
-        # item = r + #positives <= item ; fixed point by iterating (positives sorted per user)
-        keys = pu * self.n_items + pi
-        base = ptr[nu]
-        for _ in range(64):
-            cnt = np.searchsorted(keys, nu * self.n_items + ni, side="right") - base
-            new = r + cnt
-            if np.array_equal(new, ni):
-                break
-            ni = new
+        # r-th free item of user u, exactly: idx[k] - k (k = position inside the user's sorted list) is the number
+        # of free items below positive k and is non-decreasing, so j = #{k : idx[k] - k <= r} positives precede
+        # the answer and the item is r + j (one vectorised binary search over per-user keys).
+        k_in_row = np.arange(len(idx), dtype=np.int64) - np.repeat(ptr[:-1], deg)
+        free_below = pu * self.n_items + (pi - k_in_row)          # sorted: user-major, non-decreasing inside a user
+        j = np.searchsorted(free_below, nu * self.n_items + r, side="right") - ptr[nu]
+        ni = r + j
         users = np.concatenate([pu, nu])
         items = np.concatenate([pi, ni])
         labels = np.concatenate([np.ones(len(pu), dtype=np.int64), np.zeros(len(nu), dtype=np.int64)])

@@ -7,20 +7,29 @@ from . import _lib
 
 
 class CsrGraph:
-    """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the
-    per-wave work schedule rk_spmm_csr uses.  Immutable after construction."""
+    """rowptr int32[N+1], col int32[nnz], val fp32[nnz] on one HIP device, plus the per-wave work schedule
+    rk_spmm_csr uses.  Immutable after construction, cached schedules included: everything here is read-only
+    on the device and may be shared by any number of models, handles and streams.  The mutable part of an
+    SpMM (arrival counters and partial-sum slots of rows longer than a workgroup) lives in a scratch block
+    that every user allocates for itself with new_scratch()."""
 
     def __init__(self, n_rows, rowptr, col, val, class_split=0):
         self.n_rows, self.rowptr, self.col, self.val = n_rows, rowptr, col, val
         self.class_split = class_split
-        self._hot = {}
         self._sched = {}
 
     def schedule(self, dim):
-        """(wave_desc int32 device tensor, n_blocks) of the SpMM work schedule for this dim (cached)."""
+        """(wave_desc int32 device tensor, n_blocks) of the SpMM work schedule for this dim (cached, read-only)."""
         if dim not in self._sched:
             self._sched[dim] = self._schedule(self.n_rows, self.rowptr, self.class_split, dim)
-        return self._sched[dim]
+        return self._sched[dim][:2]
+
+    def new_scratch(self, dim):
+        """A fresh, zero-filled scratch block for SpMMs of this dim on ONE stream (None when the graph has no
+        row longer than a workgroup).  One per handle / per concurrent stream; never cached here."""
+        self.schedule(dim)
+        words = self._sched[dim][2]
+        return torch.zeros(words, device=self.device, dtype=torch.int32) if words else None
 
     def transpose_index(self):
         """tpos[e] = position of the transposed entry (col[e], row(e)) in this CSR (int32 device tensor, cached).
@@ -33,29 +42,6 @@ class CsrGraph:
             key = self.col.long() * self.n_rows + rows
             self._tpos = torch.argsort(key).to(torch.int32).contiguous()
         return self._tpos
-
-    def hot_tables(self, dim, min_permille=150):
-        """Tables of the persistent LDS hot-row SpMM (rk_spmm_hot_build/_upload), cached per dim.
-        None when too few nonzeros would be served from LDS to pay for the staging."""
-        if dim not in self._hot:
-            nnz = self.col.numel()
-            h, meta = C.c_void_p(), (C.c_int32 * 8)()
-            _lib.check(_lib.lib().rk_spmm_hot_build(self.n_rows, nnz, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val), self.class_split,
-                                                    dim, _lib.stream_ptr(), C.byref(h), meta), "rk_spmm_hot_build")
-            try:
-                H, max_items, n_long, two, n_pieces, grid, permille = (int(meta[k]) for k in range(7))
-                t = None
-                if permille >= min_permille:
-                    i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-                    t = {"col_tagged": i32(nnz), "val_hot": torch.empty(max(nnz, 1), device=self.device), "hot_rows": i32(2 * H), "witems": i32(grid * 16 * max_items * 4),
-                         "long_rows": i32(n_long * 4), "partials": torch.zeros(max(n_pieces, 1) * dim, device=self.device),
-                         "H": H, "max_items": max_items, "n_long": n_long, "two_classes": two, "grid": grid, "permille": permille}
-                    _lib.check(_lib.lib().rk_spmm_hot_upload(h, _lib.ptr(t["col_tagged"]), _lib.ptr(t["val_hot"]), _lib.ptr(t["hot_rows"]), _lib.ptr(t["witems"]),
-                                                             _lib.ptr(t["long_rows"]), _lib.stream_ptr()), "rk_spmm_hot_upload")
-                self._hot[dim] = t
-            finally:
-                _lib.lib().rk_spmm_hot_destroy(h)
-        return self._hot[dim]
 
     @property
     def nnz(self):
@@ -75,16 +61,15 @@ class CsrGraph:
 
     @staticmethod
     def _schedule(n_rows, rowptr, class_split, dim):
-        sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+        sched, n_blocks, n_words, s_words = C.c_void_p(), C.c_int32(0), C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().rk_csr_schedule_build(n_rows, _lib.ptr(rowptr), class_split, dim, _lib.stream_ptr(), C.byref(sched),
-                                                    C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
+                                                    C.byref(n_blocks), C.byref(n_words), C.byref(s_words)), "rk_csr_schedule_build")
         try:
-            # descriptors + workgroup metas + arrival counters + partial-sum slots of the long rows
-            desc = torch.zeros(int(n_words.value), device=rowptr.device, dtype=torch.int32)
+            desc = torch.zeros(int(n_words.value), device=rowptr.device, dtype=torch.int32)  # descriptors, metas, packed rows
             _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
         finally:
             _lib.lib().rk_csr_schedule_destroy(sched)
-        return desc, int(n_blocks.value)
+        return desc, int(n_blocks.value), int(s_words.value)
 
     @classmethod
     def from_torch_coo(cls, coo, device, class_split=0):
@@ -134,7 +119,8 @@ class CsrGraph:
         x = x.contiguous()
         y = torch.empty_like(x)
         wave_desc, n_blocks = self.schedule(x.shape[1])
+        scratch = self.new_scratch(x.shape[1])  # per call: concurrent calls on different streams stay independent
         _lib.check(_lib.lib().rk_spmm_csr(self.n_rows, _lib.ptr(self.rowptr), _lib.ptr(self.col), _lib.ptr(self.val),
-                                          _lib.ptr(wave_desc), n_blocks, x.shape[1], _lib.ptr(x),
+                                          _lib.ptr(wave_desc), n_blocks, _lib.ptr(scratch), x.shape[1], _lib.ptr(x),
                                           _lib.ptr(add), _lib.ptr(y), _lib.stream_ptr()), "rk_spmm_csr")
         return y

@@ -120,15 +120,16 @@ class HipOps:
     @staticmethod
     def _sched(slab, dim):
         if dim not in slab["sched"]:
-            sched, n_blocks, n_words = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+            sched, n_blocks, n_words, s_words = C.c_void_p(), C.c_int32(0), C.c_int64(0), C.c_int64(0)
             _lib.check(_lib.lib().rk_csr_schedule_build(slab["n_rows"], _lib.ptr(slab["rowptr"]), 0, dim, _lib.stream_ptr(), C.byref(sched),
-                                                        C.byref(n_blocks), C.byref(n_words)), "rk_csr_schedule_build")
+                                                        C.byref(n_blocks), C.byref(n_words), C.byref(s_words)), "rk_csr_schedule_build")
             try:
                 desc = torch.zeros(int(n_words.value), device=slab["rowptr"].device, dtype=torch.int32)
                 _lib.check(_lib.lib().rk_csr_schedule_upload(sched, _lib.ptr(desc), _lib.stream_ptr()), "rk_csr_schedule_upload")
             finally:
                 _lib.lib().rk_csr_schedule_destroy(sched)
-            slab["sched"][dim] = (desc, int(n_blocks.value))
+            scratch = torch.zeros(int(s_words.value), device=slab["rowptr"].device, dtype=torch.int32) if s_words.value else None
+            slab["sched"][dim] = (desc, int(n_blocks.value), scratch)   # the slab is this trainer's own: one stream
         return slab["sched"][dim]
 
     def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None):
@@ -140,9 +141,9 @@ class HipOps:
             e.adam_t, e.adam_p, e.adam_m, e.adam_v = adam["t"], _lib.ptr(adam["p"]), _lib.ptr(adam["m"]), _lib.ptr(adam["v"])
             e.coef_scratch = _lib.ptr(slab["coef"])
             e.lr, e.beta1, e.beta2, e.eps = adam["lr"], adam["b1"], adam["b2"], adam["eps"]
-        desc, n_blocks = self._sched(slab, x.shape[1])
+        desc, n_blocks, scratch = self._sched(slab, x.shape[1])
         _lib.check(_lib.lib().rk_spmm_csr_ex(slab["n_rows"], _lib.ptr(slab["rowptr"]), _lib.ptr(slab["col"]), _lib.ptr(slab["val"]),
-                                             _lib.ptr(desc), n_blocks, x.shape[1], _lib.ptr(x), x.shape[0],
+                                             _lib.ptr(desc), n_blocks, _lib.ptr(scratch), x.shape[1], _lib.ptr(x), x.shape[0],
                                              C.byref(e), _lib.stream_ptr()), "rk_spmm_csr_ex")
 
     def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials):
@@ -319,9 +320,9 @@ class ShardedLightGCN:
         lay, dev = self.layout, self.device
         nodes = torch.stack([users.to(dev).long(), pos.to(dev).long() + self.U, neg.to(dev).long() + self.U])  # [3, n]
         posn = lay.pos(nodes).contiguous()                                                        # gathered positions
-        own = (nodes % self.world) == self.rank
+        own_f = ((nodes % self.world) == self.rank).to(torch.float32)
         local = (nodes // self.world)
-        return {"pos": posn, "own": own, "local": local}
+        return {"pos": posn, "own_f": own_f, "local": local}
 
     def step(self, plan, ep, s0, nb, k):
         """One train step on triplets [s0, s0+nb) of the epoch plan; writes its loss partials to plan['loss'][k]."""
@@ -329,14 +330,10 @@ class ShardedLightGCN:
         self._forward()
         # light rows of the minibatch: own rows in place, zeros elsewhere, summed over the ranks (x + 0 is exact)
         rows = plan["rows"][: 3 * nb]
-        own = ep["own"][:, s0:s0 + nb].reshape(-1)
         loc = ep["local"][:, s0:s0 + nb].reshape(-1)
-        if self.world == 1:
-            torch.index_select(self.s, 0, loc, out=rows)
-        else:
-            rows.zero_()
-            sel = torch.nonzero(own).view(-1)
-            rows.index_copy_(0, sel, self.s.index_select(0, loc[sel]))
+        torch.index_select(self.s, 0, loc, out=rows)       # r // W is a valid local row for every node
+        if self.world > 1:
+            rows.mul_(ep["own_f"][:, s0:s0 + nb].reshape(-1, 1))   # x*1 = x, x*0 = 0: exact, no host sync
             self._all_reduce(rows)
         ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
         lp = plan["loss"][k]

@@ -60,10 +60,6 @@ class LightGCN(BaseVictim):
         self.graph_steps = 8  # steps per hipGraph replay; 0/1 = plain launches
         # last forward layer only on the minibatch's rows (-4 us of 18 on ml1m)
         self.use_batch_sparsity = True
-        # Experimental: persistent SpMM with the hottest X rows staged in LDS (spmm_csr_hot_kernel).
-        # Correct (parity-tested) but 2.5x SLOWER than the gather kernel at ml1m size (43.8 vs 17.4 us):
-        # one 16-wave workgroup per CU serialises its segments' latency chains.  Off by default.
-        self.use_lds_hot_rows = False
 
     # ------------------------------------------------------------------ C-ABI handle
     def _adam_is_default(self):
@@ -116,8 +112,14 @@ class LightGCN(BaseVictim):
         if dev.type != "cuda":
             raise _lib.HipCallError("LightGCN parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
         wu, wi, su, si = self._fuse_tables()
+        grp = self.optimizer.param_groups[0]
+        betas = grp.get("betas", (0.9, 0.999))
+        # everything the handle (and the hipGraph captured inside it) copies BY VALUE is part of the key: a later
+        # change of lr / betas / eps (a scheduler, a manual decay) or of config["lambda"] rebuilds the handle, as
+        # the reference re-reads them every step
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
-               self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0)
+               self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
+               float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]))
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -129,13 +131,10 @@ class LightGCN(BaseVictim):
         ws["state"] = torch.zeros(16, device=dev, dtype=torch.int32)
         ws["coef"] = torch.zeros(2 * _lib.RK_MAX_GRAPH_STEPS, device=dev, dtype=torch.float32)
         ws["row_bits"] = torch.zeros((N + 31) // 32, device=dev, dtype=torch.int32) if self.use_batch_sparsity else None
-        grp = self.optimizer.param_groups[0]
-        betas = grp.get("betas", (0.9, 0.999))
-        hot = g.hot_tables(d) if (self.use_lds_hot_rows and not self.graph_dropout and d in (32, 64, 128, 256)) else None
         if self.graph_dropout and self._drop_seed is None:
             self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ws["tpos"] = g.transpose_index() if self.graph_dropout else None
-        ws["hot"] = hot  # keeps the tables alive as long as the handle
+        ws["spmm_scratch"] = g.new_scratch(d)  # this handle's own long-row counters / partial slots
         desc = _lib.LightGCNDesc(
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
             lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
@@ -148,12 +147,7 @@ class LightGCN(BaseVictim):
             buf_a=_lib.ptr(ws["buf_a"]), buf_b=_lib.ptr(ws["buf_b"]), light=_lib.ptr(ws["light"]),
             gprop=_lib.ptr(ws["gprop"]), gego=_lib.ptr(ws["gego"]), grad=_lib.ptr(ws["grad"]),
             state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]),
-            col_tagged=_lib.ptr(hot["col_tagged"]) if hot else None, hot_rows=_lib.ptr(hot["hot_rows"]) if hot else None,
-            witems=_lib.ptr(hot["witems"]) if hot else None, long_rows=_lib.ptr(hot["long_rows"]) if hot else None,
-            val_hot=_lib.ptr(hot["val_hot"]) if hot else None,
-            partials=_lib.ptr(hot["partials"]) if hot else None, hot_H=hot["H"] if hot else 0,
-            max_items=hot["max_items"] if hot else 0, n_long=hot["n_long"] if hot else 0,
-            two_classes=hot["two_classes"] if hot else 0, hot_grid=hot["grid"] if hot else 0,
+            spmm_scratch=_lib.ptr(ws["spmm_scratch"]),
             row_bits=_lib.ptr(ws["row_bits"]),
             keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
             drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]))
@@ -216,7 +210,7 @@ class LightGCN(BaseVictim):
         hipGraph now, so that no later epoch (or timed region) pays for either."""
         h = self._ensure_handle(want_grad=want_grad)
         st = self._staging(int(n_triplets), int(batch), self.embedding_user.weight.device)
-        if self._fused_adam and int(self.graph_steps) > 1 and self.n_layers > 0:
+        if self._fused_adam and int(self.graph_steps) > 1:
             _lib.check(_lib.lib().rk_lightgcn_prepare(
                 h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), _lib.ptr(st["loss"]), 1,
                 int(self.graph_steps), _lib.stream_ptr()), "rk_lightgcn_prepare")

@@ -6,9 +6,7 @@ which = sys.argv[1]
 d = synth.make("ml1m")
 ds = dataset.from_config("implicit", "ml1m", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], device=dev, graph_source=which)
 m = model.from_config("victim", "lightgcn", latent_dim_rec=64).I(dataset=ds).to(dev)
-m.use_lds_hot_rows = bool(int(os.environ.get('RK_HOT', '0')))
 h = m._ensure_handle()
-if m._ws.get('hot'): print('hot tables:', {k: v for k, v in m._ws['hot'].items() if isinstance(v, int)})
 for _ in range(20): _lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr())
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
