@@ -126,6 +126,46 @@ class BaseVictim(nn.Module):
         pprint(info)
 
     # ------------------------------------------------------------------ shared plumbing
+    def _adam_is_fused(self):
+        """True when self.optimizer is torch.optim.Adam with the options the fused HIP epilogues implement
+        (recad/utils.py:181-183: `optim.Adam(params, lr=...)`, i.e. no amsgrad / weight decay / maximize, ONE
+        parameter group).  Anything else runs through `_unfused_epoch` instead of being approximated."""
+        import torch
+        opt = self.optimizer
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        return (not g.get("amsgrad", False)) and g.get("weight_decay", 0) == 0 and not g.get("maximize", False)
+
+    def _adam_slot(self, p):
+        """optimizer.state[p] with the exp_avg / exp_avg_sq / step entries torch.optim.Adam keeps (created on
+        first use), so optimizer.state_dict() / load_state_dict() carry the moments of the fused HIP Adam."""
+        import torch
+        st = self.optimizer.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _unfused_epoch(self, cols, batch, grad_step):
+        """Any optimizer the reference's pick_optim can return (recad/utils.py:181-189) other than default Adam:
+        per minibatch the HIP path computes the loss and the dense gradients only (grad_step(slices) ->
+        (loss_partials row, {param: grad tensor})), the torch optimizer applies them.  Same arithmetic as the
+        reference's loss.backward(); optimizer.step() (lightgcn.py:166-168), one host round trip per step."""
+        import torch
+        n = cols[0].numel()
+        losses = []
+        for s in range(0, n, batch):
+            part, grads = grad_step([c[s:s + batch] for c in cols])
+            for p_, g_ in grads.items():
+                p_.grad = g_
+            self.optimizer.step()
+            losses.append(part.reshape(-1).sum().double())
+        for p_ in self.parameters():
+            p_.grad = None
+        return torch.stack(losses).cpu()
+
     @staticmethod
     def _collect_epoch(dataset, keys):
         """All minibatches of one epoch as three int64 device tensors + the batch size.

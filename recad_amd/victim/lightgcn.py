@@ -53,7 +53,7 @@ class LightGCN(BaseVictim):
             self.embedding_item.weight.data.copy_(torch.from_numpy(config["item_emb"]))
         self.f = nn.Sigmoid()
         self.optimizer = pick_optim(config["optim"])(self.parameters(), lr=config["lr"])
-        self._fused_adam = isinstance(self.optimizer, torch.optim.Adam) and self._adam_is_default()
+        self._fused_adam = self._adam_is_fused()
         self._handle = None
         self._handle_key = None
         self._ws = None
@@ -62,16 +62,17 @@ class LightGCN(BaseVictim):
         self.use_batch_sparsity = True
 
     # ------------------------------------------------------------------ C-ABI handle
-    def _adam_is_default(self):
-        g = self.optimizer.param_groups[0]
-        return (not g.get("amsgrad", False)) and g.get("weight_decay", 0) == 0 and not g.get("maximize", False)
-
     def _adam_state(self, p):
-        st = self.optimizer.state[p]
-        if "exp_avg" not in st:
-            st["step"] = torch.zeros((), dtype=torch.float32)
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if self._fused_adam:
+            return self._adam_slot(p)
+        # foreign optimizer: its own state stays untouched; the handle still wants moment buffers (unused: the
+        # library is only asked for gradients then)
+        if getattr(self, "_dummy_mom", None) is None:
+            self._dummy_mom = {}
+        st = self._dummy_mom.setdefault(id(p), {"step": torch.zeros((), dtype=torch.float32)})
+        if "exp_avg" not in st or st["exp_avg"].shape != p.shape:
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
         return st
 
     def _fuse_tables(self):
@@ -236,18 +237,26 @@ class LightGCN(BaseVictim):
                 self.optimizer.state[p]["step"] += n_steps
         return loss_partials[: n_steps * _lib.RK_LOSS_PARTIALS].view(n_steps, _lib.RK_LOSS_PARTIALS)
 
+    def _grad_step(self, cols):
+        """loss partials and dLoss/dE0 of ONE minibatch (no update): the gradient half of lightgcn.py:149-167."""
+        u, p, n = cols
+        part = self._run_epoch(u, p, n, max(u.numel(), 1), apply_update=False, want_grad=True)
+        g = self._ws["grad"]
+        U = self.num_users
+        return part.clone(), {self.embedding_user.weight: g[:U].clone(), self.embedding_item.weight: g[U:].clone()}
+
     def train_step(self, **config):
         """One epoch over dataset.generate_batch() (lightgcn.py:132-172) -> (mean step loss,)."""
         self.train()
         pbar = config.get("progress_bar", None)
-        if not self._fused_adam:
-            raise NotImplementedError("the HIP LightGCN path fuses torch.optim.Adam (default options); "
-                                      f"optimizer {type(self.optimizer).__name__} is not supported")
         (users, pos, neg), batch = self._collect_epoch(self.dataset, ("users", "positive_items", "negative_items"))
         dev = self.embedding_user.weight.device
         users, pos, neg = (t.to(dev).long().contiguous() for t in (users, pos, neg))
-        partials = self._run_epoch(users, pos, neg, batch)
-        step_losses = partials.sum(dim=1).double().cpu()  # ONE device->host sync per epoch
+        if self._fused_adam:
+            partials = self._run_epoch(users, pos, neg, batch)
+            step_losses = partials.sum(dim=1).double().cpu()  # ONE device->host sync per epoch
+        else:
+            step_losses = self._unfused_epoch((users, pos, neg), batch, self._grad_step)
         mean_loss = float(step_losses.sum().item() / len(step_losses))
         if pbar:
             pbar.set_description(f"loss {mean_loss:.5f}")

@@ -30,8 +30,8 @@ class MF(BaseVictim):
         self.dropout = nn.Dropout(dropout)
         self.optimizer = pick_optim(config["optim"])(self.parameters(), lr=config["lr"])
         self.num_users, self.num_items, self.dim = num_users, num_items, embedding_size
-        self._mom = None
-        self._t = 0
+        self._fused_adam = self._adam_is_fused()
+        self._flat = None   # {"m","v","g"}: flat [U*d | I*d | U | I] buffers; optimizer.state holds views of m / v
 
     def _tables(self):
         ts = (self.user_emb.weight, self.item_emb.weight, self.user_bias.weight, self.item_bias.weight)
@@ -40,10 +40,38 @@ class MF(BaseVictim):
         return ts
 
     def _flat_state(self, dev):
-        tot = (self.num_users + self.num_items) * (self.dim + 1)
-        if self._mom is None or self._mom[0].device != dev:
-            self._mom = tuple(torch.zeros(tot, device=dev, dtype=torch.float32) for _ in range(3))  # m, v, grads
-        return self._mom
+        """Flat moment / gradient buffers in the kernel's layout [user_emb | item_emb | user_bias | item_bias].
+        The Adam moments live in optimizer.state[p] (exp_avg / exp_avg_sq / step, what torch.optim.Adam keeps) as
+        VIEWS of the flat buffers, so optimizer.state_dict() / load_state_dict() and .to(device) carry them; the
+        views are re-homed lazily whenever they are not where the kernel expects them."""
+        ps = self._tables()
+        sizes = [p.numel() for p in ps]
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + n_)
+        fl = self._flat
+        slots = [self._adam_slot(p) if self._fused_adam else None for p in ps]
+
+        def in_place(buf, t, off):
+            return t.device == buf.device and t.is_contiguous() and t.data_ptr() == buf.data_ptr() + 4 * off
+
+        ok = fl is not None and fl["m"].device == dev and fl["m"].numel() == offs[-1]
+        if ok and self._fused_adam:
+            ok = all(in_place(fl["m"], st["exp_avg"], o) and in_place(fl["v"], st["exp_avg_sq"], o) for st, o in zip(slots, offs))
+        if not ok:
+            fl = {k: torch.zeros(offs[-1], device=dev, dtype=torch.float32) for k in ("m", "v", "g")}
+            if self._fused_adam:
+                for p, st, o, n_ in zip(ps, slots, offs, sizes):
+                    fl["m"][o:o + n_].copy_(st["exp_avg"].reshape(-1).to(dev))
+                    fl["v"][o:o + n_].copy_(st["exp_avg_sq"].reshape(-1).to(dev))
+                    st["exp_avg"], st["exp_avg_sq"] = fl["m"][o:o + n_].view_as(p), fl["v"][o:o + n_].view_as(p)
+            self._flat = fl
+        self._offs = offs
+        return fl["m"], fl["v"], fl["g"]
+
+    def _steps_done(self):
+        st = self.optimizer.state.get(self.user_emb.weight, {})
+        return int(st["step"]) if "step" in st else 0
 
     def forward(self, users, items):
         ue, ie, ub, ib = self._tables()
@@ -56,8 +84,8 @@ class MF(BaseVictim):
 
     def _run_epoch(self, users, items, labels, batch, apply_update=True):
         ue, ie, ub, ib = self._tables()
-        if not isinstance(self.optimizer, torch.optim.Adam):
-            raise NotImplementedError("the HIP MF path fuses torch.optim.Adam (default options)")
+        if apply_update and not self._fused_adam:
+            raise _lib.HipCallError("fused update requested with a non-default optimizer (internal error)")
         grp = self.optimizer.param_groups[0]
         b1, b2 = grp.get("betas", (0.9, 0.999))
         m, v, grads = self._flat_state(ue.device)
@@ -67,11 +95,20 @@ class MF(BaseVictim):
         _lib.check(_lib.lib().rk_mf_train_epoch(
             self.num_users, self.num_items, self.dim, _lib.ptr(ue.data), _lib.ptr(ie.data), _lib.ptr(ub.data),
             _lib.ptr(ib.data), float(self.mean.item()), _lib.ptr(m), _lib.ptr(v), _lib.ptr(grads), _lib.ptr(users),
-            _lib.ptr(items), _lib.ptr(labels), n, batch, self._t, float(grp["lr"]), float(b1), float(b2),
+            _lib.ptr(items), _lib.ptr(labels), n, batch, self._steps_done(), float(grp.get("lr", 1e-3)), float(b1), float(b2),
             float(grp.get("eps", 1e-8)), _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()), "rk_mf_train_epoch")
         if apply_update:
-            self._t += n_steps
+            for p in (ue, ie, ub, ib):
+                self.optimizer.state[p]["step"] += n_steps
         return lp.view(n_steps, _lib.RK_LOSS_PARTIALS)
+
+    def _grad_step(self, cols):
+        """loss partials and the four dense gradients of ONE minibatch (no update): mf.py:59-63 without opt.step()."""
+        u, i, y = cols
+        part = self._run_epoch(u, i, y, max(u.numel(), 1), apply_update=False)
+        g, o = self._flat["g"], self._offs
+        ps = self._tables()
+        return part.clone(), {p: g[o[k]:o[k + 1]].view_as(p).clone() for k, p in enumerate(ps)}
 
     def train_step(self, **config):
         """One epoch of pointwise BCE training (mf.py:49-69) -> (mean step loss,)."""
@@ -80,8 +117,10 @@ class MF(BaseVictim):
         (users, items, labels), batch = self._collect_epoch(self.dataset, ("users", "items", "labels"))
         dev = self.user_emb.weight.device
         users, items, labels = (t.to(dev).long().contiguous() for t in (users, items, labels))
-        partials = self._run_epoch(users, items, labels, batch)
-        step_losses = partials.sum(dim=1).double().cpu()
+        if self._fused_adam:
+            step_losses = self._run_epoch(users, items, labels, batch).sum(dim=1).double().cpu()
+        else:
+            step_losses = self._unfused_epoch((users, items, labels), batch, self._grad_step)
         mean_loss = float(step_losses.sum().item() / len(step_losses))
         if pbar:
             pbar.set_description(f"loss: {mean_loss:.4f}")

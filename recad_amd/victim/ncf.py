@@ -53,7 +53,7 @@ class NCF(BaseVictim):
         self.loss_func = nn.BCEWithLogitsLoss()
         self._E = E
         self._ws = None
-        self._t = 0
+        self._fused_adam = self._adam_is_fused()
         self.max_batch = 16384  # forward chunk of the full-catalog evaluation: large enough for the 128x128-tile GEMM
 
     # ------------------------------------------------------------------ C-ABI descriptor
@@ -67,18 +67,13 @@ class NCF(BaseVictim):
         dev = ts[0].device
         if dev.type != "cuda":
             raise _lib.HipCallError("NCF parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
-        if not isinstance(self.optimizer, torch.optim.Adam):
-            raise NotImplementedError("the HIP NCF path fuses torch.optim.Adam (default options)")
         L, f = self.num_layers, self.factor_num
         mb = max(int(batch), self.max_batch)
         key = (tuple(t.data_ptr() for t in ts), mb)
         if self._ws is None or self._ws["key"] != key:
             widths = sum(f * 2 ** (L - l) for l in range(L + 1))
-            old = self._ws
             ws = {"key": key,
                   "grad": [torch.zeros_like(t) for t in ts],
-                  "m": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["m"]],
-                  "v": [torch.zeros_like(t) for t in ts] if old is None else [x.to(dev) for x in old["v"]],
                   "acts": torch.empty(mb * widths, device=dev), "dacts": torch.empty(mb * widths, device=dev),
                   "d0": torch.empty(mb, device=dev), "max_batch": mb,
                   "gemm_scratch": torch.empty(8 << 20, device=dev),  # split-K slices of the dX GEMMs (rk_ncf_desc)
@@ -87,7 +82,20 @@ class NCF(BaseVictim):
         ws = self._ws
         grp = self.optimizer.param_groups[0]
         b1, b2 = grp.get("betas", (0.9, 0.999))
-        d = _lib.NCFDesc(n_users=self.num_users, n_items=self.num_items, factor=f, n_layers=L, lr=float(grp["lr"]),
+        # Adam's moments live where torch.optim.Adam keeps them (optimizer.state[p]: exp_avg / exp_avg_sq / step), so
+        # optimizer.state_dict() / load_state_dict() carry them; they follow the parameters across .to(device)
+        if self._fused_adam:
+            slots = [self._adam_slot(t) for t in ts]
+            for st, t in zip(slots, ts):
+                for k_ in ("exp_avg", "exp_avg_sq"):
+                    if st[k_].device != dev or not st[k_].is_contiguous():
+                        st[k_] = st[k_].to(dev).contiguous()
+            mom_m, mom_v = [st["exp_avg"] for st in slots], [st["exp_avg_sq"] for st in slots]
+        else:  # foreign optimizer: the library only computes gradients; unused moment buffers keep the descriptor whole
+            if ws.get("dummy") is None:
+                ws["dummy"] = ([torch.zeros_like(t) for t in ts], [torch.zeros_like(t) for t in ts])
+            mom_m, mom_v = ws["dummy"]
+        d = _lib.NCFDesc(n_users=self.num_users, n_items=self.num_items, factor=f, n_layers=L, lr=float(grp.get("lr", 1e-3)),
                          beta1=float(b1), beta2=float(b2), eps=float(grp.get("eps", 1e-8)),
                          ug=_lib.ptr(ts[0].data), ig=_lib.ptr(ts[1].data), um=_lib.ptr(ts[2].data), im=_lib.ptr(ts[3].data),
                          pw=_lib.ptr(ts[-2].data), pb=_lib.ptr(ts[-1].data), acts=_lib.ptr(ws["acts"]), dacts=_lib.ptr(ws["dacts"]),
@@ -98,8 +106,8 @@ class NCF(BaseVictim):
             d.b[l] = ts[4 + L + l].data.data_ptr()
         for k in range(len(ts)):
             d.grad[k] = ws["grad"][k].data_ptr()
-            d.m[k] = ws["m"][k].data_ptr()
-            d.v[k] = ws["v"][k].data_ptr()
+            d.m[k] = mom_m[k].data_ptr()
+            d.v[k] = mom_v[k].data_ptr()
         return d
 
     # ------------------------------------------------------------------ reference API
@@ -115,12 +123,27 @@ class NCF(BaseVictim):
         n = users.numel()
         n_steps = (n + batch - 1) // batch
         lp = torch.empty(n_steps * _lib.RK_LOSS_PARTIALS, device=users.device, dtype=torch.float32)
+        if apply_update and not self._fused_adam:
+            raise _lib.HipCallError("fused update requested with a non-default optimizer (internal error)")
+        st0 = self.optimizer.state.get(self._tensors()[0], {})
+        t0 = int(st0["step"]) if "step" in st0 else 0
         _lib.check(_lib.lib().rk_ncf_train_epoch(C.byref(d), _lib.ptr(users), _lib.ptr(items), _lib.ptr(labels), n, batch,
-                                                 self._t, _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()),
+                                                 t0, _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()),
                    "rk_ncf_train_epoch")
         if apply_update:
-            self._t += n_steps
+            for t in self._tensors():
+                self.optimizer.state[t]["step"] += n_steps
         return lp.view(n_steps, _lib.RK_LOSS_PARTIALS)
+
+    def _grad_step(self, cols):
+        """loss partials and every tensor's dense gradient for ONE minibatch (no update): ncf.py:143-147 without
+        optimizer.step().  The gradient buffers accumulate (scatter-adds, split-K atomics): cleared after the copy."""
+        u, i, y = cols
+        part = self._run_epoch(u, i, y, max(u.numel(), 1), apply_update=False)
+        grads = {t: g.clone() for t, g in zip(self._tensors(), self._ws["grad"])}
+        for g in self._ws["grad"]:
+            g.zero_()
+        return part.clone(), grads
 
     def train_step(self, **config):
         """One epoch of pointwise BCE training (ncf.py:133-153) -> (mean step loss,)."""
@@ -129,8 +152,10 @@ class NCF(BaseVictim):
         (users, items, labels), batch = self._collect_epoch(self.dataset, ("users", "items", "labels"))
         dev = self.predict_layer.weight.device
         users, items, labels = (t.to(dev).long().contiguous() for t in (users, items, labels))
-        partials = self._run_epoch(users, items, labels, batch)
-        step_losses = partials.sum(dim=1).double().cpu()
+        if self._fused_adam:
+            step_losses = self._run_epoch(users, items, labels, batch).sum(dim=1).double().cpu()
+        else:
+            step_losses = self._unfused_epoch((users, items, labels), batch, self._grad_step)
         mean_loss = float(step_losses.sum().item() / len(step_losses))
         if pbar:
             pbar.set_description(f"loss: {mean_loss:.5f}")

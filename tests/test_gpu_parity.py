@@ -238,11 +238,11 @@ def test_mf_train_and_eval_golden(gpu_device, name):
     part = m._run_epoch(b["users"], b["items"], b["labels"], len(b["users"]), apply_update=False)
     assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
     U, I, d = m.num_users, m.num_items, m.dim
-    gr = m._mom[2].cpu().numpy()
+    gr = m._flat["g"].cpu().numpy()
     assert G.relerr(gr[: U * d].reshape(U, d)[::rs], g["grad1_user_emb"]) < 1e-5
     assert G.relerr(gr[U * d:(U + I) * d].reshape(I, d)[::rs], g["grad1_item_emb"]) < 1e-5
     assert G.relerr(gr[(U + I) * d:(U + I) * d + U][::rs], g["grad1_user_bias"].reshape(-1)) < 1e-5
-    m._mom[2].zero_()
+    m._flat["g"].zero_()
     for s in range(len(g["batch_len"])):
         ds.steps = [s]
         (loss,) = m.train_step()
@@ -877,3 +877,215 @@ def test_randomised_stress(gpu_device, which, n_cases):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(seed=1234, n_cases=n_cases)
+
+
+# ------------------------------------------------------------------ round 2: options the reference accepts
+def _torch_lightgcn_ref(g, optim_cls, opt_kw, steps, L):
+    """The reference's op sequence (lightgcn.py:82-113,137-169) in plain ATen on the CPU, any optimizer."""
+    U, I = int(g["n_users"]), int(g["n_items"])
+    idx = torch.from_numpy(np.stack([g["graph_row"], g["graph_col"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(idx, torch.from_numpy(g["graph_val"]), (U + I, U + I)).coalesce()
+    u0, i0 = G.lightgcn_init(g)
+    eu, ei = torch.nn.Parameter(torch.from_numpy(u0.copy())), torch.nn.Parameter(torch.from_numpy(i0.copy()))
+    opt = optim_cls([eu, ei], **opt_kw)
+    losses = []
+    for s in steps:
+        n = int(g["batch_len"][s])
+        u, p, ng = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)) for k in range(3))
+        x = torch.cat([eu, ei])
+        embs = [x]
+        for _ in range(L):
+            x = torch.sparse.mm(A, x)
+            embs.append(x)
+        light = torch.mean(torch.stack(embs, dim=1), dim=1)
+        lu, li = torch.split(light, [U, I])
+        reg = 0.5 * (eu[u].norm(2).pow(2) + ei[p].norm(2).pow(2) + ei[ng].norm(2).pow(2)) / float(n)
+        loss = torch.mean(torch.nn.functional.softplus((lu[u] * li[ng]).sum(1) - (lu[u] * li[p]).sum(1))) + 1e-4 * reg
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return losses, eu.detach().numpy(), ei.detach().numpy()
+
+
+@pytest.mark.parametrize("optim,kw", [("SGD", {"lr": 0.05}), ("Adagrad", {"lr": 0.01}), ("RMSprop", {"lr": 0.001})])
+def test_lightgcn_foreign_optimizers(gpu_device, optim, kw):
+    """pick_optim (recad/utils.py:181-189) hands any torch.optim class to the victim: non-Adam optimizers run the HIP
+    forward/backward for the gradients and the torch optimizer for the update -- same numbers as plain ATen."""
+    from recad_amd import model
+    g = G.load("lightgcn_dev_d128_l2_tg")
+    L = int(g["layers"])
+    ds = ReplayDataset(g, LGN_KEYS, device=gpu_device, steps=[0, 1, 2])
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=int(g["dim"]), lightGCN_n_layers=L, optim=optim, **kw).I(dataset=ds)
+    u0, i0 = G.lightgcn_init(g)
+    m.embedding_user.weight.data.copy_(torch.from_numpy(u0))
+    m.embedding_item.weight.data.copy_(torch.from_numpy(i0))
+    m = m.to(gpu_device)
+    assert type(m.optimizer).__name__ == optim and not m._fused_adam
+    (loss,) = m.train_step()
+    ref_losses, ru, ri = _torch_lightgcn_ref(g, getattr(torch.optim, optim), kw, [0, 1, 2], L)
+    assert abs(loss - np.mean(ref_losses)) <= 2e-5 * abs(np.mean(ref_losses))
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy(), ru) < 1e-4
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy(), ri) < 1e-4
+
+
+def test_lightgcn_adam_options_and_live_lr(gpu_device):
+    """Adam with weight decay is not what the fused epilogue implements -> unfused path, same numbers as ATen;
+    and a learning-rate change on the live optimizer (scheduler / manual decay) is honoured by the fused path."""
+    from recad_amd import model
+    g = G.load("lightgcn_dev_d128_l2_tg")
+    L = int(g["layers"])
+    ds = ReplayDataset(g, LGN_KEYS, device=gpu_device, steps=[0, 1])
+    m, _ = _make_lgn(g, gpu_device, steps=[0, 1])
+    m.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    m._fused_adam = m._adam_is_fused()
+    assert not m._fused_adam
+    m.train_step()
+    _, ru, ri = _torch_lightgcn_ref(g, torch.optim.Adam, {"lr": 1e-3, "weight_decay": 1e-2}, [0, 1], L)
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy(), ru) < 1e-4
+    # fused path, lr changed between two epochs
+    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    assert m._fused_adam
+    m.train_step()
+    m.optimizer.param_groups[0]["lr"] = 5e-3
+    ds.steps = [1]
+    m.train_step()
+    U, I = int(g["n_users"]), int(g["n_items"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u, i = G.lightgcn_init(g)
+    st = orc.AdamState(u.shape, i.shape)
+    for s, lr in ((0, 1e-3), (1, 5e-3)):
+        n = int(g["batch_len"][s])
+        orc.lightgcn_step(csr, u, i, st, *(g["batches"][s, k, :n] for k in range(3)), L, lr=lr)
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy(), u) < 1e-5
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy(), i) < 1e-5
+
+
+@pytest.mark.parametrize("graph_steps", [0, 4])
+def test_lightgcn_zero_layers(gpu_device, graph_steps):
+    """lightGCN_n_layers=0 is valid in the reference (light = E0): train and score against the oracle."""
+    from recad_amd import dataset, model, synth
+    dd = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"],
+                             device=gpu_device, graph_source="train", seed=5, pairwise_batch_size=512)
+    torch.manual_seed(11)
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=0).I(dataset=ds).to(gpu_device)
+    m.graph_steps = graph_steps
+    u0 = m.embedding_user.weight.detach().cpu().numpy().copy()
+    i0 = m.embedding_item.weight.detach().cpu().numpy().copy()
+    g = ds.graph_csr()
+    csr = (g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy())
+    st = orc.AdamState(u0.shape, i0.shape)
+    for _ in range(2):
+        e = ds.generate_epoch()
+        users, pos, neg = (e[k] for k in LGN_KEYS)
+        losses = m._run_epoch(users, pos, neg, 512).sum(1).double().cpu().numpy()
+        un, pn, nn_ = users.cpu().numpy(), pos.cpu().numpy(), neg.cpu().numpy()
+        for s in range(len(losses)):
+            sl = slice(s * 512, (s + 1) * 512)
+            ref = orc.lightgcn_step(csr, u0, i0, st, un[sl], pn[sl], nn_[sl], 0)
+            assert abs(losses[s] - ref) <= 2e-5 * abs(ref), (s, losses[s], ref)
+    assert G.relerr(m.embedding_user.weight.detach().cpu().numpy(), u0) < TABLE_RTOL
+    assert G.relerr(m.embedding_item.weight.detach().cpu().numpy(), i0) < TABLE_RTOL
+    lu, li = m.computer()
+    assert torch.equal(lu, m.embedding_user.weight.detach()) and torch.equal(li, m.embedding_item.weight.detach())
+
+
+def test_mf_ncf_optimizer_state_roundtrip(gpu_device):
+    """MF / NCF keep Adam's moments and step in optimizer.state: state_dict() is complete, a
+    checkpoint/resume continues exactly, and a device round trip keeps the moments."""
+    import copy
+    from recad_amd import model
+    for name, kind, kw in (("mf_dev_e64", "mf", {}), ("ncf_dev_f8_l3", "ncf", {})):
+        g = G.load(name)
+        if kind == "mf":
+            kw = {"embedding_size": int(g["dim"])}
+        else:
+            kw = {"factor_num": int(g["factor"]), "num_layers": int(g["layers"])}
+        n_steps = len(g["batch_len"])
+        ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+        torch.manual_seed(7)
+        m = model.from_config("victim", kind, **kw).I(dataset=ds).to(gpu_device)
+        m.train_step()
+        osd = copy.deepcopy(m.optimizer.state_dict())
+        assert len(osd["state"]) >= 4 and all(int(v["step"]) == 1 for v in osd["state"].values())
+        assert any(float(v["exp_avg"].abs().sum()) > 0 for v in osd["state"].values())
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m2 = model.from_config("victim", kind, **kw).I(dataset=ds)
+        m2.load_state_dict(sd)
+        m2 = m2.to(gpu_device)
+        m2.optimizer.load_state_dict(osd)
+        # the original takes a detour through the CPU: the moments must follow it
+        m = m.to("cpu").to(gpu_device)
+        ds.steps = [1 % n_steps]
+        la, lb = m.train_step()[0], m2.train_step()[0]
+        assert la == pytest.approx(lb, rel=1e-5), (name, la, lb)
+        for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+            ok, info = G.adam_close(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), 1e-3, 2, outlier_frac=5e-3, travel_frac=0.5)
+            assert ok, (name, k1, info)
+        assert int(m.optimizer.state_dict()["state"][0]["step"]) == 2
+
+
+def test_mf_foreign_optimizer(gpu_device):
+    from recad_amd import model
+    g = G.load("mf_dev_e64")
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0, 1])
+    m = model.from_config("victim", "mf", embedding_size=int(g["dim"]), optim="SGD", lr=0.5).I(dataset=ds)
+    init = G.mf_init(g)
+    for p, a in zip((m.user_emb, m.item_emb, m.user_bias, m.item_bias), init):
+        p.weight.data.copy_(torch.from_numpy(a))
+    m = m.to(gpu_device)
+    m.train_step()
+    # plain ATen reference (mf.py:40-69)
+    ps = [torch.nn.Parameter(torch.from_numpy(a.copy())) for a in init]
+    opt = torch.optim.SGD(ps, lr=0.5)
+    mean = float(g["mean"])
+    for s in (0, 1):
+        n = int(g["batch_len"][s])
+        u, i, y = (torch.from_numpy(g["batches"][s, k, :n].astype(np.int64)) for k in range(3))
+        logit = (ps[0][u] * ps[1][i]).sum(1) + ps[2][u].view(-1) + ps[3][i].view(-1) + mean
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, y.float())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for p, r in zip((m.user_emb, m.item_emb, m.user_bias, m.item_bias), ps):
+        assert G.relerr(p.weight.detach().cpu().numpy(), r.detach().numpy()) < 1e-4
+
+
+def test_spmm_scratch_is_per_user(gpu_device):
+    """the cached schedule is read-only; long-row counters / partial slots are per handle.  Two
+    models on ONE dataset graph, run on two streams at once, must both be exact."""
+    from recad_amd import dataset, model
+    rng = np.random.default_rng(5)
+    U, I = 600, 3000
+    # two users with > 1024 positives: long rows (pieces + arrival counters) in the user block and popular items
+    deg = rng.integers(5, 40, U)
+    deg[:2] = 2500
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(deg)
+    idx = np.concatenate([np.sort(rng.choice(I, size=k, replace=False)) for k in deg]).astype(np.int32)
+    empty = (np.zeros(U + 1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    ds = dataset.from_config("implicit", "long", train_csr=(ptr, idx), valid_csr=empty, test_csr=empty, device=gpu_device,
+                             graph_source="train", seed=1)
+    g = ds.graph_csr()
+    assert g.new_scratch(64) is not None and g.new_scratch(64).data_ptr() != g.new_scratch(64).data_ptr()
+    ms = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        ms.append(model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=3).I(dataset=ds).to(gpu_device))
+    csr = (g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy())
+    refs = [orc.lightgcn_propagate(csr, m.embedding_user.weight.detach().cpu().numpy(), m.embedding_item.weight.detach().cpu().numpy(), 3)
+            for m in ms]
+    assert ms[0]._ensure_handle() is not None and ms[1]._ensure_handle() is not None
+    assert ms[0]._ws["spmm_scratch"].data_ptr() != ms[1]._ws["spmm_scratch"].data_ptr()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(20):
+        for k, (m, s) in enumerate(zip(ms, streams)):
+            with torch.cuda.stream(s):
+                lu, li = m.computer()
+                outs[k] = torch.cat([lu, li]).clone()
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert G.relerr(outs[k].cpu().numpy(), refs[k]) < 2e-6, (rep, k)
