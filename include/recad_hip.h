@@ -247,6 +247,21 @@ int rk_topk_rows(float *scores, int32_t nb, int32_t n_items, const int32_t *user
 int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_targets, const int32_t *ks, int32_t nk,
                   int32_t *counts, void *stream);
 
+/* Users the reference evaluates (normal.py:133-143): every user whose train list (CSR seen_ptr/seen_idx, item ids
+ * sorted) is non-empty and holds none of the targets.  user_ids[0..count) = their ids in ascending order; all
+ * pointers on the device; flags_scratch: int32[n_users]; count: int32[1]. */
+int rk_eligible_users(int32_t n_users, const int32_t *seen_ptr, const int32_t *seen_idx, const int32_t *targets,
+                      int32_t n_targets, int32_t *flags_scratch, int32_t *user_ids, int32_t *count, void *stream);
+
+/* pred_shift (normal.py:147-149): out[0] = mean(score_after[i] - score_before[i]), out[1] = the sum, i < n, in
+ * double, fixed summation order.  out: device double[2]. */
+int rk_pred_shift(const float *score_before, const float *score_after, int64_t n, double *out, void *stream);
+
+/* LightGCN.getUsersRating (lightgcn.py:115-120): out[b*n_items + i] = sigmoid(<utab[user_ids[b]], itab[i]>), the
+ * dot product on the fp32 MFMA GEMM (bit-identical to the k-ordered fmaf chain). */
+int rk_users_rating(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                    int32_t n_items, float *out, void *stream);
+
 /* ---------------------------------------------------------------- NCF -------------- */
 #define RK_NCF_MAX_LAYERS 8
 #define RK_NCF_MAX_TENSORS 24

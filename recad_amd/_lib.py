@@ -99,6 +99,9 @@ _SIGNATURES = {
     "rk_pointwise_sample": [_I32, _I32, _P, _P, _I64, _I32, C.c_uint64, _P, _P, _P, _P],
     "rk_topk_rows": [_P, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P],
     "rk_hit_counts": [_P, _I64, _I32, _P, _I32, _P, _P],
+    "rk_eligible_users": [_I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rk_pred_shift": [_P, _P, _I64, _P, _P],
+    "rk_users_rating": [_I32, _P, _I32, _P, _P, _I32, _P, _P],
     "rk_ncf_forward": [C.POINTER(NCFDesc), _P, _P, _P, _I32, _I64, _P, _P],
     "rk_ncf_train_epoch": [C.POINTER(NCFDesc), _P, _P, _P, _I64, _I32, _I32, _P, _I32, _P],
     "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,

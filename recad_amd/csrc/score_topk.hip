@@ -446,3 +446,104 @@ RK_EXPORT int rk_hit_counts(const int32_t *target_rank, int64_t n, int32_t n_tar
     RK_CHECK_LAUNCH();
     return RK_OK;
 }
+
+// ---------------------------------------------------------------- evaluation plumbing on the device
+// Users the reference evaluates (normal.py:133-143): a non-empty train list that holds none of the targets.
+__global__ void eligible_flags_kernel(int n_users, const int *__restrict__ ptr, const int *__restrict__ idx,
+                                      const int *__restrict__ targets, int n_targets, int *__restrict__ flags)
+{
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
+        const int b = ptr[u], e = ptr[u + 1];
+        int ok = e > b ? 1 : 0;
+        for (int t = 0; t < n_targets && ok; ++t) {
+            const int x = targets[t];
+            int lo = b, hi = e;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[mid] < x) lo = mid + 1; else hi = mid; }
+            if (lo < e && idx[lo] == x) ok = 0;
+        }
+        flags[u] = ok;
+    }
+}
+
+// ordered stream compaction by ONE workgroup: out[k] = k-th user with flag set (ascending user id), count[0] = total
+__global__ __launch_bounds__(1024) void compact_flags_kernel(int n, const int *__restrict__ flags, int *__restrict__ out,
+                                                             int *__restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int f = i < n ? flags[i] : 0;
+        const unsigned long long m = __ballot(f != 0);
+        const int pre = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = carry, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < w) off += wsum[k]; tot += wsum[k]; }
+        if (f) out[off + pre] = i;
+        __syncthreads();
+        if (tid == 0) carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = carry;
+}
+
+RK_EXPORT int rk_eligible_users(int32_t n_users, const int32_t *seen_ptr, const int32_t *seen_idx, const int32_t *targets,
+                                int32_t n_targets, int32_t *flags_scratch, int32_t *user_ids, int32_t *count, void *stream)
+{
+    if (n_users <= 0) return RK_OK;
+    if (!seen_ptr || !seen_idx || n_targets < 0 || (n_targets > 0 && !targets) || !flags_scratch || !user_ids || !count)
+        RK_FAIL(RK_EINVAL, "rk_eligible_users: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(eligible_flags_kernel, dim3(std::min(2048, (n_users + 255) / 256)), dim3(256), 0, s, n_users, seen_ptr, seen_idx,
+                       targets, n_targets, flags_scratch);
+    RK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, s, n_users, flags_scratch, user_ids, count);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// pred_shift = mean(score_after - score_before) over all (user, target) rows (normal.py:147-149), accumulated in
+// double in a fixed order (one workgroup, strided partial sums, tree) => reproducible.
+__global__ __launch_bounds__(1024) void pred_shift_kernel(long long n, const float *__restrict__ before, const float *__restrict__ after,
+                                                          double *__restrict__ out)
+{
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += (double)after[i] - (double)before[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = n > 0 ? part[0] / (double)n : 0.0; out[1] = part[0]; }
+}
+
+RK_EXPORT int rk_pred_shift(const float *score_before, const float *score_after, int64_t n, double *out, void *stream)
+{
+    if (n < 0 || !out || (n > 0 && (!score_before || !score_after))) RK_FAIL(RK_EINVAL, "rk_pred_shift: bad arguments");
+    hipLaunchKernelGGL(pred_shift_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long long)n, score_before, score_after, out);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// LightGCN.getUsersRating (lightgcn.py:115-120): out[b, i] = sigmoid(<utab[user_ids[b]], itab[i]>) on the fp32-MFMA GEMM
+RK_EXPORT int rk_users_rating(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                              int32_t n_items, float *out, void *stream)
+{
+    if (nb <= 0) return RK_OK;
+    if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !out) RK_FAIL(RK_EINVAL, "rk_users_rating: bad arguments");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = nb; g.N = n_items; g.K = dim;
+    g.A = utab; g.a_rs = dim; g.a_cs = 1; g.a_ridx = user_ids;
+    g.B = itab; g.b_rs = dim; g.b_cs = 1;
+    g.C = out; g.ldc = n_items;
+    g.sigmoid = 1;
+    RK_HIP(gemm_f32_launch(g, (hipStream_t)stream));
+    return RK_OK;
+}

@@ -82,6 +82,33 @@ def hit_counts(target_rank, topks):
     return counts
 
 
+def eligible_users_device(seen_ptr, seen_idx, targets, device):
+    """eligible_users() on the device (rk_eligible_users): -> (user_ids int32 device tensor [n], the seen CSR and the
+    targets as int32 device tensors).  One scalar read-back (the count sizes every later buffer)."""
+    _lib.require_gpu()
+    as_dev = lambda a: (a.to(device=device, dtype=torch.int32) if torch.is_tensor(a)
+                        else torch.as_tensor(np.asarray(a), dtype=torch.int32, device=device)).contiguous()
+    ptr, idx, tg = as_dev(seen_ptr), as_dev(seen_idx), as_dev(targets)
+    if idx.numel() == 0:
+        idx = torch.zeros(1, dtype=torch.int32, device=device)
+    U = ptr.numel() - 1
+    flags = torch.empty(max(U, 1), dtype=torch.int32, device=device)
+    ids = torch.empty(max(U, 1), dtype=torch.int32, device=device)
+    count = torch.zeros(1, dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().rk_eligible_users(U, _lib.ptr(ptr), _lib.ptr(idx), _lib.ptr(tg), tg.numel(), _lib.ptr(flags), _lib.ptr(ids),
+                                            _lib.ptr(count), _lib.stream_ptr()), "rk_eligible_users")
+    return ids[: int(count.item())], ptr, idx, tg
+
+
+def pred_shift(score_before, score_after):
+    """mean(score_after - score_before) over all (user, target) rows (normal.py:147-149) as a device double[2]
+    tensor {mean, sum}; no synchronisation."""
+    a, b = score_before.contiguous().view(-1), score_after.contiguous().view(-1)
+    out = torch.empty(2, dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().rk_pred_shift(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.stream_ptr()), "rk_pred_shift")
+    return out
+
+
 def eligible_users(train_ptr, train_idx, targets):
     """Users the reference evaluates (normal.py:133-143): every user with a train list that
     contains none of the targets."""

@@ -171,7 +171,15 @@ class LightGCN(BaseVictim):
 
     # ------------------------------------------------------------------ reference API
     def computer(self):
-        """lightgcn.py:82-113 -> (users[U,d], items[I,d]); views of the handle's workspace."""
+        """lightgcn.py:82-113 -> (users[U,d], items[I,d]).  Fresh tensors like the reference's: the handle's
+        `light` workspace is overwritten by the next propagation / train step, so the public call copies it
+        (2 x [N,d] floats); the module's own consumers use the views of _propagate()."""
+        lu, li = self._propagate()
+        return lu.clone(), li.clone()
+
+    def _propagate(self):
+        """computer() as VIEWS of the handle's `light` workspace: valid until the next propagation or train step
+        on this module (same stream)."""
         h = self._ensure_handle(want_grad=self._ws is not None and self._ws.get("grad") is not None)
         if self.graph_dropout and self.training:
             # lightgcn.py:91-95: a module in training mode propagates through a freshly dropped-out graph -- also
@@ -185,11 +193,17 @@ class LightGCN(BaseVictim):
         return light[: self.num_users], light[self.num_users:]
 
     def getUsersRating(self, users):
-        all_users, all_items = self.computer()
-        return self.f(torch.matmul(all_users[users.long()], all_items.t()))
+        """lightgcn.py:115-120: sigmoid(users_emb . items_emb^T) -> [len(users), n_items]; the dot products on the
+        build's own fp32-MFMA GEMM (rk_users_rating), the user rows gathered inside its tile loads."""
+        all_users, all_items = self._propagate()
+        ids = users.to(device=all_users.device, dtype=torch.int32).contiguous()
+        out = torch.empty(ids.numel(), self.num_items, device=all_users.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rk_users_rating(self.latent_dim, _lib.ptr(all_users), ids.numel(), _lib.ptr(ids), _lib.ptr(all_items),
+                                              self.num_items, _lib.ptr(out), _lib.stream_ptr()), "rk_users_rating")
+        return out
 
     def getEmbedding(self, users, pos_items, neg_items):
-        all_users, all_items = self.computer()
+        all_users, all_items = self._propagate()   # the indexing below copies the rows out
         return (all_users[users], all_items[pos_items], all_items[neg_items], self.embedding_user(users),
                 self.embedding_item(pos_items), self.embedding_item(neg_items))
 
@@ -263,7 +277,7 @@ class LightGCN(BaseVictim):
         return (mean_loss,)
 
     def forward(self, users, items):
-        all_users, all_items = self.computer()
+        all_users, all_items = self._propagate()
         out = torch.empty(users.numel(), device=all_users.device, dtype=torch.float32)
         _lib.check(_lib.lib().rk_pair_scores(
             self.latent_dim, _lib.ptr(all_users), _lib.ptr(all_items), None, None, 0.0, _lib.ptr(users.long().contiguous()),
@@ -272,8 +286,9 @@ class LightGCN(BaseVictim):
 
     # ------------------------------------------------------------------ batched evaluation hook
     def scoring_tables(self):
-        """(user_rows[U,d], item_rows[I,d], user_bias|None, item_bias|None, mean) for rk_score_topk."""
-        all_users, all_items = self.computer()
+        """(user_rows[U,d], item_rows[I,d], user_bias|None, item_bias|None, mean) for rk_score_topk: views of the
+        handle's workspace, consumed by the caller before anything else runs on this module."""
+        all_users, all_items = self._propagate()
         return all_users, all_items, None, None, 0.0
 
     def input_describe(self):

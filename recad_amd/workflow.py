@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .default import WORKFLOW
-from .evaluate import eligible_users, full_catalog_topk, hr_rows
+from .evaluate import eligible_users, eligible_users_device, full_catalog_topk, hit_counts, hr_rows, pred_shift
 from .utils import NullProgress, get_logger
 
 
@@ -110,11 +110,17 @@ class Normal:
                     rows.append([u, st] + [1.0 if rank < k else 0.0 for k in topks])
         return np.asarray(rows, dtype=np.float64), None
 
+    @staticmethod
+    def _batched(model):
+        return hasattr(model, "scoring_tables") or hasattr(model, "score_matrix")
+
     def normal_evaluate(self, model, model_fake, dataset, target_id_list, topks):
         for m in (model, model_fake):
             fwd = m.input_describe()["forward"]
             assert len(fwd) == 2 and "users" in fwd and "items" in fwd, "Expect forward(users, items)"
         ptr, idx = dataset.train_csr_sorted()
+        if self._batched(model) and self._batched(model_fake):
+            return self._evaluate_on_device(model, model_fake, ptr, idx, target_id_list, topks)
         users = eligible_users(ptr, idx, target_id_list)
         rows, _ = self._rows(model, dataset, users, target_id_list, topks)
         rows_fake, _ = self._rows(model_fake, dataset, users, target_id_list, topks)
@@ -125,6 +131,37 @@ class Normal:
             results[f"HR@{k}"] = float(np.mean(rows[:, 2 + i]))
             results[f"HR@{k} after attack"] = float(np.mean(rows_fake[:, 2 + i]))
         results["n_eval_users"] = int(len(users))
+        return results
+
+    def _evaluate_on_device(self, model, model_fake, ptr, idx, target_id_list, topks):
+        """normal.py:111-160 without host round trips of per-user data: the target-present filter
+        (rk_eligible_users), scoring + top-K + target ranks (rk_score_topk / rk_topk_rows), the HR@k numerators
+        (rk_hit_counts) and pred_shift (rk_pred_shift) all stay in HBM; the host reads back the eligible-user
+        count and, at the end, 2*T*len(topks) integers and one double."""
+        dev = next(model.parameters()).device
+        users, ptr_d, idx_d, tg_d = eligible_users_device(ptr, idx, target_id_list, dev)
+        K = max(100, max(topks))
+        n, T = int(users.numel()), int(tg_d.numel())
+        results = OrderedDict()
+        if n == 0:
+            results["pred_shift"] = float("nan")
+            for k in topks:
+                results[f"HR@{k}"] = results[f"HR@{k} after attack"] = float("nan")
+            results["n_eval_users"] = 0
+            return results
+        res = full_catalog_topk(model, users, ptr_d, idx_d, tg_d, K=K, to_host=False)
+        res_f = full_catalog_topk(model_fake, users, ptr_d, idx_d, tg_d, K=K, to_host=False)
+        hits, hits_f = hit_counts(res["target_rank"], topks), hit_counts(res_f["target_rank"], topks)
+        shift = pred_shift(res["target_score"], res_f["target_score"])
+        packed = torch.cat([hits.double().view(-1), hits_f.double().view(-1), shift]).cpu().numpy()   # the ONE read-back
+        h = packed[: T * len(topks)].reshape(T, len(topks)).sum(axis=0)
+        hf = packed[T * len(topks): 2 * T * len(topks)].reshape(T, len(topks)).sum(axis=0)
+        results["pred_shift"] = float(packed[-2])
+        for i, k in enumerate(topks):
+            results[f"HR@{k}"] = float(h[i] / (n * T))
+            results[f"HR@{k} after attack"] = float(hf[i] / (n * T))
+        results["n_eval_users"] = n
+        self.last_eval = {"users": users, "clean": res, "poisoned": res_f}
         return results
 
     # ------------------------------------------------------------------ normal.py:162-225

@@ -1097,3 +1097,47 @@ def test_spmm_scratch_is_per_user(gpu_device):
         torch.cuda.synchronize()
         for k in range(2):
             assert G.relerr(outs[k].cpu().numpy(), refs[k]) < 2e-6, (rep, k)
+
+
+def test_get_users_rating_vs_oracle(gpu_device):
+    """a6: LightGCN.getUsersRating (lightgcn.py:115-120) = sigmoid(U_b . I^T) on the build's fp32-MFMA GEMM."""
+    g = G.load("lightgcn_game_d64_tg")
+    m, _ = _make_lgn(g, gpu_device)
+    U, I, L = int(g["n_users"]), int(g["n_items"]), int(g["layers"])
+    users = torch.tensor([0, 5, 17, 3178, 5, 1024, 77], device=gpu_device)
+    out = m.getUsersRating(users)
+    assert tuple(out.shape) == (7, I) and out.dtype == torch.float32
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    light = orc.lightgcn_propagate(csr, u0, i0, L)
+    s = orc.score_rows(light[users.cpu().numpy()], light[U:]).astype(np.float64)
+    ref = 1.0 / (1.0 + np.exp(-s))
+    assert np.abs(out.cpu().numpy() - ref).max() < 3e-7
+    # same ranking as the evaluation path (sigmoid is monotone): argmax per row agrees with the raw scores
+    assert np.array_equal(out.cpu().numpy().argmax(1), s.argmax(1))
+    # computer() hands out copies: a later train step must not change them
+    lu, li = m.computer()
+    keep = lu.clone()
+    m.train_step()
+    assert torch.equal(lu, keep)
+
+
+def test_device_eval_plumbing(gpu_device):
+    """f3: the target-present filter and the pred_shift reduction on the device equal the host restatements."""
+    from recad_amd.evaluate import eligible_users, eligible_users_device, pred_shift
+    rng = np.random.default_rng(9)
+    U, I = 5000, 700
+    deg = rng.integers(0, 30, U)
+    deg[rng.integers(0, U, 200)] = 0
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(deg)
+    idx = np.concatenate([np.sort(rng.choice(I, size=k, replace=False)) for k in deg]).astype(np.int32)
+    for targets in ([3], [0, 699, 41], []):
+        ref = eligible_users(ptr, idx, np.asarray(targets, dtype=np.int32))
+        got, _, _, _ = eligible_users_device(ptr, idx, np.asarray(targets, dtype=np.int32), gpu_device)
+        assert np.array_equal(got.cpu().numpy(), ref), targets
+    a = rng.standard_normal((3001, 3)).astype(np.float32)
+    b = rng.standard_normal((3001, 3)).astype(np.float32)
+    out = pred_shift(torch.from_numpy(a).to(gpu_device), torch.from_numpy(b).to(gpu_device)).cpu().numpy()
+    ref = np.mean(b.astype(np.float64) - a.astype(np.float64))
+    assert abs(out[0] - ref) <= 1e-12 + 1e-12 * abs(ref) * a.size
