@@ -94,6 +94,7 @@ _SIGNATURES = {
     "rk_lightgcn_prepare": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
+    "rk_score_topk_scratch_floats": [_I32, _I32, _I32, _I32, _I32],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
     "rk_bpr_sample": [_I32, _I32, _P, _P, _I64, C.c_uint64, _P, _P, _P, _P, _P],
     "rk_pointwise_sample": [_I32, _I32, _P, _P, _I64, _I32, C.c_uint64, _P, _P, _P, _P],
@@ -107,7 +108,7 @@ _SIGNATURES = {
     "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,
                           _F, _P, _I32, _P],
 }
-_RESTYPES = {"rk_last_error": C.c_char_p}
+_RESTYPES = {"rk_last_error": C.c_char_p, "rk_score_topk_scratch_floats": C.c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 

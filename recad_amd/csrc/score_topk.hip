@@ -8,19 +8,9 @@
 #include <climits>
 
 #include "gemm.h"
+#include "score_select.h"
 
 // ---------------------------------------------------------------- pass 2
-__device__ __forceinline__ unsigned score_key(float s)
-{
-    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf).  -0.0 is
-    // folded onto +0.0 so that key equality is float equality (the oracle compares floats).
-    if (s == -INFINITY) return 0u;
-    unsigned u = __float_as_uint(s);
-    if (u == 0x80000000u) u = 0u;
-    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return k == 0u ? 1u : k;
-}
-
 static constexpr int kMaxK = 256;
 static constexpr int kTopkNT = 256;      // threads per user row
 static constexpr int kInPassTargets = 4; // targets ranked inside the histogram pass
@@ -50,12 +40,6 @@ __device__ __forceinline__ void find_bin(const int *hist, int need, int tid, int
         }
     }
     __syncthreads();
-}
-
-__device__ __forceinline__ float key_score(unsigned k)
-{
-    // inverse of score_key for every finite score and +inf (-0.0 comes back as +0.0)
-    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
 // One 256-thread workgroup per user row.
@@ -377,6 +361,23 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     return RK_OK;
 }
 
+// Which path rk_score_topk takes for a request, and the scratch it needs (floats): the fused sweep
+// (score_select.h: no score matrix, 2*512 floats of candidate slots per user) whenever K <= 256 and at most 4
+// targets; otherwise GEMM + selection over a materialised [nb, n_items] matrix.  RK_SEL_OFF=1 forces the latter
+// (A/B and tests).
+static bool use_fused(int n_items, int dim, int K, int n_targets)
+{
+    const char *e = getenv("RK_SEL_OFF");  // read per call: the tests flip it to run both paths in one process
+    return !(e && atoi(e)) && sel_supported(n_items, dim, K, n_targets);
+}
+
+RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
+{
+    if (nb <= 0 || n_items <= 0) return 0;
+    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)nb * kSelC * 2;
+    return (int64_t)nb * n_items;
+}
+
 RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
                             int32_t n_items, const float *ubias, const float *ibias, float mean,
                             const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
@@ -387,7 +388,21 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
     if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
         RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
     if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
+    if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
+    if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
+        RK_FAIL(RK_EINVAL, "top-K: bad targets");
     hipStream_t s = (hipStream_t)stream;
+    if (use_fused(n_items, dim, K, n_targets) && (reinterpret_cast<uintptr_t>(scratch) & 7) == 0) {
+        SelArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nb = nb; a.n_items = n_items; a.d = dim; a.K = K;
+        a.utab = utab; a.user_ids = user_ids; a.itab = itab; a.ubias = ubias; a.ibias = ibias; a.mean = mean;
+        a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
+        a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
+        a.cand = reinterpret_cast<unsigned long long *>(scratch);
+        RK_HIP(score_select_launch(a, s));
+        return RK_OK;
+    }
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = nb; g.N = n_items; g.K = dim;

@@ -13,7 +13,9 @@ from . import _lib
 def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096, to_host=True):
     """For every user in user_ids (int array): top-K unseen items and the score/rank of each target.
 
-    seen_ptr/seen_idx: CSR (indexed by user id) of the items to exclude (the train items).
+    seen_ptr/seen_idx: CSR (indexed by user id) of the items to exclude (the train items), item ids ASCENDING
+    within a user (dataset.train_csr_sorted()): the fused sweep walks each list with a cursor.  Host arrays are
+    checked and sorted here when needed; device tensors are taken as sorted.
     Returns dict of arrays top_ids[n,K], top_scores[n,K], target_score[n,T], target_rank[n,T]: host numpy
     arrays, or (to_host=False) device tensors left in HBM, no synchronisation.
     """
@@ -31,6 +33,12 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
         n_items = victim.num_items
     as_dev = lambda a: (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
                         else torch.as_tensor(np.asarray(a), dtype=torch.int32, device=dev)).contiguous()
+    if not torch.is_tensor(seen_idx) and len(seen_idx) > 1:
+        sp, si = np.asarray(seen_ptr).astype(np.int64), np.asarray(seen_idx)
+        row = np.repeat(np.arange(len(sp) - 1, dtype=np.int64), np.diff(sp))
+        key = row * (int(si.max()) + 1) + si
+        if not bool(np.all(key[1:] >= key[:-1])):
+            seen_idx = si[np.argsort(key, kind="stable")]
     user_ids_t, seen_ptr_t, seen_idx_t = as_dev(user_ids), as_dev(seen_ptr), as_dev(seen_idx)
     if seen_idx_t.numel() == 0:
         seen_idx_t = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -41,7 +49,14 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     tscore = torch.empty(n, max(T, 1), dtype=torch.float32, device=dev)
     trank = torch.empty(n, max(T, 1), dtype=torch.int32, device=dev)
     chunk = max(1, min(chunk, n))
-    scratch = torch.empty(chunk * n_items, dtype=torch.float32, device=dev)
+    if dot:
+        # fused sweep (K <= 256, <= 4 targets): candidate slots only, so the whole user list goes in ONE call
+        per_user = int(_lib.lib().rk_score_topk_scratch_floats(1, n_items, d, K, T))
+        if per_user < n_items:
+            chunk = n
+        scratch = torch.empty(chunk * per_user, dtype=torch.float32, device=dev)
+    else:
+        scratch = torch.empty(chunk * n_items, dtype=torch.float32, device=dev)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         ids = user_ids_t[s:e]

@@ -161,11 +161,24 @@ def test_lightgcn_eval_golden(gpu_device, name):
     _eval_against_golden(g, m, gpu_device)
 
 
-@pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False)])
-def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
+@pytest.fixture
+def unfused_scoring():
+    """RK_SEL_OFF=1: rk_score_topk takes the GEMM + selection path over a materialised score matrix."""
+    import os
+    os.environ["RK_SEL_OFF"] = "1"
+    yield
+    os.environ.pop("RK_SEL_OFF", None)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
+def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request):
     """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
-    so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first)."""
+    so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first) -- on the fused sweep
+    (no score matrix) and on the GEMM + selection path."""
     from recad_amd import _lib
+    if not fused:
+        request.getfixturevalue("unfused_scoring")
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
@@ -189,7 +202,7 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
     top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
     ts = torch.empty(nb, 3, dtype=torch.float32, device=dev)
     tr = torch.empty(nb, 3, dtype=torch.int32, device=dev)
-    scratch = torch.empty(nb * I, dtype=torch.float32, device=dev)
+    scratch = torch.empty(max(nb * I, nb * 1024), dtype=torch.float32, device=dev)
     tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
     ids = t(user_ids, torch.int32)
     sp, si, tg = t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(targets, torch.int32)
@@ -197,13 +210,15 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias):
                                         _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 3,
                                         _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids] if with_bias else None, ib, 0.25 if with_bias else 0.0)
-    got_scores = scratch.view(nb, I).cpu().numpy()
+    assert int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, 3)) == (nb * 1024 if fused else nb * I)
+    got_scores = None if fused else scratch[: nb * I].view(nb, I).cpu().numpy()
     top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         seen = seen_lists[int(user_ids[b])]
         unseen = np.ones(I, dtype=bool)
         unseen[seen] = False
-        assert np.array_equal(got_scores[b][unseen], ref_scores[b][unseen]), f"row {b}: MFMA != fmaf chain"
+        if got_scores is not None:
+            assert np.array_equal(got_scores[b][unseen], ref_scores[b][unseen]), f"row {b}: MFMA != fmaf chain"
         rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen, K, targets)
         assert np.array_equal(top_ids[b], rid), b
         assert np.array_equal(top_sc[b], rsc), b
@@ -1141,3 +1156,86 @@ def test_device_eval_plumbing(gpu_device):
     out = pred_shift(torch.from_numpy(a).to(gpu_device), torch.from_numpy(b).to(gpu_device)).cpu().numpy()
     ref = np.mean(b.astype(np.float64) - a.astype(np.float64))
     assert abs(out[0] - ref) <= 1e-12 + 1e-12 * abs(ref) * a.size
+
+
+def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, targets):
+    """rk_score_topk through the C-ABI on host arrays -> (top_ids, top_scores, target_score, target_rank)"""
+    from recad_amd import _lib
+    nu, d = utab.shape
+    I = itab.shape[0]
+    nb, T = len(user_ids), len(targets)
+    seen_ptr = np.zeros(nu + 1, dtype=np.int32)
+    seen_ptr[1:] = np.cumsum([len(s) for s in seen_lists])
+    seen_idx = np.concatenate(seen_lists + [np.zeros(0, np.int32)]).astype(np.int32)
+    if len(seen_idx) == 0:
+        seen_idx = np.zeros(1, np.int32)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=dev).contiguous() if a is not None else None
+    top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev)
+    top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
+    ts = torch.empty(nb, max(T, 1), dtype=torch.float32, device=dev)
+    tr = torch.empty(nb, max(T, 1), dtype=torch.int32, device=dev)
+    need = int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, T))
+    scratch = torch.empty(max(need, 2), dtype=torch.float32, device=dev)
+    tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
+    ids, sp, si, tg = t(user_ids, torch.int32), t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(np.asarray(targets, np.int32), torch.int32)
+    _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(ids), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), float(mean),
+                                        _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg) if T else None, T,
+                                        _lib.ptr(ts) if T else None, _lib.ptr(tr) if T else None, _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+    return top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy()[:, :T], tr.cpu().numpy()[:, :T]
+
+
+@pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
+@pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
+def test_fused_sweep_stress(gpu_device, kind, I, K, T, config):
+    """The fused scoring + selection sweep (score_select.h) on rows built to stress its threshold logic: constant
+    and few-valued rows (every score ties), scores ascending with the item id (every item beats the running
+    threshold: repeated compactions), descending, long runs of seen items inside one tile, rows with fewer than
+    K unseen items -- bit-identical lists, scores and ranks to the oracle's scan (ties: lower id first).
+    The scores are made of exact pieces (zero dot product + item bias) where the pattern matters."""
+    import os
+    rng = np.random.default_rng(I + K)
+    nu, d = 90, 16
+    if config:
+        os.environ["RK_SEL_CONFIG"] = str(config)   # force the 16-row / 64-row workgroup shape
+    try:
+        utab = np.zeros((nu, d), np.float32)
+        itab = np.zeros((I, d), np.float32)
+        ub = np.zeros(nu, np.float32)
+        if kind == "const":
+            ib = np.full(I, 3.0, np.float32)
+        elif kind == "two_values":
+            ib = rng.choice(np.array([3.0, 3.0000002], np.float32), size=I)
+        elif kind == "quantised":
+            ib = (rng.integers(-40, 40, I) / 8.0).astype(np.float32)
+        elif kind == "ascending":
+            ib = (np.arange(I) * 0.25).astype(np.float32)
+        elif kind == "descending":
+            ib = (-(np.arange(I) // 3) * 0.5).astype(np.float32)
+        else:
+            utab = rng.standard_normal((nu, d), dtype=np.float32)
+            itab = rng.standard_normal((I, d), dtype=np.float32)
+            ib = rng.standard_normal(I, dtype=np.float32)
+            ub = rng.standard_normal(nu, dtype=np.float32)
+        if kind == "mostly_seen":
+            seen = [np.sort(rng.choice(I, size=I - int(rng.integers(0, min(I, 150))), replace=False)).astype(np.int32) for _ in range(nu)]
+        elif kind == "dense_seen":
+            seen = []
+            for _ in range(nu):
+                lo = int(rng.integers(0, max(1, I - 300)))
+                run = np.arange(lo, min(I, lo + int(rng.integers(1, 300))))
+                extra = rng.choice(I, size=min(I, 20), replace=False)
+                seen.append(np.unique(np.concatenate([run, extra])).astype(np.int32))
+        else:
+            seen = [np.sort(rng.choice(I, size=int(rng.integers(0, min(I, 60))), replace=False)).astype(np.int32) for _ in range(nu)]
+        user_ids = rng.permutation(nu)[:77].astype(np.int32)
+        targets = np.array([3, I - 1, I // 2, 17][:T], dtype=np.int32)
+        ti, tsc, ts, tr = _score_topk_call(gpu_device, utab, itab, ub, ib, 0.5, user_ids, seen, K, targets)
+        ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids], ib, 0.5)
+        for b in range(len(user_ids)):
+            rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen[int(user_ids[b])], K, targets)
+            assert np.array_equal(ti[b], rid), (kind, b)
+            assert np.array_equal(tsc[b], rsc), (kind, b)
+            if T:
+                assert np.array_equal(ts[b], rts) and np.array_equal(tr[b], rtr), (kind, b)
+    finally:
+        os.environ.pop("RK_SEL_CONFIG", None)
