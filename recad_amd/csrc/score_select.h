@@ -65,61 +65,86 @@ struct SelArgs {
     float *target_score;
     int *target_rank;
     unsigned long long *cand;     // [nb][kSelC] scratch
+    int *cand_cnt;                // [nb] scratch
     int id_bits;                  // item ids < 2^id_bits
+    unsigned long long *stamps;   // diagnostic build (RK_SEL_STAMPS) only: [grid][8] cycle sums of wave 0
 };
 
 __host__ __device__ inline int sel_row_stride(int d) { return ((d + kSelKC - 1) / kSelKC) * kSelKC + 4; }
 
-// K-th largest of the (distinct) composites held 8 per lane (unused slots 0), n_valid >= K: returns T with
-// exactly K composites >= T.  The 32 key bits are always resolved (T >> 32 is the exact K-th key); the id
-// bits above id_bits are ones in every entry.
-__device__ __forceinline__ unsigned long long wave_kth_composite(const unsigned long long (&c)[8], int K, int id_bits)
+// Threshold search over the (distinct) composites held 8 per lane (unused slots 0), n_valid >= K.  Bit-wise binary
+// search from the top: T grows while at least K composites stay >= T.  After `min_bits` bits it stops as soon as at
+// most `limit` composites are >= T (a COARSE threshold: cheap, and any T with count >= K is a valid pruning bound);
+// with limit == K it runs to the exact K-th composite (early exit once the count is exactly K).  Key bits are
+// searched on the high words alone (32-bit compares); the id bits above id_bits are ones in every entry.
+// Returns T; *cnt_out = #(composite >= T).
+__device__ __forceinline__ unsigned long long wave_threshold(const unsigned long long (&c)[8], int n, int K, int limit, int min_bits,
+                                                             int id_bits, int *cnt_out)
 {
-    unsigned long long T = 0ULL;
-    for (int bit = 63; bit >= 32; --bit) {
-        const unsigned long long trial = T | (1ULL << bit);
+    unsigned hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hi[j] = (unsigned)(c[j] >> 32);
+    unsigned Tk = 0u;
+    int cntT = n, done_bits = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        if (done_bits >= min_bits && cntT <= limit) { *cnt_out = cntT; return (unsigned long long)Tk << 32; }
+        const unsigned trial = Tk | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(c[j] >= trial));
-        if (cnt >= K) T = trial;
+        for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(hi[j] >= trial));
+        if (cnt >= K) { Tk = trial; cntT = cnt; }
+        ++done_bits;
     }
-    if (id_bits < 32) T |= (0xffffffffULL >> id_bits) << id_bits;   // ~id has these bits set in every entry
+    unsigned long long T = (unsigned long long)Tk << 32;
+    if (cntT <= limit) { *cnt_out = cntT; return T; }
+    // more than `limit` entries share the K-th key: resolve the tie on the (inverted) item ids
+    if (id_bits < 32) T |= (0xffffffffULL >> id_bits) << id_bits;
     for (int bit = (id_bits < 32 ? id_bits : 32) - 1; bit >= 0; --bit) {
         const unsigned long long trial = T | (1ULL << bit);
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(c[j] >= trial));
-        if (cnt >= K) T = trial;
-        if (cnt == K) break;
+        if (cnt >= K) { T = trial; cntT = cnt; }
+        if (cntT <= limit) break;
     }
+    *cnt_out = cntT;
     return T;
 }
 
-// One wave: compact the candidate list of a row (n entries in global memory, n <= kSelC) to its top K
-// composites, in place; returns the new count (min(n, K)) and the new threshold key through *tau_out.
+// One wave: shrink the candidate list of a row (n entries in global memory, kSelC - kSelTN < n <= kSelC) in place
+// to the entries at or above a threshold T that at least K of them reach (at most K + 64 unless more than that are
+// tied at the K-th key and id); returns the new count, the new pruning bound (T's key) through *tau_out.
 __device__ __forceinline__ int wave_compact_row(unsigned long long *__restrict__ row, int n, int K, int id_bits, int lane,
-                                                unsigned *tau_out, unsigned long long (&c)[8])
+                                                unsigned *tau_out)
 {
+    unsigned long long c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = (j * 64 + lane < n) ? row[j * 64 + lane] : 0ULL;
     if (n <= K) { *tau_out = 0u; return n; }
-    const unsigned long long T = wave_kth_composite(c, K, id_bits);
+    int cnt = n;
+    const int limit = K + 64 < kSelC - 2 * kSelTN ? K + 64 : K;   // leave room for two more tiles when K is large
+    const unsigned long long T = wave_threshold(c, n, K, limit, 12, id_bits, &cnt);
     int base = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const bool keep = c[j] >= T;
+        const bool keep = c[j] >= T && c[j] != 0ULL;
         const unsigned long long m = __ballot(keep);
         if (keep) row[base + __popcll(m & ((1ULL << lane) - 1ULL))] = c[j];
         base += __popcll(m);
     }
     *tau_out = (unsigned)(T >> 32);
-    return K;
+    return base;
 }
 
 // WM rows per wave (16 or 32), WAVES_M waves along the rows; 4 waves along the 128 items of a tile.
 // NTG: targets ranked inside the sweep (1 or kSelMaxT: a separate instantiation keeps the common one-target
-// evaluation free of three dead compare chains per score).
-template <int WM, int WAVES_M, int NTG>
+// evaluation free of three dead compare chains per score).  NCH: k-chunks of 32 (dim <= 32 * NCH).
+//
+// Operand traffic: the workgroup's user rows never change, so every lane keeps ITS A operands of the whole
+// sweep in registers (A[row = lane&15][k = (lane>>4) + 4j], 8*NCH floats per 16-row block) -- no LDS reads for
+// A at all.  The item tile is stored k-permuted ((k%4)*8 + k/4 inside a 32-chunk) so that the 8 B operands a
+// lane needs for one chunk are 32 contiguous bytes: two ds_read_b128 per 16-column block and chunk.
+template <int WM, int WAVES_M, int NTG, int NCH>
 __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelArgs a)
 {
     constexpr int RB = WM * WAVES_M, NW = WAVES_M * 4, NT = NW * 64, BM = WM / 16, RPL = BM * 4;  // rows per lane
@@ -130,11 +155,10 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
     const int wm = w >> 2, wn = w & 3;
     const int l16 = lane & 15, lq = lane >> 4;
     const int SA = sel_row_stride(a.d);
-    float *sA = smem;                                   // [RB][SA]
-    float *sB = smem + (size_t)RB * SA;                 // [2][128][kSelLdB]
+    float *sB = smem;                                   // [2][128][kSelLdB], k-permuted chunks
+    float *sA = smem;                                   // prologue only: [RB][SA] user rows, then the target rows
     const int row0 = blockIdx.x * RB;
     const int n_in = a.n_targets;                       // <= kSelMaxT (host-checked)
-    const int n_chunks = (a.d + kSelKC - 1) / kSelKC;
     const int n_tiles = (a.n_items + kSelTN - 1) / kSelTN;
 
     // ---- prologue: row metadata, user rows -> LDS (zero-padded), target scores
@@ -157,67 +181,83 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
         const int u = sUid[r];
         sA[i] = (u >= 0 && k < a.d) ? a.utab[(size_t)u * a.d + k] : 0.f;
     }
+    float *sT = sA + (size_t)RB * SA;                   // target item rows [n_in][d]
+    for (int i = tid; i < n_in * a.d; i += NT) sT[i] = a.itab[(size_t)a.targets[i / a.d] * a.d + i % a.d];
     __syncthreads();
+    // this lane's A operands for the whole sweep
+    float areg[BM][NCH * 8];
+#pragma unroll
+    for (int i = 0; i < BM; ++i)
+#pragma unroll
+        for (int q = 0; q < NCH * 8; ++q) areg[i][q] = sA[(wm * WM + i * 16 + l16) * SA + (q >> 3) * kSelKC + lq + 4 * (q & 7)];
+    // target scores (before masking, normal.py:83-85): one thread per (row, target) runs the MFMA's k-ordered chain
     for (int i = tid; i < RB * kSelMaxT; i += NT) {
         const int r = i / kSelMaxT, t = i % kSelMaxT;
         unsigned key = 0xffffffffu;
         if (t < n_in && sUid[r] >= 0) {
             const int tg = a.targets[t];
-            const float *iv = a.itab + (size_t)tg * a.d;
+            const float *iv = sT + t * a.d, *av = sA + r * SA;
             float s = 0.f;
-            for (int k = 0; k < a.d; ++k) s = fmaf(sA[r * SA + k], iv[k], s);   // the MFMA's k-ordered chain
+            for (int k = 0; k < a.d; ++k) s = fmaf(av[k], iv[k], s);
             if (a.ubias) s = ((s + a.ubias[sUid[r]]) + a.ibias[tg]) + a.mean;
-            a.target_score[(size_t)(row0 + r) * a.n_targets + t] = s;            // before masking (normal.py:83-85)
+            a.target_score[(size_t)(row0 + r) * a.n_targets + t] = s;
             key = score_key(s);
         }
         sTkey[r][t] = key;
     }
-    __syncthreads();
+    __syncthreads();   // sA / sT are dead from here on: the region becomes the item tile
 
     // per-lane constants: the rows this lane's accumulator registers belong to
     unsigned tkey[RPL][NTG];
     int cntr[RPL][NTG];
     int tgt[NTG];
     float ubr[RPL];
+    bool rok[RPL];
 #pragma unroll
     for (int t = 0; t < NTG; ++t) tgt[t] = t < n_in ? a.targets[t] : -1;
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
         const int r = wm * WM + (q >> 2) * 16 + 4 * lq + (q & 3);
-        ubr[q] = (a.ubias && sUid[r] >= 0) ? a.ubias[sUid[r]] : 0.f;
+        rok[q] = sUid[r] >= 0;
+        ubr[q] = (a.ubias && rok[q]) ? a.ubias[sUid[r]] : 0.f;
 #pragma unroll
         for (int t = 0; t < NTG; ++t) { tkey[q][t] = sTkey[r][t]; cntr[q][t] = 0; }
     }
 
-    // B tile loader: 128 rows x 32 k = 1024 float4, NT threads
+    // B tile loader: 128 rows x 32 k = 1024 float4, NT threads; LDS image k-permuted
     constexpr int NLD = 1024 / NT;   // float4 per thread (4 or 2)
     float4 breg[NLD];
     const bool vec_ok = (a.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.itab) & 15) == 0);
+    const int ld_r = tid >> 3, ld_k4 = (tid & 7) * 4;            // first float4 of this thread; the others NT/8 rows on
     auto load_b = [&](int tile, int chunk) {
+        const bool fast = vec_ok && (tile + 1) * kSelTN <= a.n_items && (chunk + 1) * kSelKC <= a.d;   // workgroup-uniform
+        if (fast) {
+            const float *src = a.itab + (size_t)(tile * kSelTN + ld_r) * a.d + chunk * kSelKC + ld_k4;
 #pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            const int idx = p * NT + tid, r = idx >> 3, k4 = (idx & 7) * 4;
-            const int item = tile * kSelTN + r, k = chunk * kSelKC + k4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < a.n_items) {
-                const float *src = a.itab + (size_t)item * a.d + k;
-                if (vec_ok && k + 3 < a.d) v = *reinterpret_cast<const float4 *>(src);
-                else {
+            for (int p = 0; p < NLD; ++p) breg[p] = *reinterpret_cast<const float4 *>(src + (size_t)p * (NT / 8) * a.d);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int item = tile * kSelTN + ld_r + p * (NT / 8), k = chunk * kSelKC + ld_k4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item < a.n_items) {
+                    const float *src = a.itab + (size_t)item * a.d + k;
                     if (k < a.d) v.x = src[0];
                     if (k + 1 < a.d) v.y = src[1];
                     if (k + 2 < a.d) v.z = src[2];
                     if (k + 3 < a.d) v.w = src[3];
                 }
+                breg[p] = v;
             }
-            breg[p] = v;
         }
     };
     auto store_b = [&](int buf) {
-        float *dst = sB + (size_t)buf * kSelTN * kSelLdB;
+        // element k of a row goes to (k % 4) * 8 + k / 4: the float4 (k4 .. k4+3) lands at k4/4, 8 + k4/4, 16 + ..., 24 + ...
+        float *dst = sB + (size_t)buf * kSelTN * kSelLdB + ld_r * kSelLdB + (ld_k4 >> 2);
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
-            const int idx = p * NT + tid, r = idx >> 3, k4 = (idx & 7) * 4;
-            *reinterpret_cast<float4 *>(dst + r * kSelLdB + k4) = breg[p];
+            float *q = dst + p * (NT / 8) * kSelLdB;
+            q[0] = breg[p].x; q[8] = breg[p].y; q[16] = breg[p].z; q[24] = breg[p].w;
         }
     };
 
@@ -230,55 +270,70 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
     load_b(0, 0);
     store_b(0);
     __syncthreads();
-    const int total = n_tiles * n_chunks;
-    for (int it = 0; it < total; ++it) {
-        const int tile = it / n_chunks, chunk = it % n_chunks, cur = it & 1;
-        const bool more = it + 1 < total, last_chunk = chunk == n_chunks - 1;
+#ifdef RK_SEL_STAMPS
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
+#define RK_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[k] += t_ - st_prev; st_prev = t_; }
+#else
+#define RK_STAMP(k)
+#endif
+    int buf = 0;
+    for (int tile = 0; tile < n_tiles; ++tile) {
         const int n0 = tile * kSelTN;
         // seen ids of this tile: loads issued before the MFMAs, consumed after them
         int seen_id = 0x7fffffff;
-        const bool marker = chunk == 0 && tid < RB * 8;
+        const bool marker = tid < RB * 8;
         if (marker) {
             const int r = tid >> 3, pos = sCur[r] + (tid & 7);
             if (pos < sEnd[r]) seen_id = a.seen_idx[pos];
         }
-        if (more) load_b((it + 1) / n_chunks, (it + 1) % n_chunks);
-        const float *Bc = sB + (size_t)cur * kSelTN * kSelLdB;
-        const float *Ak = sA + chunk * kSelKC;
 #pragma unroll
-        for (int kk = 0; kk < kSelKC; kk += 4) {
-            float av[BM], bv[2];
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const bool more = chunk + 1 < NCH || tile + 1 < n_tiles;
+            if (more) load_b(chunk + 1 < NCH ? tile : tile + 1, chunk + 1 < NCH ? chunk + 1 : 0);
+            const float *Bc = sB + (size_t)buf * kSelTN * kSelLdB + (wn * 32 + l16) * kSelLdB + lq * 8;
+            float4 b0[2], b1[2];
 #pragma unroll
-            for (int i = 0; i < BM; ++i) av[i] = Ak[(wm * WM + i * 16 + l16) * SA + kk + lq];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bc[(wn * 32 + j * 16 + l16) * kSelLdB + kk + lq];
-#pragma unroll
-            for (int i = 0; i < BM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (marker) {
-            // mark this tile's seen items; the ids are sorted, so the consumed lanes of a row form a prefix
-            const int r = tid >> 3, j8 = tid & 7;
-            int curp = sCur[r];
-            const int endp = sEnd[r];
-            const int sub = (lane >> 3) * 8;
-            for (;;) {
-                const bool in = seen_id < n0 + kSelTN;
-                if (in) atomicOr(&sMask[tile & 1][r][(seen_id - n0) >> 5], 1u << ((seen_id - n0) & 31));
-                const unsigned long long m = __ballot(in);
-                const int c8 = __popc((unsigned)((m >> sub) & 0xffULL));
-                curp += c8;
-                if (c8 < 8) break;
-                seen_id = (curp + j8 < endp) ? a.seen_idx[curp + j8] : 0x7fffffff;
+            for (int j = 0; j < 2; ++j) {
+                b0[j] = *reinterpret_cast<const float4 *>(Bc + j * 16 * kSelLdB);
+                b1[j] = *reinterpret_cast<const float4 *>(Bc + j * 16 * kSelLdB + 4);
             }
-            if (j8 == 0) sCur[r] = curp;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 &bb = jj < 4 ? b0[j] : b1[j];
+                    const float bv = (jj & 3) == 0 ? bb.x : (jj & 3) == 1 ? bb.y : (jj & 3) == 2 ? bb.z : bb.w;
+#pragma unroll
+                    for (int i = 0; i < BM; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][chunk * 8 + jj], bv, acc[i][j], 0, 0, 0);
+                }
+            }
+            if (chunk == NCH - 1 && marker) {
+                // mark this tile's seen items; the ids are sorted, so the consumed lanes of a row form a prefix
+                const int r = tid >> 3, j8 = tid & 7;
+                int curp = sCur[r];
+                const int endp = sEnd[r];
+                const int sub = (lane >> 3) * 8;
+                for (;;) {
+                    const bool in = seen_id < n0 + kSelTN;
+                    if (in) atomicOr(&sMask[tile & 1][r][(seen_id - n0) >> 5], 1u << ((seen_id - n0) & 31));
+                    const unsigned long long m = __ballot(in);
+                    const int c8 = __popc((unsigned)((m >> sub) & 0xffULL));
+                    curp += c8;
+                    if (c8 < 8) break;
+                    seen_id = (curp + j8 < endp) ? a.seen_idx[curp + j8] : 0x7fffffff;
+                }
+                if (j8 == 0) sCur[r] = curp;
+            }
+            RK_STAMP(0)
+            if (more) store_b(buf ^ 1);
+            RK_STAMP(1)
+            __syncthreads();
+            RK_STAMP(2)
+            buf ^= 1;
         }
-        if (more) store_b(cur ^ 1);
-        __syncthreads();
-        if (!last_chunk) continue;
 
-        // ---- epilogue of the tile, straight from the accumulators
+        // ---- epilogue of the tile, straight from the accumulators (branch-free: one LDS atomic per row group)
         // accumulator register r of block (i, j) = row 4*(lane>>4) + r, column lane&15 of the 16x16 block
 #pragma unroll
         for (int i = 0; i < BM; ++i) {
@@ -286,30 +341,43 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
             for (int r = 0; r < 4; ++r) {
                 const int q = i * 4 + r;
                 const int rl = wm * WM + i * 16 + 4 * lq + r;
-                const int uid = sUid[rl];
                 const unsigned mask = sMask[tile & 1][rl][wn];
                 const unsigned tau = sTau[rl];
-                const float ub = ubr[q];
+                unsigned key[2];
+                bool app[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = n0 + wn * 32 + j * 16 + l16;
                     float s = acc[i][j][r];
                     acc[i][j][r] = 0.f;
-                    if (a.ubias) s = ((s + ub) + (col < a.n_items ? a.ibias[col] : 0.f)) + a.mean;
-                    const bool valid = uid >= 0 && col < a.n_items && !((mask >> (j * 16 + l16)) & 1u);
-                    const unsigned key = valid ? score_key(s) : 0u;
+                    if (a.ubias) s = ((s + ubr[q]) + (col < a.n_items ? a.ibias[col] : 0.f)) + a.mean;
+                    const bool valid = rok[q] && col < a.n_items && !((mask >> (j * 16 + l16)) & 1u);
+                    key[j] = valid ? score_key(s) : 0u;
 #pragma unroll
                     for (int t = 0; t < NTG; ++t)
-                        cntr[q][t] += (key != 0u && col != tgt[t] && (key > tkey[q][t] || (key == tkey[q][t] && col < tgt[t]))) ? 1 : 0;
-                    if (key > tau) {
-                        const int p = atomicAdd(&sCnt[rl], 1);
-                        a.cand[(size_t)(row0 + rl) * kSelC + p] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)col);
-                    }
+                        cntr[q][t] += (key[j] != 0u && col != tgt[t] && (key[j] > tkey[q][t] || (key[j] == tkey[q][t] && col < tgt[t]))) ? 1 : 0;
+                    app[j] = key[j] > tau;
+                }
+                // the 16 lanes of a row group reserve their slots with ONE atomic (lane l16 == 0); past the first tiles
+                // almost no score beats its row's threshold, so the whole block is skipped wave-uniformly
+                const unsigned long long m0 = __ballot(app[0]), m1 = __ballot(app[1]);
+                if ((m0 | m1) != 0ULL) {
+                    const unsigned g0 = (unsigned)(m0 >> (lq * 16)) & 0xffffu, g1 = (unsigned)(m1 >> (lq * 16)) & 0xffffu;
+                    const int n0g = __popc(g0), tot = n0g + __popc(g1);
+                    int base = 0;
+                    if (l16 == 0 && tot) base = atomicAdd(&sCnt[rl], tot);
+                    base = __shfl(base, lq * 16, 64);
+                    unsigned long long *dst = a.cand + (size_t)(row0 + rl) * kSelC + base;
+                    const unsigned below = (1u << l16) - 1u;
+                    if (app[0]) dst[__popc(g0 & below)] = ((unsigned long long)key[0] << 32) | (unsigned)(~(unsigned)(n0 + wn * 32 + l16));
+                    if (app[1]) dst[n0g + __popc(g1 & below)] = ((unsigned long long)key[1] << 32) | (unsigned)(~(unsigned)(n0 + wn * 32 + 16 + l16));
                 }
             }
         }
+        RK_STAMP(3)
         __syncthreads();
-        // ---- rows that could overflow with the next tile are compacted to their exact top K
+        RK_STAMP(4)
+        // ---- rows that could overflow with the next tile are shrunk to (about) their top K
         for (int i = tid; i < RB * 4; i += NT) sMask[tile & 1][i >> 2][i & 3] = 0u;
         bool need = false;
         for (int r = tid; r < RB; r += NT) need |= sCnt[r] > kSelC - kSelTN;
@@ -319,9 +387,8 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
             for (int r = w; r < RB; r += NW) {
                 const int n = sCnt[r];
                 if (n > kSelC - kSelTN) {   // wave-uniform
-                    unsigned long long c[8];
                     unsigned tau;
-                    const int m = wave_compact_row(a.cand + (size_t)(row0 + r) * kSelC, n, a.K, a.id_bits, lane, &tau, c);
+                    const int m = wave_compact_row(a.cand + (size_t)(row0 + r) * kSelC, n, a.K, a.id_bits, lane, &tau);
                     if (lane == 0) { sCnt[r] = m; sTau[r] = tau; }
                 }
             }
@@ -329,7 +396,11 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
             if (tid == 0) sNeed = 0;
             __syncthreads();
         }
+        RK_STAMP(5)
     }
+#ifdef RK_SEL_STAMPS
+    if (tid == 0 && a.stamps) { for (int k = 0; k < 6; ++k) a.stamps[blockIdx.x * 8 + k] = st_sum[k]; a.stamps[blockIdx.x * 8 + 6] = st_t0; a.stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime(); }
+#endif
 
     // ---- target ranks: per-lane counters -> 16-lane groups -> LDS (the 4 waves along the items add up)
 #pragma unroll
@@ -347,50 +418,125 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
         const int r = i / n_in, t = i % n_in;
         if (sUid[r] >= 0) a.target_rank[(size_t)(row0 + r) * a.n_targets + t] = sRank[r][t];
     }
+    // ---- the candidate lists (at most kSelC entries, at least min(K, #unseen)) go to sel_finalize_kernel
+    for (int r = tid; r < RB; r += NT)
+        if (row0 + r < a.nb) a.cand_cnt[row0 + r] = sCnt[r];
+}
 
-    // ---- final selection per row: exact top K, rank-sorted by (score desc, id asc) through LDS (sB is free now)
-    unsigned long long *sSort = reinterpret_cast<unsigned long long *>(sB) + (size_t)w * kSelMaxK;
-    for (int r = w; r < RB; r += NW) {
-        if (sUid[r] < 0) continue;   // wave-uniform
-        const unsigned long long *rowp = a.cand + (size_t)(row0 + r) * kSelC;
-        const int n = sCnt[r];
-        unsigned long long c[8];
+// One radix digit of a 256-bin histogram, scanned by wave 0 alone (4 bins per lane, shuffles only).  Finds the bin
+// holding the `need`-th largest entry: out[0] = bin, out[1] = how many entries of that bin are needed, out[2] =
+// entries in or above the bin.  Called by every thread; ends with a workgroup barrier.
+__device__ __forceinline__ void sel_find_bin(const int *hist, int need, int tid, int *out)
+{
+    if (tid < 64) {
+        const int4 v = *reinterpret_cast<const int4 *>(hist + 4 * tid);
+        const int own = v.x + v.y + v.z + v.w;
+        int inc = own;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = (j * 64 + lane < n) ? rowp[j * 64 + lane] : 0ULL;
-        unsigned long long T = 1ULL;   // every real composite is >= 2^32
-        if (n > a.K) T = wave_kth_composite(c, a.K, a.id_bits);
-        int m = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool keep = c[j] >= T;
-            const unsigned long long mk = __ballot(keep);
-            if (keep) sSort[m + __popcll(mk & ((1ULL << lane) - 1ULL))] = c[j];
-            m += __popcll(mk);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_down(inc, o, 64);
+            if (tid + o < 64) inc += n;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int *out_ids = a.top_ids + (size_t)(row0 + r) * a.K;
-        float *out_sc = a.top_scores + (size_t)(row0 + r) * a.K;
-        for (int e = lane; e < m; e += 64) {
-            const unsigned long long mine = sSort[e];
-            int rank = 0;
-            for (int j = 0; j < m; ++j) rank += sSort[j] > mine ? 1 : 0;
-            out_ids[rank] = (int)(~(unsigned)(mine & 0xffffffffULL));
-            out_sc[rank] = key_score((unsigned)(mine >> 32));
+        const int above = inc - own;
+        if (above < need && need <= above + own) {
+            int cum = above, bin = 4 * tid + 3, h = v.w;
+            if (need > cum + h) { cum += h; bin = 4 * tid + 2; h = v.z; }
+            if (need > cum + h) { cum += h; bin = 4 * tid + 1; h = v.y; }
+            if (need > cum + h) { cum += h; bin = 4 * tid; h = v.x; }
+            out[0] = bin; out[1] = need - cum; out[2] = cum + h;
         }
-        for (int e = m + lane; e < a.K; e += 64) { out_ids[e] = -1; out_sc[e] = -INFINITY; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+}
+
+// Final selection: one 256-thread workgroup per user row.  The row's candidates (distinct 64-bit composites
+// key << 32 | ~id, n <= kSelC) are staged in LDS; while more than 256 of them could still belong to the top K,
+// 8-bit radix rounds over the composite (most significant byte first) narrow the set; then every thread
+// rank-sorts one survivor by counting the composites above it -- (score desc, id asc) exactly like the oracle.
+__global__ __launch_bounds__(256) void sel_finalize_kernel(const unsigned long long *__restrict__ cand, const int *__restrict__ cand_cnt,
+                                                           int K, int *__restrict__ top_ids, float *__restrict__ top_scores)
+{
+    __shared__ unsigned long long ent[kSelC];
+    __shared__ unsigned long long sel[256];
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ int sh[4];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int n = min(cand_cnt[b], kSelC);
+    for (int i = tid; i < n; i += 256) ent[i] = cand[(size_t)b * kSelC + i];
+    if (tid == 0) { sh[3] = 0; }
+    __syncthreads();
+    unsigned long long lower = 0ULL;   // survivors: composites >= lower
+    int n_sel = n;
+    if (n > 256) {
+        unsigned long long prefix = 0ULL, mask = 0ULL;
+        int need = K, shift = 64, n_cand = n;
+        while (n_cand > 256 && shift > 0) {
+            shift -= 8;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long c = ent[i];
+                if ((c & mask) == prefix) atomicAdd(&hist[(int)((c >> shift) & 255ULL)], 1);
+            }
+            __syncthreads();
+            sel_find_bin(hist, need, tid, sh);
+            const int n_gt = K - need;          // composites strictly above the old prefix range
+            prefix |= (unsigned long long)sh[0] << shift;
+            mask |= 255ULL << shift;
+            n_cand = n_gt + sh[2];
+            need = sh[1];
+            __syncthreads();
+        }
+        lower = prefix;
+        n_sel = n_cand;   // <= 256 (composites are distinct: with all 64 bits resolved exactly K remain)
+    }
+    if (n <= 256) {
+        if (tid < n) sel[tid] = ent[tid];
+        if (tid == 0) sh[3] = n;
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const unsigned long long c = ent[i];
+            if (c >= lower && c != 0ULL) sel[atomicAdd(&sh[3], 1)] = c;
+        }
+    }
+    __syncthreads();
+    n_sel = sh[3];
+    if (tid < n_sel) {
+        const unsigned long long mine = sel[tid];
+        int rank = 0;
+        for (int j = 0; j < n_sel; ++j) rank += sel[j] > mine ? 1 : 0;
+        if (rank < K) {
+            top_ids[(size_t)b * K + rank] = (int)(~(unsigned)(mine & 0xffffffffULL));
+            top_scores[(size_t)b * K + rank] = key_score((unsigned)(mine >> 32));
+        }
+    }
+    for (int k = n_sel + tid; k < K; k += 256) {
+        top_ids[(size_t)b * K + k] = -1;
+        top_scores[(size_t)b * K + k] = -INFINITY;
     }
 }
 
-inline size_t sel_lds_bytes(int rb, int d) { return sizeof(float) * ((size_t)rb * sel_row_stride(d) + 2 * (size_t)kSelTN * kSelLdB); }
+inline size_t sel_lds_bytes(int rb, int d)
+{
+    // the sweep needs the double-buffered item tile; the prologue aliases it with the user rows + target rows
+    const size_t tile = 2 * (size_t)kSelTN * kSelLdB, pro = (size_t)rb * sel_row_stride(d) + (size_t)kSelMaxT * d;
+    return sizeof(float) * (tile > pro ? tile : pro);
+}
 
-// whether the fused path applies to a request
+// whether the fused path applies to a request (dim <= 128: the A operands of the whole sweep live in registers)
 inline bool sel_supported(int n_items, int d, int K, int n_targets)
 {
-    return K >= 1 && K <= kSelMaxK && n_targets <= kSelMaxT && d >= 1 && d <= 256 && n_items >= 1;
+    return K >= 1 && K <= kSelMaxK && n_targets <= kSelMaxT && d >= 1 && d <= 128 && n_items >= 1;
+}
+
+template <int WM, int WAVES_M, int NTG>
+inline void sel_launch_nch(const SelArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t s)
+{
+    const int nch = (a.d + kSelKC - 1) / kSelKC;
+    if (nch <= 1) hipLaunchKernelGGL((score_select_kernel<WM, WAVES_M, NTG, 1>), grid, block, lds, s, a);
+    else if (nch == 2) hipLaunchKernelGGL((score_select_kernel<WM, WAVES_M, NTG, 2>), grid, block, lds, s, a);
+    else if (nch == 3) hipLaunchKernelGGL((score_select_kernel<WM, WAVES_M, NTG, 3>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((score_select_kernel<WM, WAVES_M, NTG, 4>), grid, block, lds, s, a);
 }
 
 inline hipError_t score_select_launch(SelArgs a, hipStream_t s)
@@ -402,25 +548,18 @@ inline hipError_t score_select_launch(SelArgs a, hipStream_t s)
     const int force = fe ? atoi(fe) : 0;
     // small user blocks: 16 rows per workgroup so that the chip is filled; large ones: 64 rows (4x less item traffic per flop)
     const bool small = force ? force == 1 : ((long long)(a.nb + 63) / 64 < 512);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fns[4] = {reinterpret_cast<const void *>(score_select_kernel<16, 1, 1>), reinterpret_cast<const void *>(score_select_kernel<16, 1, kSelMaxT>),
-                              reinterpret_cast<const void *>(score_select_kernel<32, 2, 1>), reinterpret_cast<const void *>(score_select_kernel<32, 2, kSelMaxT>)};
-        for (const void *f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
     const bool one = a.n_targets <= 1;
     if (small) {
         const dim3 grid((a.nb + 15) / 16), block(256);
-        if (one) hipLaunchKernelGGL((score_select_kernel<16, 1, 1>), grid, block, sel_lds_bytes(16, a.d), s, a);
-        else hipLaunchKernelGGL((score_select_kernel<16, 1, kSelMaxT>), grid, block, sel_lds_bytes(16, a.d), s, a);
+        if (one) sel_launch_nch<16, 1, 1>(a, grid, block, sel_lds_bytes(16, a.d), s);
+        else sel_launch_nch<16, 1, kSelMaxT>(a, grid, block, sel_lds_bytes(16, a.d), s);
     } else {
         const dim3 grid((a.nb + 63) / 64), block(512);
-        if (one) hipLaunchKernelGGL((score_select_kernel<32, 2, 1>), grid, block, sel_lds_bytes(64, a.d), s, a);
-        else hipLaunchKernelGGL((score_select_kernel<32, 2, kSelMaxT>), grid, block, sel_lds_bytes(64, a.d), s, a);
+        if (one) sel_launch_nch<32, 2, 1>(a, grid, block, sel_lds_bytes(64, a.d), s);
+        else sel_launch_nch<32, 2, kSelMaxT>(a, grid, block, sel_lds_bytes(64, a.d), s);
     }
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(sel_finalize_kernel, dim3(a.nb), dim3(256), 0, s, a.cand, a.cand_cnt, a.K, a.top_ids, a.top_scores);
     return hipGetLastError();
 }

@@ -361,20 +361,25 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     return RK_OK;
 }
 
-// Which path rk_score_topk takes for a request, and the scratch it needs (floats): the fused sweep
-// (score_select.h: no score matrix, 2*512 floats of candidate slots per user) whenever K <= 256 and at most 4
-// targets; otherwise GEMM + selection over a materialised [nb, n_items] matrix.  RK_SEL_OFF=1 forces the latter
-// (A/B and tests).
+// Which path rk_score_topk takes for a request, and the scratch it needs (floats).
+//   fused sweep (score_select.h): no score matrix, 1025 floats of candidate slots per user; needs K <= 256, at most 4
+//     targets, dim <= 128.  Measured on MI355X it is the SLOWER of the two wherever the score matrix fits comfortably
+//     (5893 x 3702 x 64: 198 vs 98 us; 54617 x 34474 x 128: 10.5 vs 7.7 ms -- DESIGN.md 4.3), so it is chosen by
+//     default only for catalogues of >= 2^17 items, where a block of users no longer fits a sensible score matrix;
+//   GEMM + selection over a materialised [nb, n_items] matrix otherwise.
+// RK_SEL_FORCE=1 forces the fused sweep wherever it is supported, RK_SEL_OFF=1 forbids it (tests run both; read per call).
 static bool use_fused(int n_items, int dim, int K, int n_targets)
 {
-    const char *e = getenv("RK_SEL_OFF");  // read per call: the tests flip it to run both paths in one process
-    return !(e && atoi(e)) && sel_supported(n_items, dim, K, n_targets);
+    const char *off = getenv("RK_SEL_OFF"), *force = getenv("RK_SEL_FORCE");
+    if (off && atoi(off)) return false;
+    if (!sel_supported(n_items, dim, K, n_targets)) return false;
+    return (force && atoi(force)) || n_items >= (1 << 17);
 }
 
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
 {
     if (nb <= 0 || n_items <= 0) return 0;
-    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)nb * kSelC * 2;
+    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)nb * kSelC * 2 + nb;   // candidate slots + counts
     return (int64_t)nb * n_items;
 }
 
@@ -400,6 +405,11 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
         a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
         a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
         a.cand = reinterpret_cast<unsigned long long *>(scratch);
+        a.cand_cnt = reinterpret_cast<int *>(scratch + (size_t)nb * kSelC * 2);
+#ifdef RK_SEL_STAMPS
+        // diagnostic build: the stamps go behind the candidate scratch (the caller over-allocates it by 64 KiB)
+        a.stamps = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + (size_t)nb * kSelC * 2 + nb) + 63) & ~(uintptr_t)63);
+#endif
         RK_HIP(score_select_launch(a, s));
         return RK_OK;
     }

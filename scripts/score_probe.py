@@ -1,0 +1,56 @@
+"""Probe (tuning only): rk_score_topk per-call time, fused sweep vs GEMM + selection, on random tables.
+    python3 scripts/score_probe.py <n_users> <n_items> <dim> [reps]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from recad_amd import _lib
+
+nu, I, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+dev = torch.device('cuda:0')
+g = torch.Generator(device=dev).manual_seed(1)
+utab = torch.randn(nu, d, device=dev, generator=g) * 0.1
+itab = torch.randn(I, d, device=dev, generator=g) * 0.1
+rng = np.random.default_rng(0)
+deg = rng.integers(10, 150, nu)
+ptr = np.zeros(nu + 1, dtype=np.int32)
+ptr[1:] = np.cumsum(deg)
+idx = np.concatenate([np.sort(rng.choice(I, size=k, replace=False)) for k in deg]).astype(np.int32)
+ids = torch.arange(nu, dtype=torch.int32, device=dev)
+sp, si = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+tg = torch.tensor([0], dtype=torch.int32, device=dev)
+K = 100
+top_ids = torch.empty(nu, K, dtype=torch.int32, device=dev)
+top_sc = torch.empty(nu, K, device=dev)
+ts = torch.empty(nu, 1, device=dev)
+tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
+out = {}
+for mode in ("fused", "unfused"):
+    if mode == "unfused":
+        os.environ["RK_SEL_OFF"] = "1"
+    chunk = nu if mode == "fused" else max(256, min(8192, (1 << 31) // I))
+    need = int(_lib.lib().rk_score_topk_scratch_floats(min(chunk, nu), I, d, K, 1))
+    scratch = torch.empty(need, device=dev)
+
+    def once():
+        for s in range(0, nu, chunk):
+            e = min(nu, s + chunk)
+            _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), e - s, _lib.ptr(ids[s:e]), _lib.ptr(itab), I, None, None, 0.0, _lib.ptr(sp), _lib.ptr(si),
+                                                K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_sc[s:e]), _lib.ptr(tg), 1, _lib.ptr(ts[s:e]), _lib.ptr(tr[s:e]),
+                                                _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+    once(); once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out[mode] = (top_ids.clone(), tr.clone())
+    print(f"{mode:8s} {nu} x {I} x {d}: {ms * 1e3:9.1f} us per evaluation   {2.0 * nu * I * d / ms / 1e9:7.1f} TFLOP/s", flush=True)
+print("identical lists:", bool(torch.equal(out["fused"][0], out["unfused"][0])), "identical ranks:", bool(torch.equal(out["fused"][1], out["unfused"][1])))

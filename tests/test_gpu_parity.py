@@ -150,8 +150,11 @@ def _eval_against_golden(g, m, device):
     return res, users
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", ["lightgcn_dev_d64", "lightgcn_game_d64_tg"])
-def test_lightgcn_eval_golden(gpu_device, name):
+def test_lightgcn_eval_golden(gpu_device, name, fused, request):
+    if fused:
+        request.getfixturevalue("fused_scoring")
     g = G.load(name)
     m, ds = _make_lgn(g, gpu_device)
     # train over the recorded batches exactly as the golden run did (one train_step per batch)
@@ -170,6 +173,16 @@ def unfused_scoring():
     os.environ.pop("RK_SEL_OFF", None)
 
 
+@pytest.fixture
+def fused_scoring():
+    """RK_SEL_FORCE=1: rk_score_topk takes the fused sweep (no score matrix) wherever it is supported, also below
+    the catalogue size at which it becomes the default."""
+    import os
+    os.environ["RK_SEL_FORCE"] = "1"
+    yield
+    os.environ.pop("RK_SEL_FORCE", None)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
 def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request):
@@ -177,8 +190,7 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request)
     so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first) -- on the fused sweep
     (no score matrix) and on the GEMM + selection path."""
     from recad_amd import _lib
-    if not fused:
-        request.getfixturevalue("unfused_scoring")
+    request.getfixturevalue("fused_scoring" if fused else "unfused_scoring")
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
@@ -202,7 +214,7 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request)
     top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
     ts = torch.empty(nb, 3, dtype=torch.float32, device=dev)
     tr = torch.empty(nb, 3, dtype=torch.int32, device=dev)
-    scratch = torch.empty(max(nb * I, nb * 1024), dtype=torch.float32, device=dev)
+    scratch = torch.empty(max(nb * I, nb * 1025), dtype=torch.float32, device=dev)
     tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
     ids = t(user_ids, torch.int32)
     sp, si, tg = t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(targets, torch.int32)
@@ -210,8 +222,8 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request)
                                         _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 3,
                                         _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids] if with_bias else None, ib, 0.25 if with_bias else 0.0)
-    assert int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, 3)) == (nb * 1024 if fused else nb * I)
-    got_scores = None if fused else scratch[: nb * I].view(nb, I).cpu().numpy()
+    assert int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, 3)) == (nb * 1025 if (fused and d <= 128) else nb * I)
+    got_scores = None if (fused and d <= 128) else scratch[: nb * I].view(nb, I).cpu().numpy()
     top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         seen = seen_lists[int(user_ids[b])]
@@ -1186,7 +1198,7 @@ def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, tar
 
 @pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
 @pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
-def test_fused_sweep_stress(gpu_device, kind, I, K, T, config):
+def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, fused_scoring):
     """The fused scoring + selection sweep (score_select.h) on rows built to stress its threshold logic: constant
     and few-valued rows (every score ties), scores ascending with the item id (every item beats the running
     threshold: repeated compactions), descending, long runs of seen items inside one tile, rows with fewer than
