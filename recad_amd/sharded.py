@@ -392,6 +392,10 @@ class ShardedLightGCN:
         lptr[len(mine) + 1:] = lptr[len(mine)]
         take = np.repeat(seen_ptr[mine], deg) + (np.arange(int(deg.sum())) - np.repeat(lptr[:len(mine)], deg))
         lidx = seen_idx[take]
+        if len(lidx) > 1:   # ids ascending inside a user (the fused scoring sweep walks the lists with a cursor)
+            key = np.repeat(np.arange(len(mine), dtype=np.int64), deg) * (int(lidx.max()) + 1) + lidx
+            if not bool(np.all(key[1:] >= key[:-1])):
+                lidx = lidx[np.argsort(key, kind="stable")]
         has_t = np.zeros(len(mine), dtype=bool)
         if len(lidx):
             hit = np.isin(lidx, targets)
