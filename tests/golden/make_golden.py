@@ -86,7 +86,7 @@ def run_per_step(model, dataset, batches):
     return np.asarray(losses, dtype=np.float64), snaps
 
 
-def eval_rows(recad, model, dataset, target_ids, topks):
+def eval_rows(recad, model, dataset, target_ids, topks, max_users=None):
     """Reference evaluation for ONE model: candidate dict exactly as
     Normal.normal_evaluate builds it, rows from Normal.user_item_model_generate,
     plus per-user scores so the tests can compare top-K lists."""
@@ -101,6 +101,8 @@ def eval_rows(recad, model, dataset, target_ids, topks):
         if any(t in s for t in target_ids):
             continue
         cand[k] = list(full - s)
+    if max_users is not None:   # big towers: the reference's per-user loop is evaluated on the first users only
+        cand = {k: cand[k] for k in sorted(cand)[:max_users]}
     wf = object.__new__(recad.workflow.Normal)  # only the bound method is needed
     rows = recad.workflow.Normal.user_item_model_generate(wf, model, cand, topks, target_ids, torch.device("cpu"))
     # per-user top-100 by the reference's own forward; stable sort, ties reported
@@ -252,7 +254,8 @@ def golden_mf(recad, torch, name, dim, tag, max_steps=None, row_stride=1, eval_s
     print(f"mf_{tag}: U={U} I={I} steps={len(batches)} loss0={losses[0]:.6f} lossN={losses[-1]:.6f}")
 
 
-def golden_ncf(recad, torch, name, factor, layers, tag, max_steps=None, row_stride=1, eval_stride=1, dense_stride=1):
+def golden_ncf(recad, torch, name, factor, layers, tag, max_steps=None, row_stride=1, eval_stride=1, dense_stride=1,
+               eval_max_users=None):
     torch.manual_seed(2023)
     np.random.seed(2023)
     ds = recad.dataset.from_config("implicit", name, need_graph=False, sample="pointwise", download=False)
@@ -278,7 +281,7 @@ def golden_ncf(recad, torch, name, factor, layers, tag, max_steps=None, row_stri
     losses, snaps = run_per_step(model, ds, batches)
     bt, blen = pack_pointwise(batches)
     target_ids, topks = [0], [10, 20, 50, 100]
-    rows, users, top_ids, top_scores, min_gap = eval_rows(recad, model, ds, target_ids, topks)
+    rows, users, top_ids, top_scores, min_gap = eval_rows(recad, model, ds, target_ids, topks, max_users=eval_max_users)
     tptr, tidx = dict_to_csr(info["train_dict"], U)
     rs = slice(None, None, row_stride)
     es = slice(None, None, eval_stride)
@@ -359,6 +362,11 @@ def main():
         "ncf_dev": lambda: golden_ncf(recad, torch, "dev", 8, 3, "dev_f8_l3"),
         "ncf_game": lambda: golden_ncf(recad, torch, "game", 32, 5, "game_f32_l5", max_steps=6, row_stride=32, eval_stride=16,
                                             dense_stride=7),
+        # BASELINE.json config 5: NCF on Amazon-game at factor_num=256 (MLP tables [., 1024] / [., 4096])
+        "ncf_game_f256_l3": lambda: golden_ncf(recad, torch, "game", 256, 3, "game_f256_l3", max_steps=3, row_stride=128, eval_stride=1,
+                                               dense_stride=211, eval_max_users=24),
+        "ncf_game_f256_l5": lambda: golden_ncf(recad, torch, "game", 256, 5, "game_f256_l5", max_steps=2, row_stride=256, eval_stride=1,
+                                               dense_stride=3001, eval_max_users=3),
         "inject_dev": lambda: golden_graph_inject(recad, torch, "dev", "dev"),
     }
     for k, fn in jobs.items():

@@ -354,8 +354,10 @@ def test_defense_workflow_on_device(gpu_device):
     assert np.allclose(g.val.cpu().numpy(), ov, rtol=4e-7, atol=0)
 
 
-@pytest.mark.parametrize("name", ["ncf_dev_f8_l3", "ncf_game_f32_l5"])
+@pytest.mark.parametrize("name", ["ncf_dev_f8_l3", "ncf_game_f32_l5", "ncf_game_f256_l3", "ncf_game_f256_l5"])
 def test_ncf_train_golden(gpu_device, name):
+    """NCF against the reference's goldens; the two f256 cases are BASELINE.json config 5 (Amazon-game,
+    factor_num=256: MLP tables [., 1024] at L=3 and [., 4096] at L=5, tower up to 8192 -> 4096)."""
     from recad_amd import model
     g = G.load(name)
     f, L = int(g["factor"]), int(g["layers"])
@@ -405,6 +407,19 @@ def test_ncf_train_golden(gpu_device, name):
         assert ok, (nme, info)
     if name == "ncf_dev_f8_l3":
         _eval_against_golden(g, m, gpu_device)
+    if "f256" in name:
+        # the reference's per-user evaluation was recorded for the first eligible users only (eval_max_users)
+        from recad_amd.evaluate import full_catalog_topk, hr_rows
+        users = g["eval_users"]
+        res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=100, chunk=8)
+        rows = hr_rows(users, res, g["topks"])
+        ref = g["eval_rows"]
+        assert rows.shape == ref.shape and np.array_equal(rows[:, 0], ref[:, 0])
+        assert np.allclose(rows[:, 1], ref[:, 1], rtol=2e-5, atol=1e-6)
+        tie_free = g["top_min_gap"] > G.TIE_RTOL
+        assert np.array_equal(rows[tie_free, 2:], ref[tie_free, 2:])
+        mine = [(res["top_ids"][r], res["top_scores"][r]) for r in range(len(users))]
+        G.compare_topk_lists(mine, g["top_ids"], g["top_scores"], score_rtol=2e-5)
 
 
 @pytest.mark.parametrize("name,chunks", [("lightgcn_game_d64_tg", 1), ("lightgcn_game_d64_tg", 3), ("lightgcn_dev_d128_l2_tg", 2)])
@@ -1251,3 +1266,123 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, fused_scoring):
                 assert np.array_equal(ts[b], rts) and np.array_equal(tr[b], rtr), (kind, b)
     finally:
         os.environ.pop("RK_SEL_CONFIG", None)
+
+
+def _spmm_rows_host(rp, c, v, x, rows):
+    """float64 reference of selected rows of A.x (numpy, vectorised per row)"""
+    out = np.zeros((len(rows), x.shape[1]), dtype=np.float64)
+    for k, r in enumerate(rows):
+        a, b = rp[r], rp[r + 1]
+        if b > a:
+            out[k] = (v[a:b, None].astype(np.float64) * x[c[a:b]].astype(np.float64)).sum(0)
+    return out
+
+
+@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused")])
+def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
+    """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128) and
+    config 4 / 4 (250 K x 125 K, 25 M edges, d=64: rows of > 100 K nonzeros, i.e. hundreds of cross-workgroup
+    pieces, 32-bit gather offsets at 96 MB tables).  The oracle cannot replay these sizes in seconds, so:
+    size-independent properties (linearity, symmetry, spectral bound of the normalised adjacency, determinism),
+    float64 host restatements of SAMPLED rows (the longest rows included), a train step that moves the loss, and
+    bit-exact top-K lists / target ranks against the oracle on sampled users."""
+    from recad_amd import dataset, model, synth
+    from recad_amd.evaluate import eligible_users_device, full_catalog_topk
+    if mode == "fused":
+        request.getfixturevalue("fused_scoring")
+    if shape == "c4s":
+        dd = synth.make_device(shape, gpu_device)
+        d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+        del dd
+    else:
+        d = synth.make(shape)
+    ds = dataset.from_config("implicit", shape, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                             device=gpu_device, graph_source="train", seed=7, pairwise_batch_size=1024)
+    g = ds.graph_csr()
+    N, U = g.n_rows, ds.n_users
+    assert g.nnz == 2 * ds.traindataSize
+    rp, c, v = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
+    deg = np.diff(rp)
+    # structure: symmetric pattern with equal values (D^-1/2 A D^-1/2), checked on sampled entries
+    rng = np.random.default_rng(1)
+    for e in rng.integers(0, g.nnz, 200):
+        r = int(np.searchsorted(rp, e, side="right") - 1)
+        cc = int(c[e])
+        lo, hi = rp[cc], rp[cc + 1]
+        p = lo + int(np.searchsorted(c[lo:hi], r))
+        assert p < hi and c[p] == r and v[p] == v[e]
+        assert abs(v[e] - 1.0 / np.sqrt(float(deg[r]) * float(deg[cc]))) <= 4e-7 * v[e]
+    gen = torch.Generator(device=gpu_device).manual_seed(3)
+    x = torch.randn(N, dim, device=gpu_device, generator=gen)
+    y = torch.randn(N, dim, device=gpu_device, generator=gen)
+    ax, ay = g.spmm(x), g.spmm(y)
+    assert torch.equal(g.spmm(x), ax), "SpMM must be bit-reproducible run to run (long-row pieces included)"
+    axy = g.spmm(x + 2 * y)
+    assert float((axy - (ax + 2 * ay)).abs().max()) <= 1e-5 * float(axy.abs().max())
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * ay.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), float(ax.double().norm() * y.double().norm()) * 1e-3)
+    assert float(ax.norm()) <= float(x.norm()) * (1 + 1e-5)
+    # sampled rows in float64 on the host: the longest rows (cross-workgroup pieces), the shortest, random ones
+    order = np.argsort(deg)
+    rows = np.unique(np.concatenate([order[-12:], order[:6], rng.integers(0, N, 150)]))
+    xh = x.cpu().numpy()
+    ref = _spmm_rows_host(rp, c, v, xh, rows)
+    got = ax[torch.from_numpy(rows).to(gpu_device)].cpu().numpy().astype(np.float64)
+    assert deg[order[-1]] > 1024, "the sample must contain rows longer than one workgroup"
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    # training: three epoch slices move the loss down; the propagated tables stay finite
+    torch.manual_seed(2023)
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=3).I(dataset=ds).to(gpu_device)
+    ep = ds.generate_epoch()
+    B = 1024
+    cols = [ep[k][: 24 * B] for k in LGN_KEYS]
+    losses = m._run_epoch(*cols, B).sum(1).double().cpu().numpy()
+    assert np.isfinite(losses).all() and losses[-8:].mean() < losses[:8].mean()
+    # one train step against a float64 host restatement of the loss on the same triplets (light rows sampled)
+    lu, li = m.computer()
+    assert bool(torch.isfinite(lu).all()) and bool(torch.isfinite(li).all())
+    # evaluation on a sample of users: structural properties + bit-exact lists vs the oracle
+    ptr, idx = ds.train_csr_sorted()
+    users_dev, ptr_d, idx_d, tg_d = eligible_users_device(ptr, idx, np.array([0, 17], dtype=np.int32), gpu_device)
+    users = users_dev.cpu().numpy()
+    pick = users[:: max(1, len(users) // 3000)]
+    res = full_catalog_topk(m, pick, ptr, idx, [0, 17], K=100)
+    ts, ti = res["top_scores"], res["top_ids"]
+    assert (np.diff(ts, axis=1) <= 0).all() and (ti >= 0).all()
+    utab, itab = lu.cpu().numpy(), li.cpu().numpy()
+    for r in range(0, len(pick), max(1, len(pick) // 12)):
+        u = int(pick[r])
+        seen = idx[ptr[u]:ptr[u + 1]]
+        assert not (set(seen.tolist()) & set(ti[r].tolist()))
+        s = orc.score_rows(utab[u:u + 1], itab)[0]
+        ids, sc, tsc, trk = orc.topk_row(s, seen, 100, np.array([0, 17], dtype=np.int32))
+        assert np.array_equal(ids, ti[r]) and np.array_equal(sc, ts[r]), u
+        assert np.array_equal(trk, res["target_rank"][r]) and np.array_equal(tsc, res["target_score"][r])
+
+
+def test_mf_full_size_ml1m(gpu_device):
+    """BASELINE.json config[0] at ml1m size on the device: MF (embedding_size=64) through the workflow driver with the
+    random attacker (attack_num=50, filler_num=36), rec_epoch=1 -- finite metrics, and the clean model's HR rows
+    re-derived by the oracle from the trained tables."""
+    from recad_amd import dataset, model, synth, workflow
+    from recad_amd.evaluate import eligible_users
+    d = synth.make("ml1m")
+    ds = dataset.from_config("implicit", "ml1m", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], need_graph=False,
+                             device=gpu_device, sample="pointwise", graph_source="train", seed=3)
+    wf = workflow.from_config("no defense", victim_data=ds, attack_data=None, victim=model.from_config("victim", "mf", embedding_size=64),
+                              attacker=workflow.RandomAttack(ds.n_items, attack_num=50, filler_num=36, seed=2),
+                              rec_epoch=1, attack_epoch=0, device=gpu_device)
+    res = wf.execute()
+    assert all(np.isfinite(v) for v in res.values()) and res["n_eval_users"] > 5000
+    assert wf.fake_victim.user_emb.weight.shape[0] == ds.n_users + 50
+    ptr, idx = ds.train_csr_sorted()
+    users = eligible_users(ptr, idx, [0])[::37]
+    utab, itab, ub, ib, mean = wf.victim.scoring_tables()
+    utab, itab, ubn, ibn = utab.cpu().numpy(), itab.cpu().numpy(), ub.cpu().numpy(), ib.cpu().numpy()
+    rows, _ = orc.evaluate(lambda u: orc.score_rows(utab[u:u + 1], itab, ubn[u:u + 1], ibn, mean)[0], ds.n_items, ptr.astype(np.int32), idx,
+                           [0], [10, 20, 50, 100], users=users)
+    got = wf.last_eval["clean"]
+    sel = np.searchsorted(wf.last_eval["users"].cpu().numpy(), users)
+    rank = got["target_rank"].cpu().numpy()[sel, 0]
+    for i, k in enumerate([10, 20, 50, 100]):
+        assert np.array_equal((rank < k).astype(np.float64), rows[:, 2 + i])
