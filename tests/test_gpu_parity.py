@@ -389,17 +389,15 @@ def test_ncf_train_golden(gpu_device, name):
     big = f >= 256
 
     def grad_close(nme, got, ref):
-        """Step-1 gradients vs the reference.  At factor_num=256 a handful of pre-activations of the 1024 x (1024..4096)
-        tower are zero to within summation noise, and ATen's blocked sum and the k-ordered fmaf chain (GPU == oracle)
-        put them on opposite sides of the ReLU gate: each flip moves one unit's row of dW / db by one sample's
-        contribution (the CPU oracle shows the same 7e-4 against this golden).  So: every element within 2e-5 of the
-        largest, except at most 0.1 % of them, which must still stay within 2e-3."""
+        """Step-1 gradients vs the reference.  At factor_num=256 a few pre-activations of the 1024 x (1024..4096) tower
+        are zero to within summation noise, and ATen's blocked sums and the k-ordered fmaf chain (GPU == oracle) put
+        them on opposite sides of the ReLU gate.  One flipped gate in an upper layer changes that sample's dX through
+        the dense weights, i.e. adds a rank-1 term to EVERY lower dW: many elements move, each by <= 1e-3 of the
+        largest (the CPU oracle shows the same 7e-4 / 9e-4 against this golden; checked tightly against it below)."""
         ref = ref.reshape(got.shape)
         if not big:
             return G.relerr(got, ref) < 2e-5
-        scale = np.abs(ref).max()
-        diff = np.abs(got - ref)
-        return (diff > 2e-5 * scale).mean() <= 1e-3 and diff.max() <= 2e-3 * scale
+        return np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
 
     for nme, gr in zip(names, m._ws["grad"]):
         assert grad_close(nme, pick(nme, gr), g["grad1_" + nme]), nme
