@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 3
+#define RK_ABI_VERSION 4
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -187,7 +187,8 @@ int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *po
 /* out[b] = <utab[users[b]], itab[items[b]]> (+ ubias[users[b]] + ibias[items[b]] + mean when
  * ubias != NULL).  LightGCN.forward tail (lightgcn.py:179-182) and MF.forward (mf.py:40-47). */
 int rk_pair_scores(int32_t dim, const float *utab, const float *itab, const float *ubias, const float *ibias,
-                   float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, void *stream);
+                   float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, float dropout,
+                   uint64_t drop_seed, void *stream);   /* dropout > 0: nn.Dropout on the score (mf.py:47), mask of drop_seed */
 
 /* Dense torch.optim.Adam step on one tensor (recad/utils.py:181-183): t = 1-based step. */
 int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
@@ -220,7 +221,8 @@ int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, float *user
                       float *user_bias, float *item_bias, float mean, float *m, float *v, float *grads,
                       const int64_t *users, const int64_t *items, const int64_t *labels, int64_t n,
                       int32_t batch, int32_t adam_t0, float lr, float beta1, float beta2, float eps,
-                      float *loss_partials, int32_t apply_update, void *stream);
+                      float *loss_partials, int32_t apply_update, float dropout, uint64_t drop_seed, void *stream);
+/* dropout > 0: nn.Dropout on the logit (mf.py:27,47), one counter-based mask per optimizer step and sample. */
 
 /* ---------------------------------------------------------------- samplers ---------- */
 /* BPR triplets with the semantics of pairwise_sample, recad/dataset/implicit.py:50-74: n_draws
@@ -261,6 +263,12 @@ int rk_eligible_users(int32_t n_users, const int32_t *seen_ptr, const int32_t *s
  * double, fixed summation order.  out: device double[2]. */
 int rk_pred_shift(const float *score_before, const float *score_after, int64_t n, double *out, void *stream);
 
+/* out[b*n_items + i] = <utab[user_ids[b]], itab[i]> (+ ubias[user_ids[b]] + ibias[i] + mean), optionally through
+ * nn.Dropout(dropout) on the score -- MF.forward of a module in training mode (mf.py:40-47); feeds rk_topk_rows. */
+int rk_score_matrix(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                    int32_t n_items, const float *ubias, const float *ibias, float mean, float dropout,
+                    uint64_t drop_seed, float *out, void *stream);
+
 /* LightGCN.getUsersRating (lightgcn.py:115-120): out[b*n_items + i] = sigmoid(<utab[user_ids[b]], itab[i]>), the
  * dot product on the fp32 MFMA GEMM (bit-identical to the k-ordered fmaf chain). */
 int rk_users_rating(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
@@ -269,7 +277,7 @@ int rk_users_rating(int32_t dim, const float *utab, int32_t nb, const int32_t *u
 /* ---------------------------------------------------------------- NCF -------------- */
 #define RK_NCF_MAX_LAYERS 8
 #define RK_NCF_MAX_TENSORS 24
-/* NeuMF-end (recad/model/victim/ncf.py:9-58).  E = factor * 2^(n_layers-1) is the MLP embedding
+/* NCF (recad/model/victim/ncf.py:9-58; variants: `mode` below).  E = factor * 2^(n_layers-1) is the MLP embedding
  * width; tower layer l is Linear(in_l -> in_l/2) + ReLU with in_l = factor * 2^(n_layers-l)
  * (ncf.py:41-47); W[l] is nn.Linear's [out, in] row-major weight.  Tensor order of grad/m/v:
  * ug, ig, um, im, W[0..L-1], b[0..L-1], pw, pb. */
@@ -289,7 +297,21 @@ typedef struct rk_ncf_desc {
     float *gemm_scratch;
     int64_t gemm_scratch_floats;
     float *wgrad_part;                         /* training: float[ceil(max_batch/64) * (2*factor + 1)] */
+    /* model variant (ncf.py:49-52,112-131): RK_NCF_NEUMF = 'NeuMF-end' / 'NeuMF-pre' (they differ in initialisation
+     * only, ncf.py:78-110), RK_NCF_MLP = tower only, RK_NCF_GMF = element-wise product only; pw has 2*factor entries
+     * for NeuMF and factor entries otherwise.  Tensors a variant does not use receive zero gradients. */
+    int32_t mode;
+    /* nn.Dropout(p) in front of every tower layer (ncf.py:44); 0 = off.  Counter-based masks of drop_seed, the call
+     * (train: optimizer step; rk_ncf_forward: drop_call and the chunk) and the layer: the stream differs from
+     * torch's, the distribution does not.  The reference's workflows score WITHOUT .eval() (normal.py:61-67), so a
+     * module in training mode passes its dropout here for rk_ncf_forward too. */
+    float dropout;
+    uint64_t drop_seed;
+    int32_t drop_call, reserved2;
 } rk_ncf_desc;
+#define RK_NCF_NEUMF 0
+#define RK_NCF_MLP 1
+#define RK_NCF_GMF 2
 
 /* NCF.forward (ncf.py:112-131) for n pairs -> out[n].  Pairs are (users[b], items[b]), or -- when
  * user_ids != NULL -- the full catalog of each listed user: pair q = (user_ids[q / n_items_catalog],

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryMissing(RuntimeError):
@@ -67,6 +67,7 @@ class NCFDesc(C.Structure):
         ("acts", C.c_void_p), ("dacts", C.c_void_p), ("d0", C.c_void_p),
         ("max_batch", C.c_int32), ("reserved", C.c_int32),
         ("gemm_scratch", C.c_void_p), ("gemm_scratch_floats", C.c_int64), ("wgrad_part", C.c_void_p),
+        ("mode", C.c_int32), ("dropout", C.c_float), ("drop_seed", C.c_uint64), ("drop_call", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -92,7 +93,8 @@ _SIGNATURES = {
     "rk_lightgcn_propagate_dropout": [_P, C.c_uint64, _P],
     "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],
     "rk_lightgcn_prepare": [_P, _P, _P, _P, _P, _I32, _I32, _P],
-    "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _P],
+    "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _F, C.c_uint64, _P],
+    "rk_score_matrix": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _F, C.c_uint64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
     "rk_score_topk_scratch_floats": [_I32, _I32, _I32, _I32, _I32],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
@@ -106,7 +108,7 @@ _SIGNATURES = {
     "rk_ncf_forward": [C.POINTER(NCFDesc), _P, _P, _P, _I32, _I64, _P, _P],
     "rk_ncf_train_epoch": [C.POINTER(NCFDesc), _P, _P, _P, _I64, _I32, _I32, _P, _I32, _P],
     "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,
-                          _F, _P, _I32, _P],
+                          _F, _P, _I32, _F, C.c_uint64, _P],
 }
 _RESTYPES = {"rk_last_error": C.c_char_p, "rk_score_topk_scratch_floats": C.c_int64}
 EXPORTS = tuple(_SIGNATURES)

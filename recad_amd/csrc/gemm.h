@@ -27,6 +27,9 @@ struct GemmArgs {
     float const_add;
     int relu;
     int sigmoid;                           // s = 1 / (1 + exp(-s))  (LightGCN.getUsersRating, lightgcn.py:119)
+    unsigned drop_thresh24;                // > 0: nn.Dropout on the output (mf.py:47): keep element (m, n) iff its counter hash
+    float drop_scale;                      //      is below keep_prob * 2^24, scaled by 1 / keep_prob
+    unsigned long long drop_seed;
     const float *mask; int ldmask;         // keep s only where mask[m,n] > 0
     float *sk_part; long long sk_stride;   // split_k > 1 and sk_part: slice q STORES its partial at sk_part[q*sk_stride + m*ldc + n]
                                            // (the caller adds the slices in order: deterministic, no zeroing, no atomics)
@@ -269,6 +272,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
                                 if (g.relu) s = s > 0.f ? s : 0.f;
                                 if (g.sigmoid) s = 1.f / (1.f + expf(-s));
                                 if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                                if (g.drop_thresh24) s = rk_drop_keep(g.drop_seed, (unsigned)((size_t)m * g.N + n), g.drop_thresh24) ? s * g.drop_scale : 0.f;
                                 g.C[(size_t)m * g.ldc + n] = s;
                             }
                             if (kClearInside) acc[i][j][r] = 0.f;
@@ -391,7 +395,9 @@ static __global__ __launch_bounds__(256, 4) void gemm_f32_skinny_kernel(const Ge
                     if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
                     else if (g.col_bias) s += g.col_bias[n];
                     if (g.relu) s = s > 0.f ? s : 0.f;
+                    if (g.sigmoid) s = 1.f / (1.f + expf(-s));
                     if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                    if (g.drop_thresh24) s = rk_drop_keep(g.drop_seed, (unsigned)((size_t)m * g.N + n), g.drop_thresh24) ? s * g.drop_scale : 0.f;
                     g.C[(size_t)m * g.ldc + n] = s;
                 }
             }
@@ -424,7 +430,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     const dim3 grid((nwg128 + tpb - 1) / tpb);
     // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
     // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
-    const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.mask && !g.sigmoid;
+    const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.mask && !g.sigmoid && !g.drop_thresh24;
     if (g.a_ridx && plain) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, true>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     else if (g.a_ridx) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, false>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 2, 2>), grid, dim3(256), gemm_lds_bytes<128>(2), s, g, tpb);

@@ -14,6 +14,9 @@ struct MfArgs {
     long long off;
     int nb;
     float *loss_partials;  // this step's RK_LOSS_PARTIALS slots
+    unsigned drop_thresh24;  // > 0: nn.Dropout on the logit (mf.py:27,47), one counter-hash mask per (step, sample)
+    float drop_scale;
+    unsigned long long drop_seed;
 };
 
 // One wave per sample; lanes stride over the embedding (mf.py:40-47), wave-shuffle dot,
@@ -33,9 +36,14 @@ __global__ __launch_bounds__(256) void mf_step_kernel(const MfArgs a)
         float s = 0.f;
         for (int k = lane; k < d; k += 64) s += pu[k] * pi[k];
         s = wave_sum(s);
-        const float x = ((s + a.ub[u]) + a.ib[i]) + a.mean;
+        float x = ((s + a.ub[u]) + a.ib[i]) + a.mean;
+        float keep = 1.f;
+        if (a.drop_thresh24) {
+            keep = rk_drop_keep(a.drop_seed, (unsigned)b, a.drop_thresh24) ? a.drop_scale : 0.f;
+            x *= keep;
+        }
         lsum += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
-        const float dx = (1.f / (1.f + expf(-x)) - y) * invB;
+        const float dx = (1.f / (1.f + expf(-x)) - y) * invB * keep;
         for (int k = lane; k < d; k += 64) {
             unsafeAtomicAdd(gue + (size_t)u * d + k, dx * pi[k]);
             unsafeAtomicAdd(gie + (size_t)i * d + k, dx * pu[k]);
@@ -81,9 +89,10 @@ RK_EXPORT int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, f
                                 float *user_bias, float *item_bias, float mean, float *m, float *v, float *grads,
                                 const int64_t *users, const int64_t *items, const int64_t *labels, int64_t n,
                                 int32_t batch, int32_t adam_t0, float lr, float beta1, float beta2, float eps,
-                                float *loss_partials, int32_t apply_update, void *stream)
+                                float *loss_partials, int32_t apply_update, float dropout, uint64_t drop_seed, void *stream)
 {
     if (n_users <= 0 || n_items <= 0 || dim <= 0 || n <= 0 || batch <= 0) RK_FAIL(RK_EINVAL, "rk_mf_train_epoch: bad sizes");
+    if (!(dropout >= 0.f) || dropout >= 1.f) RK_FAIL(RK_EINVAL, "rk_mf_train_epoch: dropout must be in [0, 1)");
     if (!user_emb || !item_emb || !user_bias || !item_bias || !m || !v || !grads || !users || !items || !labels || !loss_partials)
         RK_FAIL(RK_EINVAL, "rk_mf_train_epoch: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -100,6 +109,9 @@ RK_EXPORT int rk_mf_train_epoch(int32_t n_users, int32_t n_items, int32_t dim, f
         a.off = (long long)step * batch;
         a.nb = (int)std::min<long long>(batch, n - a.off);
         a.loss_partials = loss_partials + (size_t)step * RK_LOSS_PARTIALS;
+        a.drop_thresh24 = dropout > 0.f ? (unsigned)((1.0 - (double)dropout) * 16777216.0) : 0u;
+        a.drop_scale = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.f;
+        a.drop_seed = rk_drop_step_seed((unsigned long long)drop_seed, (unsigned long long)(adam_t0 + step));
         const int grid = std::min(RK_LOSS_PARTIALS, (a.nb + 3) / 4);
         hipLaunchKernelGGL(mf_step_kernel, dim3(grid), dim3(256), 0, s, a);
         RK_CHECK_LAUNCH();

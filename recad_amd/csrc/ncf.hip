@@ -1,4 +1,4 @@
-// NCF (NeuMF-end) victim hot path on gfx950 (recad/model/victim/ncf.py:112-153): embedding
+// NCF victim hot path on gfx950 (model = NeuMF-end / NeuMF-pre / MLP / GMF, ncf.py:49-52,112-131) (recad/model/victim/ncf.py:112-153): embedding
 // gathers, the MLP tower as exact-fp32 MFMA GEMMs (forward, dX and dW), predict layer +
 // BCE-with-logits, embedding-gradient scatter-add and one multi-tensor dense Adam launch.
 #include <algorithm>
@@ -96,8 +96,26 @@ __device__ __forceinline__ void pair_at(const PairSrc &p, long long b, long long
 }
 
 // X0[b] = [um[u] | im[i]]   (ncf.py:119-121)
+// nn.Dropout in front of a tower layer (ncf.py:44): element `id` of the layer input is kept iff its counter hash under the
+// (call, layer) seed is below keep_prob * 2^24, and scaled by 1 / keep_prob.  The backward applies the same function
+// to dX of that layer (same ids => same mask).
+struct DropSpec {
+    unsigned thresh24;   // 0 = off
+    float scale;
+    unsigned long long seed;
+};
+__device__ __forceinline__ float drop_apply(const DropSpec &d, unsigned id, float v)
+{
+    return d.thresh24 ? (rk_drop_keep(d.seed, id, d.thresh24) ? v * d.scale : 0.f) : v;
+}
+__global__ void dropout_apply_kernel(long long n, float *x, DropSpec d)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[i] = drop_apply(d, (unsigned)i, x[i]);
+}
+
 __global__ void ncf_gather_kernel(PairSrc p, int nb, int E, const float *__restrict__ um, const float *__restrict__ im,
-                                  float *__restrict__ x0)
+                                  float *__restrict__ x0, DropSpec drop)
 {
     const int lane = threadIdx.x & 63;
     for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += (long long)gridDim.x * (blockDim.x >> 6)) {
@@ -106,14 +124,21 @@ __global__ void ncf_gather_kernel(PairSrc p, int nb, int E, const float *__restr
         const float *su = um + (size_t)u * E, *si = im + (size_t)i * E;
         float *d = x0 + (size_t)b * 2 * E;
         for (int k = lane * 4; k < E; k += 256) {
-            *reinterpret_cast<float4 *>(d + k) = *reinterpret_cast<const float4 *>(su + k);
-            *reinterpret_cast<float4 *>(d + E + k) = *reinterpret_cast<const float4 *>(si + k);
+            float4 a = *reinterpret_cast<const float4 *>(su + k), c = *reinterpret_cast<const float4 *>(si + k);
+            if (drop.thresh24) {
+                const unsigned ia = (unsigned)((size_t)b * 2 * E + k), ic = ia + (unsigned)E;
+                a.x = drop_apply(drop, ia, a.x); a.y = drop_apply(drop, ia + 1, a.y); a.z = drop_apply(drop, ia + 2, a.z); a.w = drop_apply(drop, ia + 3, a.w);
+                c.x = drop_apply(drop, ic, c.x); c.y = drop_apply(drop, ic + 1, c.y); c.z = drop_apply(drop, ic + 2, c.z); c.w = drop_apply(drop, ic + 3, c.w);
+            }
+            *reinterpret_cast<float4 *>(d + k) = a;
+            *reinterpret_cast<float4 *>(d + E + k) = c;
         }
     }
 }
 
-// logit = pw . [ug*ig | xL] + pb (ncf.py:114-116,123-131); optional BCE loss + d0 = (sigmoid - y)/nb
-__global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug,
+// logit = pw . concat + pb with concat = [ug*ig | xL] (NeuMF), xL (MLP) or ug*ig (GMF) (ncf.py:114-131); optional BCE
+// loss + d0 = (sigmoid - y)/nb.  mode: RK_NCF_NEUMF / RK_NCF_MLP / RK_NCF_GMF.
+__global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int f, int mode, const float *__restrict__ ug,
                                                           const float *__restrict__ ig, const float *__restrict__ xl,
                                                           const float *__restrict__ pw, const float *__restrict__ pb,
                                                           float *__restrict__ logits, const int64_t *labels, float *d0,
@@ -128,7 +153,9 @@ __global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int
         pair_at(p, b, u, i);
         const float *pu = ug + (size_t)u * f, *pi = ig + (size_t)i * f, *px = xl + (size_t)b * f;
         float s = 0.f;
-        for (int k = lane; k < f; k += 64) s += pw[k] * (pu[k] * pi[k]) + pw[f + k] * px[k];
+        if (mode == RK_NCF_NEUMF) { for (int k = lane; k < f; k += 64) s += pw[k] * (pu[k] * pi[k]) + pw[f + k] * px[k]; }
+        else if (mode == RK_NCF_MLP) { for (int k = lane; k < f; k += 64) s += pw[k] * px[k]; }
+        else { for (int k = lane; k < f; k += 64) s += pw[k] * (pu[k] * pi[k]); }
         s = wave_sum(s) + pb[0];
         if (lane == 0) {
             if (logits) logits[p.off + b] = s;
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int
 }
 
 // backward of the predict layer: dXL[b,k] = d0[b]*pw[f+k]; GMF table grads by atomics
-__global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug, const float *__restrict__ ig,
+__global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, int mode, const float *__restrict__ ug, const float *__restrict__ ig,
                                        const float *__restrict__ pw, const float *__restrict__ d0, float *__restrict__ dxl,
                                        float *g_ug, float *g_ig)
 {
@@ -157,9 +184,11 @@ __global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__
         pair_at(p, b, u, i);
         const float dd = d0[b];
         for (int k = lane; k < f; k += 64) {
-            dxl[(size_t)b * f + k] = dd * pw[f + k];
-            unsafeAtomicAdd(g_ug + (size_t)u * f + k, dd * pw[k] * ig[(size_t)i * f + k]);
-            unsafeAtomicAdd(g_ig + (size_t)i * f + k, dd * pw[k] * ug[(size_t)u * f + k]);
+            if (mode != RK_NCF_GMF) dxl[(size_t)b * f + k] = dd * pw[(mode == RK_NCF_NEUMF ? f : 0) + k];
+            if (mode != RK_NCF_MLP) {
+                unsafeAtomicAdd(g_ug + (size_t)u * f + k, dd * pw[k] * ig[(size_t)i * f + k]);
+                unsafeAtomicAdd(g_ig + (size_t)i * f + k, dd * pw[k] * ug[(size_t)u * f + k]);
+            }
         }
     }
 }
@@ -171,7 +200,7 @@ __global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, const float *__
 // order -> part[slab][k]; stage 2 adds the slabs in order.  (One workgroup per 64 outputs walking all 1024
 // rows' dependent gathers was 57 us of a 417 us step.)
 static constexpr int kWgradSlab = 64;
-__global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, const float *__restrict__ ug,
+__global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int nb, int f, int mode, const float *__restrict__ ug,
                                                                 const float *__restrict__ ig, const float *__restrict__ xl,
                                                                 const float *__restrict__ d0, float *__restrict__ part)
 {
@@ -179,8 +208,9 @@ __global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int 
     const int kc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kc;
     const int b_lo = blockIdx.y * kWgradSlab, b_hi = min(nb, b_lo + kWgradSlab);
+    const int PS = mode == RK_NCF_NEUMF ? 2 * f : f;   // predict_layer input width (ncf.py:49-52)
     float s = 0.f;
-    if (k <= 2 * f) {
+    if (k <= PS) {
         float z[kWgradSlab / 16], dd[kWgradSlab / 16];
 #pragma unroll
         for (int j = 0; j < kWgradSlab / 16; ++j) {
@@ -188,7 +218,8 @@ __global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int 
             z[j] = 0.f; dd[j] = 0.f;
             if (b < b_hi) {
                 dd[j] = d0[b];
-                if (k == 2 * f) z[j] = 1.f;
+                if (k == PS) z[j] = 1.f;
+                else if (mode == RK_NCF_MLP) z[j] = xl[(size_t)b * f + k];
                 else if (k < f) { long long u, i; pair_at(p, b, u, i); z[j] = ug[(size_t)u * f + k] * ig[(size_t)i * f + k]; }
                 else z[j] = xl[(size_t)b * f + (k - f)];
             }
@@ -198,19 +229,19 @@ __global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int 
     }
     red[rg][kc] = s;
     __syncthreads();
-    if (rg == 0 && k <= 2 * f) {
+    if (rg == 0 && k <= PS) {
         float t = red[0][kc];
         for (int q = 1; q < 16; ++q) t += red[q][kc];
-        part[(size_t)blockIdx.y * (2 * f + 1) + k] = t;
+        part[(size_t)blockIdx.y * (PS + 1) + k] = t;
     }
 }
-__global__ void ncf_predict_wgrad_finish_kernel(int f, int n_slabs, const float *__restrict__ part, float *gpw, float *gpb)
+__global__ void ncf_predict_wgrad_finish_kernel(int PS, int n_slabs, const float *__restrict__ part, float *gpw, float *gpb)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > 2 * f) return;
+    if (k > PS) return;
     float t = 0.f;
-    for (int q = 0; q < n_slabs; ++q) t += part[(size_t)q * (2 * f + 1) + k];
-    if (k == 2 * f) gpb[0] += t; else gpw[k] += t;
+    for (int q = 0; q < n_slabs; ++q) t += part[(size_t)q * (PS + 1) + k];
+    if (k == PS) gpb[0] += t; else gpw[k] += t;
 }
 
 // db[n] += sum_m dY[m,n]: 64 columns x 16 row groups per workgroup, fixed-order LDS combine (deterministic,
@@ -294,6 +325,8 @@ static int check_ncf(const rk_ncf_desc &d)
         RK_FAIL(RK_EINVAL, "ncf: null pointer");
     for (int l = 0; l < d.n_layers; ++l)
         if (!d.W[l] || !d.b[l]) RK_FAIL(RK_EINVAL, "ncf: tower pointer missing");
+    if (d.mode != RK_NCF_NEUMF && d.mode != RK_NCF_MLP && d.mode != RK_NCF_GMF) RK_FAIL(RK_EINVAL, "ncf: unknown mode %d", d.mode);
+    if (!(d.dropout >= 0.f) || d.dropout >= 1.f) RK_FAIL(RK_EINVAL, "ncf: dropout must be in [0, 1)");
     return RK_OK;
 }
 
@@ -305,18 +338,35 @@ static size_t act_off(const rk_ncf_desc &d, int l, int nbmax)
     return o;
 }
 
-// forward for one chunk of nb pairs; acts[l] = input of layer l, acts[L] = tower output [nb, f]
-static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, hipStream_t s)
+static DropSpec drop_spec(const rk_ncf_desc &d, unsigned long long call, int layer)
 {
+    DropSpec ds;
+    ds.thresh24 = d.dropout > 0.f ? (unsigned)((1.0 - (double)d.dropout) * 16777216.0) : 0u;
+    ds.scale = d.dropout > 0.f ? 1.0f / (1.0f - d.dropout) : 1.f;
+    ds.seed = rk_drop_step_seed((unsigned long long)d.drop_seed, call * 16ULL + (unsigned long long)layer);
+    return ds;
+}
+
+// forward for one chunk of nb pairs; acts[l] = input of layer l (after its dropout), acts[L] = tower output [nb, f].
+// `call` numbers the dropout masks (train: the global step; scoring: desc.drop_call and the chunk).
+static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, unsigned long long call, hipStream_t s)
+{
+    if (d.mode == RK_NCF_GMF) return RK_OK;   // no tower (ncf.py:118-127)
     const int L = d.n_layers, E = d.factor << (L - 1);
     float *x0 = d.acts;
-    hipLaunchKernelGGL(ncf_gather_kernel, dim3(std::min(2048, (nb + 3) / 4)), dim3(256), 0, s, p, nb, E, d.um, d.im, x0);
+    hipLaunchKernelGGL(ncf_gather_kernel, dim3(std::min(2048, (nb + 3) / 4)), dim3(256), 0, s, p, nb, E, d.um, d.im, x0, drop_spec(d, call, 0));
     RK_CHECK_LAUNCH();
     for (int l = 0; l < L; ++l) {
         const int in = in_of(d, l), out = in / 2;
+        float *y = d.acts + act_off(d, l + 1, d.max_batch);
         int rc = gemm_auto(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
-                           d.acts + act_off(d, l + 1, d.max_batch), d.b[l], 1, nullptr, nullptr, 0);  // whole-K: see gemm_auto
+                           y, d.b[l], 1, nullptr, nullptr, 0);  // whole-K: see gemm_auto
         if (rc) return rc;
+        if (d.dropout > 0.f && l + 1 < L) {   // Dropout in front of layer l+1 (none in front of predict_layer)
+            const long long n = (long long)nb * out;
+            hipLaunchKernelGGL(dropout_apply_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, n, y, drop_spec(d, call, l + 1));
+            RK_CHECK_LAUNCH();
+        }
     }
     return RK_OK;
 }
@@ -333,9 +383,9 @@ RK_EXPORT int rk_ncf_forward(const rk_ncf_desc *desc, const int64_t *users, cons
     for (long long off = 0; off < n; off += d.max_batch) {
         const int nb = (int)std::min<long long>(d.max_batch, n - off);
         PairSrc p{users, items, user_ids, n_items_catalog, off};
-        rc = ncf_forward_chunk(d, p, nb, s);
+        rc = ncf_forward_chunk(d, p, nb, ((unsigned long long)d.drop_call << 24) + (unsigned long long)(off / d.max_batch) + (1ULL << 60), s);
         if (rc) return rc;
-        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, s, p, nb, d.factor, d.ug, d.ig,
+        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, s, p, nb, d.factor, d.mode, d.ug, d.ig,
                            d.acts + act_off(d, d.n_layers, d.max_batch), d.pw, d.pb, out, (const int64_t *)nullptr,
                            (float *)nullptr, (float *)nullptr);
         RK_CHECK_LAUNCH();
@@ -354,6 +404,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
     const rk_ncf_desc &d = *desc;
     if (batch > d.max_batch) RK_FAIL(RK_EINVAL, "rk_ncf_train_epoch: batch %d > desc.max_batch %d", batch, d.max_batch);
     const int L = d.n_layers, f = d.factor, E = f << (L - 1), T = 4 + 2 * L + 2;
+    const int PS = d.mode == RK_NCF_NEUMF ? 2 * f : f;
     for (int t = 0; t < T; ++t)
         if (!d.grad[t] || !d.m[t] || !d.v[t]) RK_FAIL(RK_EINVAL, "ncf: grad/moment pointer %d missing", t);
     if (!d.wgrad_part) RK_FAIL(RK_EINVAL, "ncf: desc.wgrad_part missing");
@@ -370,7 +421,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         P[4 + l] = d.W[l]; NN[4 + l] = (long long)in * (in / 2);
         P[4 + L + l] = d.b[l]; NN[4 + L + l] = in / 2;
     }
-    P[4 + 2 * L] = d.pw; NN[4 + 2 * L] = 2 * f;
+    P[4 + 2 * L] = d.pw; NN[4 + 2 * L] = PS;
     P[5 + 2 * L] = d.pb; NN[5 + 2 * L] = 1;
     for (int t = 0; t < T; ++t) RK_HIP(hipMemsetAsync(d.grad[t], 0, sizeof(float) * (size_t)NN[t], s));
     const int n_steps = (int)((n + batch - 1) / batch);
@@ -380,26 +431,27 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         const long long off = (long long)step * batch;
         const int nb = (int)std::min<long long>(batch, n - off);
         PairSrc p{users, items, nullptr, 0, off};
-        rc = ncf_forward_chunk(d, p, nb, s);
+        const unsigned long long call = (unsigned long long)(adam_t0 + step);
+        rc = ncf_forward_chunk(d, p, nb, call, s);
         if (rc) return rc;
         float *xl = d.acts + act_off(d, L, d.max_batch), *dxl = d.dacts + act_off(d, L, d.max_batch);
-        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(RK_LOSS_PARTIALS, (nb + 3) / 4)), dim3(256), 0, s, p, nb, f, d.ug, d.ig,
+        hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(RK_LOSS_PARTIALS, (nb + 3) / 4)), dim3(256), 0, s, p, nb, f, d.mode, d.ug, d.ig,
                            xl, d.pw, d.pb, (float *)nullptr, labels, d.d0, loss_partials + (size_t)step * RK_LOSS_PARTIALS);
         RK_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
+        hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.mode, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
         RK_CHECK_LAUNCH();
         {
             const int n_slabs = (nb + kWgradSlab - 1) / kWgradSlab;
-            hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((2 * f + 1 + 63) / 64, n_slabs), dim3(1024), 0, s, p, nb, f, d.ug, d.ig, xl,
+            hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((PS + 1 + 63) / 64, n_slabs), dim3(1024), 0, s, p, nb, f, d.mode, d.ug, d.ig, xl,
                                d.d0, d.wgrad_part);
             RK_CHECK_LAUNCH();
-            hipLaunchKernelGGL(ncf_predict_wgrad_finish_kernel, dim3((2 * f + 1 + 255) / 256), dim3(256), 0, s, f, n_slabs, d.wgrad_part,
+            hipLaunchKernelGGL(ncf_predict_wgrad_finish_kernel, dim3((PS + 1 + 255) / 256), dim3(256), 0, s, PS, n_slabs, d.wgrad_part,
                                d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
             RK_CHECK_LAUNCH();
         }
         // tower backward.  dY of the top layer is masked by its own ReLU here; for the layers below
         // the mask (x > 0, x = the previous layer's ReLU output) is applied in the dX GEMM's epilogue.
-        for (int l = L - 1; l >= 0; --l) {
+        for (int l = (d.mode == RK_NCF_GMF ? -1 : L - 1); l >= 0; --l) {
             const int in = in_of(d, l), out = in / 2;
             float *x = d.acts + act_off(d, l, d.max_batch), *y = d.acts + act_off(d, l + 1, d.max_batch);
             float *dy = d.dacts + act_off(d, l + 1, d.max_batch), *dx = d.dacts + act_off(d, l, d.max_batch);
@@ -419,9 +471,18 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
             // dX[nb,in] = dY W, masked by (x > 0) for l >= 1 (x is the previous layer's ReLU output)
             rc = gemm_auto(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, nullptr, 0, l >= 1 ? x : nullptr, d.gemm_scratch, d.gemm_scratch_floats);
             if (rc) return rc;
+            if (d.dropout > 0.f) {
+                // back through the Dropout in front of layer l: the forward's mask again (same ids), times 1 / keep_prob.
+                // (For l >= 1 the ReLU mask above already zeroed the dropped entries: x is the post-dropout activation.)
+                const long long n = (long long)nb * in;
+                hipLaunchKernelGGL(dropout_apply_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, n, dx, drop_spec(d, call, l));
+                RK_CHECK_LAUNCH();
+            }
         }
-        hipLaunchKernelGGL(ncf_scatter_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, E, d.dacts, d.grad[2], d.grad[3]);
-        RK_CHECK_LAUNCH();
+        if (d.mode != RK_NCF_GMF) {
+            hipLaunchKernelGGL(ncf_scatter_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, E, d.dacts, d.grad[2], d.grad[3]);
+            RK_CHECK_LAUNCH();
+        }
         if (!apply_update) break;
         const AdamCoef c = adam_coef(adam_t0 + step + 1, d.lr, d.beta1, d.beta2);
         MultiAdam a;

@@ -374,7 +374,8 @@ RK_EXPORT int rk_build_norm_adj(int32_t n_users, int32_t n_items, const int32_t 
 // ---- pairwise scores
 __global__ void pair_scores_kernel(int d, const float *__restrict__ utab, const float *__restrict__ itab, const float *ubias,
                                    const float *ibias, float mean, const int64_t *__restrict__ users,
-                                   const int64_t *__restrict__ items, long long n, float *__restrict__ out)
+                                   const int64_t *__restrict__ items, long long n, float *__restrict__ out,
+                                   unsigned drop_thresh24, float drop_scale, unsigned long long drop_seed)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -387,20 +388,24 @@ __global__ void pair_scores_kernel(int d, const float *__restrict__ utab, const 
         s = wave_sum(s);
         if (lane == 0) {
             if (ubias) s = ((s + ubias[u]) + ibias[i]) + mean;
+            if (drop_thresh24) s = rk_drop_keep(drop_seed, (unsigned)b, drop_thresh24) ? s * drop_scale : 0.f;
             out[b] = s;
         }
     }
 }
 
 RK_EXPORT int rk_pair_scores(int32_t dim, const float *utab, const float *itab, const float *ubias, const float *ibias,
-                             float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, void *stream)
+                             float mean, const int64_t *users, const int64_t *items, int64_t n, float *out, float dropout,
+                             uint64_t drop_seed, void *stream)
 {
     if (n <= 0) return RK_OK;
+    if (!(dropout >= 0.f) || dropout >= 1.f) RK_FAIL(RK_EINVAL, "rk_pair_scores: dropout must be in [0, 1)");
     if (dim <= 0 || !utab || !itab || !users || !items || !out) RK_FAIL(RK_EINVAL, "rk_pair_scores: bad arguments");
     if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_pair_scores: give both biases or neither");
     const int grid = (int)std::min<long long>((n + 3) / 4, 4096);
     hipLaunchKernelGGL(pair_scores_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dim, utab, itab, ubias, ibias, mean,
-                       users, items, (long long)n, out);
+                       users, items, (long long)n, out, dropout > 0.f ? (unsigned)((1.0 - (double)dropout) * 16777216.0) : 0u,
+                       dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.f, (unsigned long long)drop_seed);
     RK_CHECK_LAUNCH();
     return RK_OK;
 }

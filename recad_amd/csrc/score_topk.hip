@@ -556,6 +556,32 @@ RK_EXPORT int rk_pred_shift(const float *score_before, const float *score_after,
     return RK_OK;
 }
 
+// Materialised score block out[b, i] = <utab[user_ids[b]], itab[i]> (+ biases + mean), optionally through nn.Dropout on
+// the score (MF.forward of a module in training mode with dropout > 0, mf.py:47: the workflows score without .eval()).
+RK_EXPORT int rk_score_matrix(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
+                              int32_t n_items, const float *ubias, const float *ibias, float mean, float dropout,
+                              uint64_t drop_seed, float *out, void *stream)
+{
+    if (nb <= 0) return RK_OK;
+    if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !out) RK_FAIL(RK_EINVAL, "rk_score_matrix: bad arguments");
+    if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_matrix: give both biases or neither");
+    if (!(dropout >= 0.f) || dropout >= 1.f) RK_FAIL(RK_EINVAL, "rk_score_matrix: dropout must be in [0, 1)");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = nb; g.N = n_items; g.K = dim;
+    g.A = utab; g.a_rs = dim; g.a_cs = 1; g.a_ridx = user_ids;
+    g.B = itab; g.b_rs = dim; g.b_cs = 1;
+    g.C = out; g.ldc = n_items;
+    g.row_bias = ubias; g.col_bias = ibias; g.const_add = mean;
+    if (dropout > 0.f) {
+        g.drop_thresh24 = (unsigned)((1.0 - (double)dropout) * 16777216.0);
+        g.drop_scale = 1.0f / (1.0f - dropout);
+        g.drop_seed = (unsigned long long)drop_seed;
+    }
+    RK_HIP(gemm_f32_launch(g, (hipStream_t)stream));
+    return RK_OK;
+}
+
 // LightGCN.getUsersRating (lightgcn.py:115-120): out[b, i] = sigmoid(<utab[user_ids[b]], itab[i]>) on the fp32-MFMA GEMM
 RK_EXPORT int rk_users_rating(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
                               int32_t n_items, float *out, void *stream)

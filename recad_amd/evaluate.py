@@ -20,9 +20,10 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     arrays, or (to_host=False) device tensors left in HBM, no synchronisation.
     """
     _lib.require_gpu()
-    dot = hasattr(victim, "scoring_tables")
+    tabs = victim.scoring_tables() if hasattr(victim, "scoring_tables") else None
+    dot = tabs is not None
     if dot:
-        utab, itab, ubias, ibias, mean = victim.scoring_tables()
+        utab, itab, ubias, ibias, mean = tabs
         dev = itab.device
         utab, itab = utab.contiguous(), itab.contiguous()
         if ubias is not None:

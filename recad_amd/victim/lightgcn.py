@@ -281,7 +281,7 @@ class LightGCN(BaseVictim):
         out = torch.empty(users.numel(), device=all_users.device, dtype=torch.float32)
         _lib.check(_lib.lib().rk_pair_scores(
             self.latent_dim, _lib.ptr(all_users), _lib.ptr(all_items), None, None, 0.0, _lib.ptr(users.long().contiguous()),
-            _lib.ptr(items.long().contiguous()), users.numel(), _lib.ptr(out), _lib.stream_ptr()), "rk_pair_scores")
+            _lib.ptr(items.long().contiguous()), users.numel(), _lib.ptr(out), 0.0, 0, _lib.stream_ptr()), "rk_pair_scores")
         return out
 
     # ------------------------------------------------------------------ batched evaluation hook

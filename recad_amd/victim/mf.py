@@ -15,8 +15,11 @@ class MF(BaseVictim):
         num_users, num_items = info["n_users"], info["n_items"]
         self.dataset = config["dataset"]
         self.config = config
-        if dropout:
-            raise ValueError("dropout is not supported by the HIP path (reference default is 0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+        self.drop_p = float(dropout)
+        self._drop_seed = None   # drawn from torch's global RNG on first use, like nn.Dropout draws its masks from it
+        self._drop_calls = 0
         # same construction / RNG order as mf.py:16-24
         self.user_emb = nn.Embedding(num_users, embedding_size)
         self.user_bias = nn.Embedding(num_users, 1)
@@ -73,14 +76,35 @@ class MF(BaseVictim):
         st = self.optimizer.state.get(self.user_emb.weight, {})
         return int(st["step"]) if "step" in st else 0
 
+    def _dropout_now(self):
+        """(p, seed) of the nn.Dropout on the logit (mf.py:27,47): active whenever the module is in training mode --
+        also while the workflows score under no_grad without .eval() (normal.py:61-67).  A fresh mask per call."""
+        if not (self.drop_p > 0.0 and self.training):
+            return 0.0, 0
+        if self._drop_seed is None:
+            self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._drop_calls += 1
+        return self.drop_p, (self._drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls) % (1 << 63)
+
     def forward(self, users, items):
         ue, ie, ub, ib = self._tables()
         out = torch.empty(users.numel(), device=ue.device, dtype=torch.float32)
+        p, seed = self._dropout_now()
         _lib.check(_lib.lib().rk_pair_scores(
             self.dim, _lib.ptr(ue.data), _lib.ptr(ie.data), _lib.ptr(ub.data), _lib.ptr(ib.data), float(self.mean.item()),
             _lib.ptr(users.long().contiguous()), _lib.ptr(items.long().contiguous()), users.numel(), _lib.ptr(out),
-            _lib.stream_ptr()), "rk_pair_scores")
+            p, seed, _lib.stream_ptr()), "rk_pair_scores")
         return out
+
+    def score_matrix(self, user_ids, out):
+        """out[len(user_ids), n_items] <- MF.forward over the full catalogue of each user, through the module's
+        dropout when it is active (rk_score_matrix); the batched evaluation then runs rk_topk_rows on it."""
+        ue, ie, ub, ib = self._tables()
+        p, seed = self._dropout_now()
+        _lib.check(_lib.lib().rk_score_matrix(
+            self.dim, _lib.ptr(ue.data), user_ids.numel(), _lib.ptr(user_ids), _lib.ptr(ie.data), self.num_items,
+            _lib.ptr(ub.data.reshape(-1)), _lib.ptr(ib.data.reshape(-1)), float(self.mean.item()), p, seed, _lib.ptr(out),
+            _lib.stream_ptr()), "rk_score_matrix")
 
     def _run_epoch(self, users, items, labels, batch, apply_update=True):
         ue, ie, ub, ib = self._tables()
@@ -96,7 +120,8 @@ class MF(BaseVictim):
             self.num_users, self.num_items, self.dim, _lib.ptr(ue.data), _lib.ptr(ie.data), _lib.ptr(ub.data),
             _lib.ptr(ib.data), float(self.mean.item()), _lib.ptr(m), _lib.ptr(v), _lib.ptr(grads), _lib.ptr(users),
             _lib.ptr(items), _lib.ptr(labels), n, batch, self._steps_done(), float(grp.get("lr", 1e-3)), float(b1), float(b2),
-            float(grp.get("eps", 1e-8)), _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()), "rk_mf_train_epoch")
+            float(grp.get("eps", 1e-8)), _lib.ptr(lp), 1 if apply_update else 0, *self._dropout_now(), _lib.stream_ptr()),
+            "rk_mf_train_epoch")
         if apply_update:
             for p in (ue, ie, ub, ib):
                 self.optimizer.state[p]["step"] += n_steps
@@ -127,6 +152,10 @@ class MF(BaseVictim):
         return (mean_loss,)
 
     def scoring_tables(self):
+        """Tables for the dot-product scoring path; None while a logit dropout is active (the evaluation then goes
+        through score_matrix())."""
+        if self.drop_p > 0.0 and self.training:
+            return None
         ue, ie, ub, ib = self._tables()
         return ue.data, ie.data, ub.data.reshape(-1), ib.data.reshape(-1), float(self.mean.item())
 

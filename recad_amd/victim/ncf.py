@@ -1,5 +1,6 @@
-"""NCF (NeuMF-end) victim on MI355X: same interface as recad/model/victim/ncf.py, hot path in HIP
-(recad_amd/csrc/ncf.hip: fp32-MFMA tower GEMMs, fused predict/BCE, multi-tensor Adam)."""
+"""NCF victim on MI355X (model = 'NeuMF-end' | 'NeuMF-pre' | 'MLP' | 'GMF'): same interface as
+recad/model/victim/ncf.py, hot path in HIP (recad_amd/csrc/ncf.hip: fp32-MFMA tower GEMMs, fused predict/BCE,
+counter-based dropout masks, multi-tensor Adam)."""
 import ctypes as C
 
 import torch
@@ -18,10 +19,12 @@ class NCF(BaseVictim):
         self.config = config
         info = self.dataset.info_describe()
         user_num, item_num = info["n_users"], info["n_items"]
-        if model != "NeuMF-end":
-            raise ValueError("the HIP NCF path implements model='NeuMF-end' (the reference default) only")
-        if dropout:
-            raise ValueError("dropout is not supported by the HIP path (reference default is 0)")
+        if model not in ("NeuMF-end", "NeuMF-pre", "MLP", "GMF"):
+            raise ValueError(f"model must be one of 'MLP', 'GMF', 'NeuMF-end', 'NeuMF-pre' (ncf.py:19), got {model!r}")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+        if model == "NeuMF-pre" and (GMF_model is None or MLP_model is None):
+            raise ValueError("model='NeuMF-pre' needs the pre-trained GMF_model and MLP_model (ncf.py:78-110)")
         if not 1 <= num_layers <= 8:
             raise ValueError("num_layers must be in [1, 8]")
         self.dropout, self.model, self.GMF_model, self.MLP_model = dropout, model, GMF_model, MLP_model
@@ -39,21 +42,41 @@ class NCF(BaseVictim):
             width = factor_num * (2 ** (num_layers - i))
             mods += [nn.Dropout(p=dropout), nn.Linear(width, width // 2), nn.ReLU()]
         self.MLP_layers = nn.Sequential(*mods)
-        self.predict_layer = nn.Linear(factor_num * 2, 1)
-        for emb in (self.embed_user_GMF, self.embed_user_MLP, self.embed_item_GMF, self.embed_item_MLP):
-            nn.init.normal_(emb.weight, std=0.01)
-        for m in self.MLP_layers:
-            if isinstance(m, nn.Linear):
-                nn.init.xavier_uniform_(m.weight)
-        nn.init.kaiming_uniform_(self.predict_layer.weight, a=1, nonlinearity="sigmoid")
-        for m in self.modules():
-            if isinstance(m, nn.Linear) and m.bias is not None:
-                m.bias.data.zero_()
+        self.predict_layer = nn.Linear(factor_num if model in ("MLP", "GMF") else factor_num * 2, 1)   # ncf.py:49-53
+        if model != "NeuMF-pre":
+            for emb in (self.embed_user_GMF, self.embed_user_MLP, self.embed_item_GMF, self.embed_item_MLP):
+                nn.init.normal_(emb.weight, std=0.01)
+            for m in self.MLP_layers:
+                if isinstance(m, nn.Linear):
+                    nn.init.xavier_uniform_(m.weight)
+            nn.init.kaiming_uniform_(self.predict_layer.weight, a=1, nonlinearity="sigmoid")
+            for m in self.modules():
+                if isinstance(m, nn.Linear) and m.bias is not None:
+                    m.bias.data.zero_()
+        else:
+            # ncf.py:78-110: embeddings and tower from the pre-trained GMF / MLP models, the predict layer the
+            # concatenation of theirs, halved
+            with torch.no_grad():
+                self.embed_user_GMF.weight.copy_(GMF_model.embed_user_GMF.weight.to("cpu"))
+                self.embed_item_GMF.weight.copy_(GMF_model.embed_item_GMF.weight.to("cpu"))
+                self.embed_user_MLP.weight.copy_(MLP_model.embed_user_MLP.weight.to("cpu"))
+                self.embed_item_MLP.weight.copy_(MLP_model.embed_item_MLP.weight.to("cpu"))
+                for m1, m2 in zip(self.MLP_layers, MLP_model.MLP_layers):
+                    if isinstance(m1, nn.Linear) and isinstance(m2, nn.Linear):
+                        m1.weight.copy_(m2.weight.to("cpu"))
+                        m1.bias.copy_(m2.bias.to("cpu"))
+                pw = torch.cat([GMF_model.predict_layer.weight.to("cpu"), MLP_model.predict_layer.weight.to("cpu")], dim=1)
+                self.predict_layer.weight.copy_(0.5 * pw)
+                self.predict_layer.bias.copy_(0.5 * (GMF_model.predict_layer.bias.to("cpu") + MLP_model.predict_layer.bias.to("cpu")))
         self.optimizer = pick_optim(config["optim"])(self.parameters(), lr=config["lr"])
         self.loss_func = nn.BCEWithLogitsLoss()
         self._E = E
         self._ws = None
         self._fused_adam = self._adam_is_fused()
+        self._mode = {"NeuMF-end": 0, "NeuMF-pre": 0, "MLP": 1, "GMF": 2}[model]
+        self.drop_p = float(dropout)
+        self._drop_seed = None   # drawn from torch's global RNG on first use (nn.Dropout draws its masks from it)
+        self._drop_calls = 0
         self.max_batch = 16384  # forward chunk of the full-catalog evaluation: large enough for the 128x128-tile GEMM
 
     # ------------------------------------------------------------------ C-ABI descriptor
@@ -100,7 +123,12 @@ class NCF(BaseVictim):
                          ug=_lib.ptr(ts[0].data), ig=_lib.ptr(ts[1].data), um=_lib.ptr(ts[2].data), im=_lib.ptr(ts[3].data),
                          pw=_lib.ptr(ts[-2].data), pb=_lib.ptr(ts[-1].data), acts=_lib.ptr(ws["acts"]), dacts=_lib.ptr(ws["dacts"]),
                          d0=_lib.ptr(ws["d0"]), max_batch=ws["max_batch"], gemm_scratch=_lib.ptr(ws["gemm_scratch"]),
-                         gemm_scratch_floats=ws["gemm_scratch"].numel(), wgrad_part=_lib.ptr(ws["wgrad_part"]))
+                         gemm_scratch_floats=ws["gemm_scratch"].numel(), wgrad_part=_lib.ptr(ws["wgrad_part"]), mode=self._mode)
+        if self.drop_p > 0.0 and self.training:   # also while the workflows score without .eval() (normal.py:61-67)
+            if self._drop_seed is None:
+                self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._drop_calls += 1
+            d.dropout, d.drop_seed, d.drop_call = self.drop_p, self._drop_seed, self._drop_calls & 0x7FFFFFFF
         for l in range(L):
             d.W[l] = ts[4 + l].data.data_ptr()
             d.b[l] = ts[4 + L + l].data.data_ptr()

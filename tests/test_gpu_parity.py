@@ -1420,3 +1420,192 @@ def test_mf_full_size_ml1m(gpu_device):
     rank = got["target_rank"].cpu().numpy()[sel, 0]
     for i, k in enumerate([10, 20, 50, 100]):
         assert np.array_equal((rank < k).astype(np.float64), rows[:, 2 + i])
+
+
+def _drop_keep(seed_step, n, keep_prob):
+    """numpy mirror of rk_drop_keep (recad_amd/csrc/common.h) for element ids 0..n-1"""
+    with np.errstate(over="ignore"):
+        ids = np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)
+        u24 = _mix64(np.uint64(seed_step) ^ ids) >> np.uint64(40)
+    return u24 < np.uint64(int((1.0 - (1.0 - float(keep_prob))) * 16777216.0))
+
+
+def _step_seed(base, step):
+    with np.errstate(over="ignore"):
+        return int(_mix64(np.uint64(base) ^ _mix64(np.uint64(step))))
+
+
+def _torch_ncf(params, mode, f, L, users, items, drop=None):
+    """ncf.py:112-131 in plain ATen on the CPU; drop = (p, [mask_l as float tensors]) applies explicit dropout masks"""
+    ug, ig, um, im, W, b, pw, pb = params
+    x = torch.cat([um[users], im[items]], dim=1)
+    for l in range(L):
+        if drop is not None:
+            x = x * drop[1][l] / (1.0 - drop[0])
+        x = torch.relu(x @ W[l].t() + b[l])
+    gmf = ug[users] * ig[items]
+    concat = gmf if mode == "GMF" else x if mode == "MLP" else torch.cat([gmf, x], dim=1)
+    return (concat @ pw.t()).view(-1) + pb
+
+
+@pytest.mark.parametrize("variant", ["MLP", "GMF", "NeuMF-end"])
+def test_ncf_model_variants(gpu_device, variant):
+    """NCF model in {MLP, GMF, NeuMF-end} (ncf.py:49-52,112-131): forward, two fused Adam steps and the evaluation hook
+    against a plain-ATen restatement on the CPU."""
+    from recad_amd import model
+    g = G.load("ncf_dev_f8_l3")
+    f, L = 8, 3
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    torch.manual_seed(5)
+    m = model.from_config("victim", "ncf", factor_num=f, num_layers=L, model=variant).I(dataset=ds)
+    assert m.predict_layer.weight.shape[1] == (f if variant in ("MLP", "GMF") else 2 * f)
+    lin = [x for x in m.MLP_layers if isinstance(x, torch.nn.Linear)]
+    for x in lin:   # larger weights than the 0.01 init so that gradients are well above rounding noise
+        x.bias.data.uniform_(-0.05, 0.05)
+    for e in (m.embed_user_GMF, m.embed_item_GMF, m.embed_user_MLP, m.embed_item_MLP):
+        e.weight.data.normal_(0, 0.3)
+    ref = [torch.nn.Parameter(t.detach().clone()) for t in (m.embed_user_GMF.weight, m.embed_item_GMF.weight, m.embed_user_MLP.weight,
+                                                             m.embed_item_MLP.weight)]
+    refW = [torch.nn.Parameter(x.weight.detach().clone()) for x in lin]
+    refb = [torch.nn.Parameter(x.bias.detach().clone()) for x in lin]
+    refpw, refpb = torch.nn.Parameter(m.predict_layer.weight.detach().clone()), torch.nn.Parameter(m.predict_layer.bias.detach().clone())
+    m = m.to(gpu_device)
+    used = {"MLP": ref[2:] + refW + refb + [refpw, refpb], "GMF": ref[:2] + [refpw, refpb]}.get(variant, ref + refW + refb + [refpw, refpb])
+    opt = torch.optim.Adam(used, lr=1e-3)
+    for s_ in (0, 1):
+        n = int(g["batch_len"][s_])
+        u, i, y = (torch.from_numpy(g["batches"][s_, k, :n].astype(np.int64)) for k in range(3))
+        logit = _torch_ncf((*ref, refW, refb, refpw, refpb), variant, f, L, u, i)
+        if s_ == 0:
+            got = m(u.to(gpu_device), i.to(gpu_device)).cpu()
+            assert torch.allclose(got, logit.detach(), rtol=1e-5, atol=1e-6)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, y.float())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ds.steps = [s_]
+        (l_gpu,) = m.train_step()
+        assert abs(l_gpu - float(loss)) <= 2e-5 * abs(float(loss)), (variant, s_, l_gpu, float(loss))
+    names = ["embed_user_GMF", "embed_item_GMF", "embed_user_MLP", "embed_item_MLP"]
+    for nme, r in zip(names, ref):
+        ok, info = G.adam_close(getattr(m, nme).weight.detach().cpu().numpy(), r.detach().numpy(), 1e-3, 2, outlier_frac=5e-3, travel_frac=0.5)
+        assert ok, (variant, nme, info)
+    for x, rw, rb in zip(lin, refW, refb):
+        ok, info = G.adam_close(x.weight.detach().cpu().numpy(), rw.detach().numpy(), 1e-3, 2, outlier_frac=5e-3, travel_frac=0.5)
+        assert ok, (variant, "W", info)
+    assert torch.allclose(m.predict_layer.weight.detach().cpu(), refpw.detach(), rtol=0, atol=1.2e-3)
+    # evaluation hook: score_matrix == forward over the catalogue
+    ids = torch.tensor([3, 100, 7], dtype=torch.int32, device=gpu_device)
+    out = torch.empty(3 * m.num_items, device=gpu_device)
+    m.score_matrix(ids, out)
+    it = torch.arange(m.num_items, device=gpu_device)
+    for r, uu in enumerate(ids.tolist()):
+        assert torch.equal(out[r * m.num_items:(r + 1) * m.num_items], m(torch.full_like(it, uu), it))
+
+
+def test_ncf_neumf_pre_initialisation(gpu_device):
+    """model='NeuMF-pre' (ncf.py:78-110): tables and tower copied from the pre-trained GMF / MLP victims, the predict
+    layer = 0.5 * [GMF | MLP]; its first forward is the mean of the two pre-trained models' logits."""
+    from recad_amd import model
+    g = G.load("ncf_dev_f8_l3")
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    torch.manual_seed(1)
+    gmf = model.from_config("victim", "ncf", factor_num=8, num_layers=3, model="GMF").I(dataset=ds).to(gpu_device)
+    mlp = model.from_config("victim", "ncf", factor_num=8, num_layers=3, model="MLP").I(dataset=ds).to(gpu_device)
+    for v in (gmf, mlp):
+        for e in (v.embed_user_GMF, v.embed_item_GMF, v.embed_user_MLP, v.embed_item_MLP):
+            e.weight.data.normal_(0, 0.3)
+        v.train_step()
+    pre = model.from_config("victim", "ncf", factor_num=8, num_layers=3, model="NeuMF-pre", GMF_model=gmf, MLP_model=mlp).I(dataset=ds).to(gpu_device)
+    assert torch.equal(pre.embed_user_GMF.weight, gmf.embed_user_GMF.weight) and torch.equal(pre.embed_item_MLP.weight, mlp.embed_item_MLP.weight)
+    u = torch.arange(0, 400, device=gpu_device)
+    i = (u * 3) % pre.num_items
+    want = 0.5 * (gmf(u, i) + mlp(u, i))
+    assert torch.allclose(pre(u, i), want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception):
+        model.from_config("victim", "ncf", model="NeuMF-pre").I(dataset=ds)
+
+
+def test_ncf_and_mf_dropout(gpu_device):
+    """dropout > 0 (ncf.py:44, mf.py:27,47): the HIP path draws counter-based masks; fed with the SAME masks a plain-ATen
+    restatement gives the same loss and gradients.  Scoring in training mode stays stochastic (the workflows never
+    call .eval(), normal.py:61-67); .eval() switches it off."""
+    from recad_amd import model
+    g = G.load("ncf_dev_f8_l3")
+    f, L, p, seed = 8, 3, 0.3, 0x5EED1234
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    torch.manual_seed(9)
+    m = model.from_config("victim", "ncf", factor_num=f, num_layers=L, dropout=p).I(dataset=ds)
+    for e in (m.embed_user_GMF, m.embed_item_GMF, m.embed_user_MLP, m.embed_item_MLP):
+        e.weight.data.normal_(0, 0.3)
+    lin = [x for x in m.MLP_layers if isinstance(x, torch.nn.Linear)]
+    ref = [t.detach().clone().requires_grad_(True) for t in (m.embed_user_GMF.weight, m.embed_item_GMF.weight, m.embed_user_MLP.weight,
+                                                            m.embed_item_MLP.weight)]
+    refW = [x.weight.detach().clone().requires_grad_(True) for x in lin]
+    refb = [x.bias.detach().clone().requires_grad_(True) for x in lin]
+    refpw, refpb = m.predict_layer.weight.detach().clone().requires_grad_(True), m.predict_layer.bias.detach().clone().requires_grad_(True)
+    m = m.to(gpu_device)
+    m._drop_seed = seed
+    n = int(g["batch_len"][0])
+    u, i, y = (torch.from_numpy(g["batches"][0, k, :n].astype(np.int64)) for k in range(3))
+    part = m._run_epoch(u.to(gpu_device), i.to(gpu_device), y.to(gpu_device), n, apply_update=False)
+    # masks of optimizer step 0, layer l: elements of the [n, in_l] layer input in row-major order
+    masks = []
+    for l in range(L):
+        width = f * 2 ** (L - l)
+        keep = _drop_keep(_step_seed(seed, 0 * 16 + l), n * width, 1.0 - p)
+        masks.append(torch.from_numpy(keep.reshape(n, width).astype(np.float32)))
+    assert 0.6 < float(masks[0].mean()) < 0.8
+    logit = _torch_ncf((*ref, refW, refb, refpw, refpb), "NeuMF-end", f, L, u, i, drop=(p, masks))
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, y.float())
+    loss.backward()
+    assert abs(float(part.sum()) - float(loss)) <= 2e-5 * abs(float(loss))
+    got = m._ws["grad"]
+    for k_, r in enumerate(ref + refW + refb + [refpw, refpb]):
+        assert G.relerr(got[k_].cpu().numpy(), r.grad.numpy().reshape(tuple(got[k_].shape))) < 5e-5, k_
+    # scoring: stochastic in training mode, deterministic and dropout-free after .eval()
+    uu = torch.arange(0, 300, device=gpu_device)
+    ii = (uu * 5) % m.num_items
+    a, b_ = m(uu, ii), m(uu, ii)
+    assert not torch.equal(a, b_)
+    m.eval()
+    c, d_ = m(uu, ii), m(uu, ii)
+    assert torch.equal(c, d_)
+    logit_eval = _torch_ncf(tuple(t.detach() for t in ref) + ([w.detach() for w in refW], [x.detach() for x in refb], refpw.detach(), refpb.detach()),
+                            "NeuMF-end", f, L, uu.cpu(), ii.cpu())
+    assert torch.allclose(c.cpu(), logit_eval, rtol=1e-5, atol=1e-6)
+
+    # ---- MF: dropout on the logit
+    gm = G.load("mf_dev_e64")
+    dsm = ReplayDataset(gm, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    mf = model.from_config("victim", "mf", embedding_size=int(gm["dim"]), dropout=0.25).I(dataset=dsm)
+    init = G.mf_init(gm)
+    for pr, a_ in zip((mf.user_emb, mf.item_emb, mf.user_bias, mf.item_bias), init):
+        pr.weight.data.copy_(torch.from_numpy(a_))
+    mf = mf.to(gpu_device)
+    mf._drop_seed = seed
+    n = int(gm["batch_len"][0])
+    u, i, y = (torch.from_numpy(gm["batches"][0, k, :n].astype(np.int64)) for k in range(3))
+    part = mf._run_epoch(u.to(gpu_device), i.to(gpu_device), y.to(gpu_device), n, apply_update=False)
+    call_seed = (seed + 0x9E3779B97F4A7C15 * 1) % (1 << 63)
+    keep = torch.from_numpy(_drop_keep(_step_seed(call_seed, 0), n, 0.75).astype(np.float32))
+    ps = [torch.from_numpy(a_.copy()).requires_grad_(True) for a_ in init]
+    logit = ((ps[0][u] * ps[1][i]).sum(1) + ps[2][u].view(-1) + ps[3][i].view(-1) + float(gm["mean"])) * keep / 0.75
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, y.float())
+    loss.backward()
+    assert abs(float(part.sum()) - float(loss)) <= 2e-5 * abs(float(loss))
+    gflat = mf._flat["g"].cpu().numpy()
+    U, I, d = mf.num_users, mf.num_items, mf.dim
+    assert G.relerr(gflat[: U * d].reshape(U, d), ps[0].grad.numpy()) < 2e-5
+    assert G.relerr(gflat[(U + I) * d:(U + I) * d + U], ps[2].grad.numpy().reshape(-1)) < 2e-5
+    # evaluation in training mode goes through score_matrix (dropped scores are exactly 0), in eval mode through the tables
+    from recad_amd.evaluate import full_catalog_topk
+    assert mf.scoring_tables() is None
+    out = torch.empty(4 * I, device=gpu_device)
+    mf.score_matrix(torch.arange(4, dtype=torch.int32, device=gpu_device), out)
+    frac0 = float((out == 0).float().mean())
+    assert 0.2 < frac0 < 0.3
+    res = full_catalog_topk(mf, np.arange(8, dtype=np.int32), gm["train_ptr"], gm["train_idx"], [0], K=10)
+    assert res["top_ids"].shape == (8, 10)
+    mf.eval()
+    assert mf.scoring_tables() is not None
