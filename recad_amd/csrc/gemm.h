@@ -426,7 +426,9 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
     // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
     int tpb = (g.K <= 64) ? nwg128 / 1024 : 1;
-    tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+    static const int tpb_env = getenv("RK_GEMM_TPB") ? atoi(getenv("RK_GEMM_TPB")) : 0;   // tuning only
+    if (tpb_env > 0) tpb = tpb_env;
+    tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
     const dim3 grid((nwg128 + tpb - 1) / tpb);
     // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
     // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
