@@ -59,13 +59,19 @@ def parse(argv=None):
                     help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default) or one "
                          "independent victim replica per GPU (weak scaling, no data-path collective)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the workers")
+    ap.add_argument("--gather", default="collective", choices=["collective", "direct"],
+                    help="rows mode: all_gather_into_tensor (RCCL picks the algorithm) or one batched group of W-1 sends / receives "
+                         "per rank (one-shot all-gather over the xGMI mesh)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N=1 with --parallel rows: keep every collective of the sharded trainer (one-rank RCCL group): "
+                         "exercises the real all-gather / all-reduce calls, async handles and stream ordering on a 1-GPU box")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
     a = ap.parse_args(argv)
     if a.workload is None:
         a.workload = "ml1m" if a.gpus == 1 else "config4"
     if a.parallel is None:
-        a.parallel = "rows" if a.gpus > 1 else "replicas"
+        a.parallel = "rows" if (a.gpus > 1 or a.force_collectives) else "replicas"
     if a.dim is None:
         a.dim = 128 if a.workload == "yelp" else 64
     if a.steps is None:
@@ -245,20 +251,23 @@ def worker(args):
 
     # gloo workers may share one GPU (the 1-GPU box check of the sharded path); nccl needs one GPU per rank
     n_dev = torch.cuda.device_count()
-    local_dev = local % max(n_dev, 1) if args.backend == "gloo" else local
+    share = args.backend == "gloo" or os.environ.get("RECAD_BENCH_SHARE_GPU") == "1"   # (box check: several ranks on one GPU)
+    local_dev = local % max(n_dev, 1) if share else local
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    if world > 1 or args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import recad_amd  # noqa: F401
     from recad_amd import _lib, dataset, model, synth
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 
-    rows_mode = world > 1 and args.parallel == "rows"
+    rows_mode = (world > 1 or args.force_collectives) and args.parallel == "rows"
     B = args.batch
 
     # ---------------- workload: synthetic interactions of the named shape, resident on the GPU
@@ -297,7 +306,8 @@ def worker(args):
         for p_ in victim.parameters():
             dist.broadcast(p_.data, src=0)
         sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
-                                  victim.embedding_user.weight, victim.embedding_item.weight, device=dev)
+                                  victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
+                                  gather=args.gather, force_collectives=args.force_collectives)
         sharded.reserve(max(args.steps, args.warmup) * B, B)
     else:
         victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
@@ -310,7 +320,7 @@ def worker(args):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.force_collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -462,7 +472,7 @@ def worker(args):
             "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.barrier()
         dist.destroy_process_group()
 

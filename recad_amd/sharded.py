@@ -175,7 +175,7 @@ class ShardedLightGCN:
     in place: the slab is cut on the device)."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective"):
+                 eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective", force_collectives=False):
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -187,9 +187,12 @@ class ShardedLightGCN:
         self.lam, self.lr, self.betas, self.eps = lam, lr, betas, eps
         self.N = self.U + self.I
         if chunks is None:  # overlap only pays when there is a collective to hide and the slab is big
-            chunks = 2 if (self.world > 1 and self.N // self.world >= 4096) else 1
+            chunks = 2 if ((self.world > 1 or force_collectives) and self.N // self.world >= 4096) else 1
         self.layout = RowLayout(self.N, self.world, chunks)
         self.gather_mode = gather
+        # W == 1 normally short-circuits every collective to a copy; force_collectives keeps them (a one-rank RCCL
+        # group on a single-GPU box exercises the real collective calls, their async handles and stream ordering)
+        self.force_collectives = bool(force_collectives) and on
         self.device = torch.device(device) if device is not None else user_emb.device
         if hasattr(csr, "rowptr"):
             rowptr, col, val = csr.rowptr, csr.col, csr.val
@@ -225,7 +228,7 @@ class ShardedLightGCN:
         return self.world > 1 and self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
 
     def _all_reduce(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         if self._host_staged():
             h = t.cpu()
@@ -238,7 +241,7 @@ class ShardedLightGCN:
         """all-gather chunk c (rows [c*Mc, (c+1)*Mc) of a local [M,d] buffer) into its block of out_full."""
         L, W = self.layout, self.world
         blk = out_full[c * W * L.Mc:(c + 1) * W * L.Mc]
-        if W == 1:
+        if W == 1 and not self.force_collectives:
             blk.copy_(local_chunk)
             return None
         if self._host_staged():
@@ -246,7 +249,7 @@ class ShardedLightGCN:
             dist.all_gather_into_tensor(h, local_chunk.cpu().contiguous(), group=self.group)
             blk.copy_(h)
             return None
-        if self.gather_mode == "direct":
+        if self.gather_mode == "direct" and W > 1:
             # one-shot: every rank sends its shard to each peer and receives theirs, all pairs at once
             # (one RCCL group of 2(W-1) point-to-point ops: each rides its own xGMI link)
             blk[self.rank * L.Mc:(self.rank + 1) * L.Mc].copy_(local_chunk)
@@ -332,7 +335,7 @@ class ShardedLightGCN:
         rows = plan["rows"][: 3 * nb]
         loc = ep["local"][:, s0:s0 + nb].reshape(-1)
         torch.index_select(self.s, 0, loc, out=rows)       # r // W is a valid local row for every node
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             rows.mul_(ep["own_f"][:, s0:s0 + nb].reshape(-1, 1))   # x*1 = x, x*0 = 0: exact, no host sync
             self._all_reduce(rows)
         ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
