@@ -305,6 +305,13 @@ def worker(args):
             dist.broadcast(t, src=0)
         for p_ in victim.parameters():
             dist.broadcast(p_.data, src=0)
+        # every rank generated the workload itself (same seed): refuse to go on if the graphs differ
+        chk = torch.stack([g.col.long().sum(), g.rowptr.long().sum(), torch.tensor(g.nnz, device=dev)]).double()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool(torch.equal(lo, hi)):
+            raise SystemExit("bench.py: the ranks generated different graphs (synthetic workload not reproducible across ranks)")
         sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
                                   victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
                                   gather=args.gather, force_collectives=args.force_collectives)
