@@ -20,6 +20,11 @@ struct GemmArgs {
     int M, N, K;
     const float *A; long long a_rs, a_cs;  // A(m,k) = A[row(m)*a_rs + k*a_cs], row(m) = a_ridx ? a_ridx[m] : m
     const int *a_ridx;                     // optional row gather of A (and of row_bias): scoring a block of user ids
+    int a_rmod, a_roff;                    // a_rmod > 0 (and a_ridx == NULL): row(m) = (m + a_roff) % a_rmod -- the full-catalog pair
+                                           // list (user q / I, item q % I) of the NCF evaluation reads the item table in place
+    const float *acc_init; int ld_init, init_base;  // optional: the accumulator of C(m, n) starts at acc_init[((m + a_roff) / a_rmod -
+                                           // init_base) * ld_init + n] instead of 0: the k-ordered chain CONTINUES a prefix computed
+                                           // once per user (layer 0 of the tower over [user | item]: the user half is shared)
     const float *B; long long b_rs, b_cs;  // B(n,k) = B[n*b_rs + k*b_cs]
     float *C; int ldc;
     const float *col_bias;                 // + col_bias[n]
@@ -58,15 +63,17 @@ __device__ __forceinline__ int tile_mode(const float *src, int n_rows, int n_k, 
 
 template <int BT, bool GATHER = false>
 __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float *__restrict__ src, int n_rows, int n_k, int r0,
-                                          int k0, long long rs, long long cs, const int *__restrict__ ridx = nullptr)
+                                          int k0, long long rs, long long cs, const int *__restrict__ ridx = nullptr, int rmod = 0,
+                                          int roff = 0)
 {
+    auto row_of = [&](int m) -> long long { return ridx ? (long long)ridx[m] : (long long)((m + roff) % rmod); };
     const int tid = threadIdx.x;
     constexpr int NP = BT / 32;  // float4 loads per thread
     if (mode == 1) {  // 8 float4 per row of 32 k: thread -> (row = p*32 + tid/8, k4 = tid%8)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = p * 32 + (tid >> 3), c = (tid & 7) * 4;
-            const long long gr = GATHER ? ridx[r0 + r] : r0 + r;
+            const long long gr = GATHER ? row_of(r0 + r) : r0 + r;
             const float4 x = *reinterpret_cast<const float4 *>(src + gr * rs + (k0 + c));
             t.v[p * 4 + 0] = x.x; t.v[p * 4 + 1] = x.y; t.v[p * 4 + 2] = x.z; t.v[p * 4 + 3] = x.w;
         }
@@ -84,7 +91,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT> &t, int mode, const float
             const int idx = p * 256 + tid;
             const int r = idx / kGK, c = idx % kGK;
             const int gr = r0 + r, gc = k0 + c;
-            t.v[p] = (gr < n_rows && gc < n_k) ? src[(long long)(GATHER ? ridx[gr] : gr) * rs + (long long)gc * cs] : 0.f;
+            t.v[p] = (gr < n_rows && gc < n_k) ? src[(GATHER ? row_of(gr) : (long long)gr) * rs + (long long)gc * cs] : 0.f;
         }
     }
 }
@@ -176,7 +183,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
     int m0, n0;
     tile_origin<BT>(t_begin, gx, gy, m0, n0);
     int ma = tile_mode<BT>(g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, GATHER), mb = tile_mode<BT>(g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
-    tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx);
+    tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m0, c_lo * kGK, g.a_rs, g.a_cs, g.a_ridx, g.a_rmod, g.a_roff);
     tile_load(tb, mb, g.B, g.N, g.K, n0, c_lo * kGK, g.b_rs, g.b_cs);
     tile_store(ta, ma, tileA(0));
     tile_store(tb, mb, tileB(0));
@@ -193,10 +200,30 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
             tile_origin<BT>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
             ma = tile_mode<BT>(g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, GATHER);
             mb = tile_mode<BT>(g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
-            tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx);
+            tile_load<BT, GATHER>(ta, ma, g.A, g.M, g.K, m1, c1 * kGK, g.a_rs, g.a_cs, g.a_ridx, g.a_rmod, g.a_roff);
             tile_load(tb, mb, g.B, g.N, g.K, n1, c1 * kGK, g.b_rs, g.b_cs);
         }
         const int kc = min(kGK, g.K - c * kGK);
+        if (GATHER && !PLAIN && g.acc_init && c == c_lo) {   // the tile's chains continue a per-user prefix
+            int mi, ni;
+            tile_origin<BT>(t_begin + it / n_chunks, gx, gy, mi, ni);
+            // rows of a tile are consecutive pairs: one division for the tile, a carry test per row
+            const int q0 = (mi + g.a_roff) / g.a_rmod, rem0 = (mi + g.a_roff) % g.a_rmod;
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = wr * WS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, m = mi + dm;
+                    const int t = rem0 + dm;
+                    const int q = q0 + (t >= g.a_rmod ? (g.a_rmod >= BT ? 1 : t / g.a_rmod) : 0) - g.init_base;
+                    const float *src = g.acc_init + (size_t)q * g.ld_init;
+#pragma unroll
+                    for (int j = 0; j < TA; ++j) {
+                        const int n = ni + wc * WS + j * 32 + lr;
+                        if (m < g.M && n < g.N) acc[i][j][r] = src[n];
+                    }
+                }
+        }
         float (*Ac)[kGLd] = tileA(cur);
         float (*Bc)[kGLd] = tileB(cur);
         for (int kk = 0; kk < kc; kk += 2) {
@@ -267,7 +294,7 @@ static __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmAr
                                     if (kClearInside) acc[i][j][r] = 0.f;
                                     continue;
                                 }
-                                if (g.row_bias) s = ((s + g.row_bias[GATHER ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
+                                if (g.row_bias) s = ((s + g.row_bias[(GATHER && g.a_ridx) ? g.a_ridx[m] : m]) + g.col_bias[n]) + g.const_add;
                                 else if (g.col_bias) s += g.col_bias[n];
                                 if (g.relu) s = s > 0.f ? s : 0.f;
                                 if (g.sigmoid) s = 1.f / (1.f + expf(-s));
@@ -415,7 +442,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         attr_set = true;
     }
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
-    if (nwg128 < 384 && variant != 3 && !g.a_ridx) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
+    if (nwg128 < 384 && variant != 3 && !g.a_ridx && !g.a_rmod) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         GemmArgs g2 = g;
         const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);
@@ -433,8 +460,8 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     // default: single LDS buffer + register prefetch, 3 workgroups per CU (measured 101 TF/s at K=256
     // vs 93 for the double-buffered 2-per-CU form, RK_GEMM_VARIANT=1)
     const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.mask && !g.sigmoid && !g.drop_thresh24;
-    if (g.a_ridx && plain) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, true>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
-    else if (g.a_ridx) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, false>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
+    if (g.a_ridx && plain && !g.acc_init) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, true>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
+    else if (g.a_ridx || g.a_rmod) hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3, true, false>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 2, 2>), grid, dim3(256), gemm_lds_bytes<128>(2), s, g, tpb);
     else hipLaunchKernelGGL((gemm_f32_kernel<128, 1, 3>), grid, dim3(256), gemm_lds_bytes<128>(1), s, g, tpb);
     return hipGetLastError();

@@ -349,14 +349,30 @@ static DropSpec drop_spec(const rk_ncf_desc &d, unsigned long long call, int lay
 
 // forward for one chunk of nb pairs; acts[l] = input of layer l (after its dropout), acts[L] = tower output [nb, f].
 // `call` numbers the dropout masks (train: the global step; scoring: desc.drop_call and the chunk).
-static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, unsigned long long call, hipStream_t s)
+static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, unsigned long long call, hipStream_t s,
+                             const float *prefix = nullptr)   // prefix: [users of the call][out0] layer-0 user halves
 {
     if (d.mode == RK_NCF_GMF) return RK_OK;   // no tower (ncf.py:118-127)
     const int L = d.n_layers, E = d.factor << (L - 1);
     float *x0 = d.acts;
-    hipLaunchKernelGGL(ncf_gather_kernel, dim3(std::min(2048, (nb + 3) / 4)), dim3(256), 0, s, p, nb, E, d.um, d.im, x0, drop_spec(d, call, 0));
-    RK_CHECK_LAUNCH();
-    for (int l = 0; l < L; ++l) {
+    int l_first = 0;
+    const int out0 = in_of(d, 0) / 2;
+    if (prefix) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = nb; g.N = out0; g.K = E;
+        g.A = d.im; g.a_rs = E; g.a_cs = 1; g.a_rmod = p.n_items; g.a_roff = (int)(p.off % p.n_items);
+        g.acc_init = prefix; g.ld_init = out0; g.init_base = -(int)(p.off / p.n_items);   // row = user index within the call
+        g.B = d.W[0] + E; g.b_rs = 2 * E; g.b_cs = 1;
+        g.C = d.acts + act_off(d, 1, d.max_batch); g.ldc = out0;
+        g.col_bias = d.b[0]; g.relu = 1;
+        RK_HIP(gemm_f32_launch(g, s));
+        l_first = 1;
+    } else {
+        hipLaunchKernelGGL(ncf_gather_kernel, dim3(std::min(2048, (nb + 3) / 4)), dim3(256), 0, s, p, nb, E, d.um, d.im, x0, drop_spec(d, call, 0));
+        RK_CHECK_LAUNCH();
+    }
+    for (int l = l_first; l < L; ++l) {
         const int in = in_of(d, l), out = in / 2;
         float *y = d.acts + act_off(d, l + 1, d.max_batch);
         int rc = gemm_auto(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
@@ -380,10 +396,29 @@ RK_EXPORT int rk_ncf_forward(const rk_ncf_desc *desc, const int64_t *users, cons
     if (rc) return rc;
     const rk_ncf_desc &d = *desc;
     hipStream_t s = (hipStream_t)stream;
+    // Full-catalog scoring (pair q = (user_ids[q / I], q % I)), no dropout: layer 0 over [um[u] | im[i]] is the SAME k-ordered
+    // chain for every item of a user up to k = E.  That prefix is computed once per user of the call (one GEMM over the user
+    // half of W0); layer 0 then runs over the ITEM half only with its accumulators starting at the user's prefix: bit-identical
+    // results, half the layer-0 flops (layer 0 is 3/4 of the tower), and neither the gather nor the [pairs, 2E] input exist.
+    const float *prefix = nullptr;
+    if (user_ids && d.mode != RK_NCF_GMF && !(d.dropout > 0.f) && d.gemm_scratch && n_items_catalog > 0) {
+        const int E = d.factor << (d.n_layers - 1), out0 = in_of(d, 0) / 2;
+        const long long n_u = (n + n_items_catalog - 1) / n_items_catalog;
+        if (n_u * out0 <= d.gemm_scratch_floats && E % 4 == 0) {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.M = (int)n_u; g.N = out0; g.K = E;
+            g.A = d.um; g.a_rs = E; g.a_cs = 1; g.a_ridx = user_ids;
+            g.B = d.W[0]; g.b_rs = 2 * E; g.b_cs = 1;
+            g.C = d.gemm_scratch; g.ldc = out0;
+            RK_HIP(gemm_f32_launch(g, s));
+            prefix = d.gemm_scratch;
+        }
+    }
     for (long long off = 0; off < n; off += d.max_batch) {
         const int nb = (int)std::min<long long>(d.max_batch, n - off);
         PairSrc p{users, items, user_ids, n_items_catalog, off};
-        rc = ncf_forward_chunk(d, p, nb, ((unsigned long long)d.drop_call << 24) + (unsigned long long)(off / d.max_batch) + (1ULL << 60), s);
+        rc = ncf_forward_chunk(d, p, nb, ((unsigned long long)d.drop_call << 24) + (unsigned long long)(off / d.max_batch) + (1ULL << 60), s, prefix);
         if (rc) return rc;
         hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, s, p, nb, d.factor, d.mode, d.ug, d.ig,
                            d.acts + act_off(d, d.n_layers, d.max_batch), d.pw, d.pb, out, (const int64_t *)nullptr,
