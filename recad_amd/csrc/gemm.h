@@ -430,6 +430,156 @@ static __global__ __launch_bounds__(256, 4) void gemm_f32_skinny_kernel(const Ge
             }
 }
 
+// ---- the same 64x64 tile with k-chunks of 128 ("deep"): for problems with FEW tiles and LONG K (the whole-K forward
+// GEMMs of the NCF tower at batch 1024: 128-256 workgroups, K = 1024-8192).  With 32-deep chunks such a workgroup is
+// latency-bound: 1 024 MFMA cycles per chunk against ~1 us of global-load latency + two barriers, and one workgroup per
+// CU has nobody to hide behind (measured: 70.5 us for 1024 x 1024 x 2048 = 64 chunks x 1.1 us).  128-deep chunks put
+// 4 096 MFMA cycles behind every load / barrier pair, so the chunk loop runs at the MFMA rate.  Same k-ordered chain.
+static constexpr int kDK = 128, kDLd = kDK + 4;
+struct DeepRegs { f32x4 v[8]; };   // native vectors: stay in registers across the conditional prefetch
+
+// operand form of a deep chunk: 1 = k contiguous (unit column stride), 2 = rows contiguous (unit row stride); 0 = neither.
+// The deep kernel only takes whole 64 x 128 chunks of 16-byte aligned operands -- the launcher falls back to the
+// 32-deep kernel (bounds-checked loads) for anything else.
+inline int deep_form(const float *src, long long rs, long long cs)
+{
+    if (((uintptr_t)src & 15) != 0) return 0;
+    if (cs == 1 && (rs & 3) == 0) return 1;
+    if (rs == 1 && (cs & 3) == 0) return 2;
+    return 0;
+}
+template <int MODE>
+__device__ __forceinline__ void deep_load(DeepRegs &t, const float *__restrict__ src, int r0, int k0, long long rs, long long cs)
+{
+    const int tid = threadIdx.x;
+    if (MODE == 1) {   // 32 float4 per row of 128 k: thread -> (row = p*8 + tid/32, k4 = tid%32)
+        const float *q = src + (long long)(r0 + (tid >> 5)) * rs + (k0 + (tid & 31) * 4);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 8 * rs);
+    } else {           // 16 float4 per k column of 64 rows: thread -> (k = p*16 + tid/16, row4 = tid%16)
+        const float *q = src + (long long)(k0 + (tid >> 4)) * cs + (r0 + (tid & 15) * 4);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 16 * cs);
+    }
+}
+// LDS image of a chunk.  Form 1 (k contiguous): [row][k], rows padded to 132 floats -- an operand read of a k-step touches
+// banks 4*row + k, every bank twice (the minimum for 64 lanes).  Form 2 (rows contiguous): kept as it arrives, [k][row] with
+// rows of 80 floats -- the b128 stores are conflict-free (the transposing scalar stores of the 32-deep kernel are 8-way
+// conflicted) and an operand read touches banks 16*k + row, again every bank twice.
+static constexpr int kDLdT = 64 + 16;
+template <int MODE> constexpr int deep_floats() { return MODE == 1 ? 64 * kDLd : kDK * kDLdT; }
+template <int MODE>
+__device__ __forceinline__ void deep_store(const DeepRegs &t, float *dst)
+{
+    const int tid = threadIdx.x;
+    if (MODE == 1) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 8 + (tid >> 5)) * kDLd + (tid & 31) * 4) = t.v[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 16 + (tid >> 4)) * kDLdT + (tid & 15) * 4) = t.v[p];
+    }
+}
+// operand of k-step `st` for the 16-row block `i` of a wave's sub-tile: base points at (row l16 of the sub-tile, k = lq)
+template <int MODE>
+__device__ __forceinline__ float deep_operand(const float *base, int i, int st)
+{
+    return MODE == 1 ? base[i * 16 * kDLd + st * 4] : base[st * 4 * kDLdT + i * 16];
+}
+
+template <int MA, int MB>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_skinny_deep_kernel(const GemmArgs g)
+{
+    constexpr int BT = 64;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *sA = dsm, *sB = dsm + deep_floats<MA>();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int gx = g.N / BT;
+    const int m0 = ((int)blockIdx.x / gx) * BT, n0 = ((int)blockIdx.x % gx) * BT;
+    // K-slice in units of 32-deep chunks, as gemm_effective_splits counts them (the launcher made it a multiple of 4)
+    const int all_chunks = g.K / kGK;
+    const int splits = g.split_k > 1 ? g.split_k : 1;
+    const int per = (all_chunks + splits - 1) / splits;
+    const int c_lo = (int)blockIdx.y * per, c_hi = min(all_chunks, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int k_lo = c_lo * kGK, k_end = c_hi * kGK;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l16 = lane & 15, lq = lane >> 4;
+    DeepRegs ta, tb;
+    deep_load<MA>(ta, g.A, m0, k_lo, g.a_rs, g.a_cs);
+    deep_load<MB>(tb, g.B, n0, k_lo, g.b_rs, g.b_cs);
+    deep_store<MA>(ta, sA);
+    deep_store<MB>(tb, sB);
+    __syncthreads();
+    const float *pa = MA == 1 ? sA + (wr * 32 + l16) * kDLd + lq : sA + lq * kDLdT + wr * 32 + l16;
+    const float *pb = MB == 1 ? sB + (wc * 32 + l16) * kDLd + lq : sB + lq * kDLdT + wc * 32 + l16;
+    for (int k0 = k_lo; k0 < k_end; k0 += kDK) {
+        const bool more = k0 + kDK < k_end;
+        if (more) {  // the next chunk's global loads fly under this chunk's 128 MFMAs per wave
+            deep_load<MA>(ta, g.A, m0, k0 + kDK, g.a_rs, g.a_cs);
+            deep_load<MB>(tb, g.B, n0, k0 + kDK, g.b_rs, g.b_cs);
+        }
+        // operands of k-step s+1 are read from LDS before the MFMAs of step s issue: with one wave per SIMD nobody else
+        // hides the ds_read latency
+        float av[2][2], bv[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            av[0][i] = deep_operand<MA>(pa, i, 0);
+            bv[0][i] = deep_operand<MB>(pb, i, 0);
+        }
+#pragma unroll
+        for (int st = 0; st < kDK / 4; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < kDK / 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[nxt][i] = deep_operand<MA>(pa, i, st + 1);
+                    bv[nxt][i] = deep_operand<MB>(pb, i, st + 1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // everyone is done reading the buffer
+        if (more) {
+            deep_store<MA>(ta, sA);
+            deep_store<MB>(tb, sB);
+        }
+        __syncthreads();
+    }
+    // accumulator register r of a 16x16 block = row 4*(lane>>4) + r, column lane&15
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + i * 16 + 4 * lq + r, n = n0 + wc * 32 + j * 16 + l16;
+                if (m < g.M && n < g.N) {
+                    float s = acc[i][j][r];
+                    if (splits > 1) {
+                        if (g.sk_part) g.sk_part[(size_t)blockIdx.y * g.sk_stride + (size_t)m * g.ldc + n] = s;
+                        else unsafeAtomicAdd(&g.C[(size_t)m * g.ldc + n], s);
+                        continue;
+                    }
+                    if (g.row_bias) s = ((s + g.row_bias[m]) + g.col_bias[n]) + g.const_add;
+                    else if (g.col_bias) s += g.col_bias[n];
+                    if (g.relu) s = s > 0.f ? s : 0.f;
+                    if (g.sigmoid) s = 1.f / (1.f + expf(-s));
+                    if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                    if (g.drop_thresh24) s = rk_drop_keep(g.drop_seed, (unsigned)((size_t)m * g.N + n), g.drop_thresh24) ? s * g.drop_scale : 0.f;
+                    g.C[(size_t)m * g.ldc + n] = s;
+                }
+            }
+}
+
 // asynchronous launch; returns the hipError_t of the launch
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
@@ -446,8 +596,31 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         GemmArgs g2 = g;
         const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);
+        // whole 64 x 128 chunks of aligned operands and >= 512 of K per slice: the 128-deep chunk loop (MFMA-rate)
+        const int chunks = (g.K + kGK - 1) / kGK, per = (chunks + splits - 1) / splits;
+        static const int no_deep = getenv("RK_GEMM_NO_DEEP") ? atoi(getenv("RK_GEMM_NO_DEEP")) : 0;   // A/B only
+        const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
+        const bool deep = !no_deep && variant != 4 && fa && fb && g.M % 64 == 0 && g.N % 64 == 0 && g.K % kDK == 0 && per % 4 == 0 &&
+                          per * kGK >= 512;
         if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
-        else hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(nwg, splits), dim3(256), 0, s, g2);
+        else if (deep) {
+            const int lds = (deep_floats<1>() > deep_floats<2>() ? 2 * deep_floats<1>() : 2 * deep_floats<2>()) * (int)sizeof(float);
+            static bool deep_attr = false;
+            if (!deep_attr) {
+                const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2>),
+                                     reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2>)};
+                for (const void *f : fn) {
+                    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    if (e != hipSuccess) return e;
+                }
+                deep_attr = true;
+            }
+            const size_t la = (fa == 1 ? deep_floats<1>() : deep_floats<2>()) * sizeof(float), lb = (fb == 1 ? deep_floats<1>() : deep_floats<2>()) * sizeof(float);
+            if (fa == 1 && fb == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<1, 1>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
+            else if (fa == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<1, 2>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
+            else if (fb == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<2, 1>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
+            else hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<2, 2>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
+        } else hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(nwg, splits), dim3(256), 0, s, g2);
         return hipGetLastError();
     }
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
