@@ -448,55 +448,58 @@ inline int deep_form(const float *src, long long rs, long long cs)
     if (rs == 1 && (cs & 3) == 0) return 2;
     return 0;
 }
-template <int MODE>
+template <int MODE, int ROWS>
 __device__ __forceinline__ void deep_load(DeepRegs &t, const float *__restrict__ src, int r0, int k0, long long rs, long long cs)
 {
     const int tid = threadIdx.x;
+    constexpr int NP = ROWS / 8, LPC = ROWS / 4;   // float4 loads per thread; lanes per k column (form 2)
     if (MODE == 1) {   // 32 float4 per row of 128 k: thread -> (row = p*8 + tid/32, k4 = tid%32)
         const float *q = src + (long long)(r0 + (tid >> 5)) * rs + (k0 + (tid & 31) * 4);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 8 * rs);
-    } else {           // 16 float4 per k column of 64 rows: thread -> (k = p*16 + tid/16, row4 = tid%16)
-        const float *q = src + (long long)(k0 + (tid >> 4)) * cs + (r0 + (tid & 15) * 4);
+        for (int p = 0; p < NP; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 8 * rs);
+    } else {           // ROWS/4 float4 per k column: thread -> (k = p*(256/LPC) + tid/LPC, row4 = tid%LPC)
+        const float *q = src + (long long)(k0 + tid / LPC) * cs + (r0 + (tid % LPC) * 4);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 16 * cs);
+        for (int p = 0; p < NP; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * (256 / LPC) * cs);
     }
 }
 // LDS image of a chunk.  Form 1 (k contiguous): [row][k], rows padded to 132 floats -- an operand read of a k-step touches
 // banks 4*row + k, every bank twice (the minimum for 64 lanes).  Form 2 (rows contiguous): kept as it arrives, [k][row] with
-// rows of 80 floats -- the b128 stores are conflict-free (the transposing scalar stores of the 32-deep kernel are 8-way
+// rows of ROWS+16 floats -- the b128 stores are conflict-free (the transposing scalar stores of the 32-deep kernel are 8-way
 // conflicted) and an operand read touches banks 16*k + row, again every bank twice.
-static constexpr int kDLdT = 64 + 16;
-template <int MODE> constexpr int deep_floats() { return MODE == 1 ? 64 * kDLd : kDK * kDLdT; }
-template <int MODE>
+template <int MODE, int ROWS> constexpr int deep_floats() { return MODE == 1 ? ROWS * kDLd : kDK * (ROWS + 16); }
+template <int MODE, int ROWS>
 __device__ __forceinline__ void deep_store(const DeepRegs &t, float *dst)
 {
     const int tid = threadIdx.x;
+    constexpr int NP = ROWS / 8, LPC = ROWS / 4;
     if (MODE == 1) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 8 + (tid >> 5)) * kDLd + (tid & 31) * 4) = t.v[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 8 + (tid >> 5)) * kDLd + (tid & 31) * 4) = t.v[p];
     } else {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 16 + (tid >> 4)) * kDLdT + (tid & 15) * 4) = t.v[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4 *>(dst + (p * (256 / LPC) + tid / LPC) * (ROWS + 16) + (tid % LPC) * 4) = t.v[p];
     }
 }
 // operand of k-step `st` for the 16-row block `i` of a wave's sub-tile: base points at (row l16 of the sub-tile, k = lq)
-template <int MODE>
+template <int MODE, int ROWS>
 __device__ __forceinline__ float deep_operand(const float *base, int i, int st)
 {
-    return MODE == 1 ? base[i * 16 * kDLd + st * 4] : base[st * 4 * kDLdT + i * 16];
+    return MODE == 1 ? base[i * 16 * kDLd + st * 4] : base[st * 4 * (ROWS + 16) + i * 16];
 }
 
-template <int MA, int MB>
+// BM = rows of C per workgroup: 64 (each wave 32x32 as 2x2 accumulators) or 32 (each wave 16x32 as 1x2) -- the latter
+// doubles the workgroup count for problems that would leave CUs idle (forward layers with N <= 512 at batch 1024).
+template <int MA, int MB, int BM>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_skinny_deep_kernel(const GemmArgs g)
 {
-    constexpr int BT = 64;
+    constexpr int BN = 64, TI = BM / 32, HM = BM / 2;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float *sA = dsm, *sB = dsm + deep_floats<MA>();
+    float *sA = dsm, *sB = dsm + deep_floats<MA, BM>();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
-    const int gx = g.N / BT;
-    const int m0 = ((int)blockIdx.x / gx) * BT, n0 = ((int)blockIdx.x % gx) * BT;
+    const int gx = g.N / BN;
+    const int m0 = ((int)blockIdx.x / gx) * BM, n0 = ((int)blockIdx.x % gx) * BN;
     // K-slice in units of 32-deep chunks, as gemm_effective_splits counts them (the launcher made it a multiple of 4)
     const int all_chunks = g.K / kGK;
     const int splits = g.split_k > 1 ? g.split_k : 1;
@@ -504,64 +507,62 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2
     const int c_lo = (int)blockIdx.y * per, c_hi = min(all_chunks, c_lo + per);
     if (c_lo >= c_hi) return;
     const int k_lo = c_lo * kGK, k_end = c_hi * kGK;
-    f32x4 acc[2][2];
+    f32x4 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int l16 = lane & 15, lq = lane >> 4;
     DeepRegs ta, tb;
-    deep_load<MA>(ta, g.A, m0, k_lo, g.a_rs, g.a_cs);
-    deep_load<MB>(tb, g.B, n0, k_lo, g.b_rs, g.b_cs);
-    deep_store<MA>(ta, sA);
-    deep_store<MB>(tb, sB);
+    deep_load<MA, BM>(ta, g.A, m0, k_lo, g.a_rs, g.a_cs);
+    deep_load<MB, BN>(tb, g.B, n0, k_lo, g.b_rs, g.b_cs);
+    deep_store<MA, BM>(ta, sA);
+    deep_store<MB, BN>(tb, sB);
     __syncthreads();
-    const float *pa = MA == 1 ? sA + (wr * 32 + l16) * kDLd + lq : sA + lq * kDLdT + wr * 32 + l16;
-    const float *pb = MB == 1 ? sB + (wc * 32 + l16) * kDLd + lq : sB + lq * kDLdT + wc * 32 + l16;
+    const float *pa = MA == 1 ? sA + (wr * HM + l16) * kDLd + lq : sA + lq * (BM + 16) + wr * HM + l16;
+    const float *pb = MB == 1 ? sB + (wc * 32 + l16) * kDLd + lq : sB + lq * (BN + 16) + wc * 32 + l16;
     for (int k0 = k_lo; k0 < k_end; k0 += kDK) {
         const bool more = k0 + kDK < k_end;
         if (more) {  // the next chunk's global loads fly under this chunk's 128 MFMAs per wave
-            deep_load<MA>(ta, g.A, m0, k0 + kDK, g.a_rs, g.a_cs);
-            deep_load<MB>(tb, g.B, n0, k0 + kDK, g.b_rs, g.b_cs);
+            deep_load<MA, BM>(ta, g.A, m0, k0 + kDK, g.a_rs, g.a_cs);
+            deep_load<MB, BN>(tb, g.B, n0, k0 + kDK, g.b_rs, g.b_cs);
         }
         // operands of k-step s+1 are read from LDS before the MFMAs of step s issue: with one wave per SIMD nobody else
         // hides the ds_read latency
-        float av[2][2], bv[2][2];
+        float av[2][TI], bv[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            av[0][i] = deep_operand<MA>(pa, i, 0);
-            bv[0][i] = deep_operand<MB>(pb, i, 0);
-        }
+        for (int i = 0; i < TI; ++i) av[0][i] = deep_operand<MA, BM>(pa, i, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[0][j] = deep_operand<MB, BN>(pb, j, 0);
 #pragma unroll
         for (int st = 0; st < kDK / 4; ++st) {
             const int cur = st & 1, nxt = cur ^ 1;
             if (st + 1 < kDK / 4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    av[nxt][i] = deep_operand<MA>(pa, i, st + 1);
-                    bv[nxt][i] = deep_operand<MB>(pb, i, st + 1);
-                }
+                for (int i = 0; i < TI; ++i) av[nxt][i] = deep_operand<MA, BM>(pa, i, st + 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[nxt][j] = deep_operand<MB, BN>(pb, j, st + 1);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();  // everyone is done reading the buffer
         if (more) {
-            deep_store<MA>(ta, sA);
-            deep_store<MB>(tb, sB);
+            deep_store<MA, BM>(ta, sA);
+            deep_store<MB, BN>(tb, sB);
         }
         __syncthreads();
     }
     // accumulator register r of a 16x16 block = row 4*(lane>>4) + r, column lane&15
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + i * 16 + 4 * lq + r, n = n0 + wc * 32 + j * 16 + l16;
+                const int m = m0 + wr * HM + i * 16 + 4 * lq + r, n = n0 + wc * 32 + j * 16 + l16;
                 if (m < g.M && n < g.N) {
                     float s = acc[i][j][r];
                     if (splits > 1) {
@@ -604,22 +605,27 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
                           per * kGK >= 512;
         if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
         else if (deep) {
-            const int lds = (deep_floats<1>() > deep_floats<2>() ? 2 * deep_floats<1>() : 2 * deep_floats<2>()) * (int)sizeof(float);
+            static const int no_half = getenv("RK_GEMM_NO_HALF") ? atoi(getenv("RK_GEMM_NO_HALF")) : 0;   // A/B only
+            const bool half = nwg * splits < 256 && !no_half;   // fewer workgroups than CUs: 32-row tiles
+            const void *fn[8] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 64>),
+                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 64>),
+                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 32>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 32>),
+                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1, 32>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 32>)};
             static bool deep_attr = false;
             if (!deep_attr) {
-                const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2>),
-                                     reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2>)};
                 for (const void *f : fn) {
-                    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * deep_floats<2, 64>() * (int)sizeof(float));
                     if (e != hipSuccess) return e;
                 }
                 deep_attr = true;
             }
-            const size_t la = (fa == 1 ? deep_floats<1>() : deep_floats<2>()) * sizeof(float), lb = (fb == 1 ? deep_floats<1>() : deep_floats<2>()) * sizeof(float);
-            if (fa == 1 && fb == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<1, 1>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
-            else if (fa == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<1, 2>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
-            else if (fb == 1) hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<2, 1>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
-            else hipLaunchKernelGGL((gemm_f32_skinny_deep_kernel<2, 2>), dim3(nwg, splits), dim3(256), la + lb, s, g2);
+            const int fl_a = half ? (fa == 1 ? deep_floats<1, 32>() : deep_floats<2, 32>()) : (fa == 1 ? deep_floats<1, 64>() : deep_floats<2, 64>());
+            const int fl_b = fb == 1 ? deep_floats<1, 64>() : deep_floats<2, 64>();
+            const size_t lds = (size_t)(fl_a + fl_b) * sizeof(float);
+            const dim3 grid(half ? 2 * nwg : nwg, splits);
+            const int which = (half ? 4 : 0) + (fa == 2 ? 2 : 0) + (fb == 2 ? 1 : 0);
+            void *params[1] = {const_cast<GemmArgs *>(&g2)};
+            return hipLaunchKernel(fn[which], grid, dim3(256), params, lds, s);
         } else hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(nwg, splits), dim3(256), 0, s, g2);
         return hipGetLastError();
     }

@@ -1,4 +1,4 @@
-// Timing probe for gemm.h (not part of the library): gemm_probe M N K [pad_a] [pad_b] [split] [forms: 0 = A[M,K] B[N,K]; 1 = dX form; 2 = dW form]
+// Timing probe for gemm.h (not part of the library): gemm_probe M N K [pad_a] [pad_b] [split] [forms: 0 = A[M,K] B[N,K]; 1 = dX form; 2 = dW form] [gather: 1 = rows of A through an index list]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +19,12 @@ int main(int argc, char **argv)
     g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.C = C; g.ldc = N;
     if (form == 2) { g.a_rs = 1; g.a_cs = M + pa; } else { g.a_rs = K + pa; g.a_cs = 1; }
     if (form == 0) { g.b_rs = K + pb; g.b_cs = 1; } else { g.b_rs = 1; g.b_cs = N + pb; }
+    if (argc > 8 && atoi(argv[8])) {
+        std::vector<int> idx(M);
+        for (int i = 0; i < M; ++i) idx[i] = (int)((i * 7919LL) % M);
+        int *d; hipMalloc(&d, M * 4); hipMemcpy(d, idx.data(), M * 4, hipMemcpyHostToDevice);
+        g.a_ridx = d;
+    }
     g.split_k = split; if (split > 1) { g.sk_part = P; g.sk_stride = (long long)M * N; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) gemm_f32_launch(g, 0);
