@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int
                                                           const float *__restrict__ ig, const float *__restrict__ xl,
                                                           const float *__restrict__ pw, const float *__restrict__ pb,
                                                           float *__restrict__ logits, const int64_t *labels, float *d0,
-                                                          float *loss_partials)
+                                                          float *loss_partials, float *__restrict__ dxl, float *g_ug, float *g_ig)
 {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -157,12 +157,28 @@ __global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int
         else if (mode == RK_NCF_MLP) { for (int k = lane; k < f; k += 64) s += pw[k] * px[k]; }
         else { for (int k = lane; k < f; k += 64) s += pw[k] * (pu[k] * pi[k]); }
         s = wave_sum(s) + pb[0];
+        float dd = 0.f;
         if (lane == 0) {
             if (logits) logits[p.off + b] = s;
             if (labels) {
                 const float y = (float)labels[p.off + b];
                 lsum += fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));
-                d0[b] = (1.f / (1.f + expf(-s)) - y) * invB;
+                dd = (1.f / (1.f + expf(-s)) - y) * invB;
+                d0[b] = dd;
+            }
+        }
+        if (dxl) {
+            // training: the predict layer's backward for this pair straight away -- dXL[b,k] = d0[b]*pw[off+k], masked by the top
+            // tower layer's own ReLU (xL > 0); GMF table gradients by atomics.  (Was two more launches of ~5 us each.)
+            dd = __shfl(dd, 0);
+            float *pd = dxl + (size_t)b * f;
+            const int off = mode == RK_NCF_NEUMF ? f : 0;
+            for (int k = lane; k < f; k += 64) {
+                if (mode != RK_NCF_GMF) pd[k] = px[k] > 0.f ? dd * pw[off + k] : 0.f;
+                if (mode != RK_NCF_MLP) {
+                    unsafeAtomicAdd(g_ug + (size_t)u * f + k, dd * pw[k] * pi[k]);
+                    unsafeAtomicAdd(g_ig + (size_t)i * f + k, dd * pw[k] * pu[k]);
+                }
             }
         }
     }
@@ -170,26 +186,6 @@ __global__ __launch_bounds__(256) void ncf_predict_kernel(PairSrc p, int nb, int
         if (lane == 0) red[w] = lsum;
         __syncthreads();
         if (threadIdx.x == 0) loss_partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * invB;
-    }
-}
-
-// backward of the predict layer: dXL[b,k] = d0[b]*pw[f+k]; GMF table grads by atomics
-__global__ void ncf_predict_bwd_kernel(PairSrc p, int nb, int f, int mode, const float *__restrict__ ug, const float *__restrict__ ig,
-                                       const float *__restrict__ pw, const float *__restrict__ d0, float *__restrict__ dxl,
-                                       float *g_ug, float *g_ig)
-{
-    const int lane = threadIdx.x & 63;
-    for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += (long long)gridDim.x * (blockDim.x >> 6)) {
-        long long u, i;
-        pair_at(p, b, u, i);
-        const float dd = d0[b];
-        for (int k = lane; k < f; k += 64) {
-            if (mode != RK_NCF_GMF) dxl[(size_t)b * f + k] = dd * pw[(mode == RK_NCF_NEUMF ? f : 0) + k];
-            if (mode != RK_NCF_MLP) {
-                unsafeAtomicAdd(g_ug + (size_t)u * f + k, dd * pw[k] * ig[(size_t)i * f + k]);
-                unsafeAtomicAdd(g_ig + (size_t)i * f + k, dd * pw[k] * ug[(size_t)u * f + k]);
-            }
-        }
     }
 }
 
@@ -286,12 +282,6 @@ __global__ void ncf_scatter_kernel(PairSrc p, int nb, int E, const float *__rest
             unsafeAtomicAdd(g_im + (size_t)i * E + k, s[E + k]);
         }
     }
-}
-
-__global__ void relu_mask_kernel(long long n, float *dy, const float *y)
-{
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        if (!(y[i] > 0.f)) dy[i] = 0.f;
 }
 
 // dense Adam over every tensor in one launch; gradients are re-zeroed after use
@@ -422,7 +412,7 @@ RK_EXPORT int rk_ncf_forward(const rk_ncf_desc *desc, const int64_t *users, cons
         if (rc) return rc;
         hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, s, p, nb, d.factor, d.mode, d.ug, d.ig,
                            d.acts + act_off(d, d.n_layers, d.max_batch), d.pw, d.pb, out, (const int64_t *)nullptr,
-                           (float *)nullptr, (float *)nullptr);
+                           (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
         RK_CHECK_LAUNCH();
     }
     return RK_OK;
@@ -471,9 +461,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         if (rc) return rc;
         float *xl = d.acts + act_off(d, L, d.max_batch), *dxl = d.dacts + act_off(d, L, d.max_batch);
         hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(RK_LOSS_PARTIALS, (nb + 3) / 4)), dim3(256), 0, s, p, nb, f, d.mode, d.ug, d.ig,
-                           xl, d.pw, d.pb, (float *)nullptr, labels, d.d0, loss_partials + (size_t)step * RK_LOSS_PARTIALS);
-        RK_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ncf_predict_bwd_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, f, d.mode, d.ug, d.ig, d.pw, d.d0, dxl, d.grad[0], d.grad[1]);
+                           xl, d.pw, d.pb, (float *)nullptr, labels, d.d0, loss_partials + (size_t)step * RK_LOSS_PARTIALS, dxl, d.grad[0], d.grad[1]);
         RK_CHECK_LAUNCH();
         {
             const int n_slabs = (nb + kWgradSlab - 1) / kWgradSlab;
@@ -484,17 +472,12 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
                                d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
             RK_CHECK_LAUNCH();
         }
-        // tower backward.  dY of the top layer is masked by its own ReLU here; for the layers below
+        // tower backward.  dY of the top layer was masked by its own ReLU in the predict kernel; for the layers below
         // the mask (x > 0, x = the previous layer's ReLU output) is applied in the dX GEMM's epilogue.
         for (int l = (d.mode == RK_NCF_GMF ? -1 : L - 1); l >= 0; --l) {
             const int in = in_of(d, l), out = in / 2;
-            float *x = d.acts + act_off(d, l, d.max_batch), *y = d.acts + act_off(d, l + 1, d.max_batch);
+            float *x = d.acts + act_off(d, l, d.max_batch);
             float *dy = d.dacts + act_off(d, l + 1, d.max_batch), *dx = d.dacts + act_off(d, l, d.max_batch);
-            if (l == L - 1) {
-                hipLaunchKernelGGL(relu_mask_kernel, dim3(std::min(1024, (nb * out + 255) / 256)), dim3(256), 0, s,
-                                   (long long)nb * out, dy, y);
-                RK_CHECK_LAUNCH();
-            }
             // dW[out,in] += dY^T X : A(m=o,k=b) = dy[b*out+o], B(n=i,k=b) = x[b*in+i].  K = batch is long and
             // the tile count small: split K over workgroups that add into the (zeroed) gradient.
             const int tiles = ((out + 63) / 64) * ((in + 63) / 64);
