@@ -11,6 +11,7 @@
 //   bit-identical to  s = fmaf(a[k], b[k], s), k = 0..K-1  (the oracle's orc_score_rows).
 #pragma once
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -464,7 +465,7 @@ __device__ __forceinline__ void deep_load(DeepRegs &t, const float *__restrict__
     }
 }
 // LDS image of a chunk.  Form 1 (k contiguous): [row][k], rows padded to 132 floats -- an operand read of a k-step touches
-// banks 4*row + k, every bank twice (the minimum for 64 lanes).  Form 2 (rows contiguous): kept as it arrives, [k][row] with
+// banks 4*row + k = 0..63, each once (measured: rotating k so that a half-wave covers 32 distinct banks instead is 5 % SLOWER).  Form 2 (rows contiguous): kept as it arrives, [k][row] with
 // rows of ROWS+16 floats -- the b128 stores are conflict-free (the transposing scalar stores of the 32-deep kernel are 8-way
 // conflicted) and an operand read touches banks 16*k + row, again every bank twice.
 template <int MODE, int ROWS> constexpr int deep_floats() { return MODE == 1 ? ROWS * kDLd : kDK * (ROWS + 16); }
@@ -581,6 +582,179 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2
             }
 }
 
+// ---- 128x128 tiles with 64-deep chunks ("wide"): the deep form's recipe for problems with MANY tiles (the scoring GEMM).
+// Against gemm_f32_kernel: half the barrier pairs per k, b128 LDS stores (rows of 68 floats stay 16-byte aligned; the 33-float
+// rows of the 32x32x2 layout force scalar stores), operands of k-step s+1 read before step s issues, and 2 workgroups of
+// 256 VGPRs per CU instead of 3 squeezed under 168 (scratch spills).  Each wave owns 64x64 as 4x4 accumulators of
+// v_mfma_f32_16x16x4_f32; same k-ordered chain per element.  A partial last tile is taken for k-contiguous operands (row
+// loads clamped to the last row, stores guarded); for row-contiguous ones the launcher hands the edge strip to gemm_f32_kernel.
+static constexpr int kWK = 64, kWLd = kWK + 4, kWLdT = 128 + 16;
+template <int MODE> constexpr int wide_floats() { return MODE == 1 ? 128 * kWLd : kWK * kWLdT; }
+template <int MODE>
+__device__ __forceinline__ void wide_load(DeepRegs &t, const float *__restrict__ src, const long long (&rowoff)[8], int r0, int k0, long long cs)
+{
+    const int tid = threadIdx.x;
+    if (MODE == 1) {   // 16 float4 per row of 64 k: thread -> (row = p*16 + tid/16, k4 = tid%16); rowoff[p] = row(p) * rs
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(src + rowoff[p] + (k0 + (tid & 15) * 4));
+    } else {           // 32 float4 per k column of 128 rows: thread -> (k = p*8 + tid/32, row4 = tid%32)
+        const float *q = src + (long long)(k0 + (tid >> 5)) * cs + (r0 + (tid & 31) * 4);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t.v[p] = *reinterpret_cast<const f32x4 *>(q + (long long)p * 8 * cs);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void wide_store(const DeepRegs &t, float *dst)
+{
+    const int tid = threadIdx.x;
+    if (MODE == 1) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 16 + (tid >> 4)) * kWLd + (tid & 15) * 4) = t.v[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4 *>(dst + (p * 8 + (tid >> 5)) * kWLdT + (tid & 31) * 4) = t.v[p];
+    }
+}
+template <int MODE>
+__device__ __forceinline__ float wide_operand(const float *base, int i, int st)
+{
+    return MODE == 1 ? base[i * 16 * kWLd + st * 4] : base[st * 4 * kWLdT + i * 16];
+}
+
+template <int MA, int MB>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_f32_wide_kernel(const GemmArgs g, const int gx, const int gy)
+{
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *sA = dsm, *sB = dsm + wide_floats<MA>();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int wr = w >> 1, wc = w & 1;
+    // Persistent workgroups, each a contiguous run of the tile order; workgroups are dealt round-robin over the 8 XCDs, so
+    // give every XCD a contiguous range of runs (bijective remap).
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    {
+        const int q = nb / 8, r = nb % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int n_tiles = gx * gy;
+    const int t_begin = (int)((long long)bid * n_tiles / nb), t_end = (int)((long long)(bid + 1) * n_tiles / nb);
+    if (t_begin >= t_end) return;
+    const int n_chunks = g.K / kWK, total = (t_end - t_begin) * n_chunks;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l16 = lane & 15, lq = lane >> 4;
+    long long ra[8], rb[8];
+    int m0, n0, m1, n1;   // origin of the tile being accumulated / of the tile whose chunk is being prefetched
+    auto row_offsets = [&](int mt, int nt) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            // rows past the edge of a partial tile (k-contiguous operands only) re-read the last row; their results are not stored
+            const int m = min(mt + p * 16 + (tid >> 4), g.M - 1);
+            ra[p] = (long long)(g.a_ridx ? g.a_ridx[m] : m) * g.a_rs;
+            rb[p] = (long long)min(nt + p * 16 + (tid >> 4), g.N - 1) * g.b_rs;
+        }
+    };
+    tile_origin<128>(t_begin, gx, gy, m0, n0);
+    m1 = m0; n1 = n0;
+    row_offsets(m0, n0);
+    DeepRegs ta, tb;
+    wide_load<MA>(ta, g.A, ra, m0, 0, g.a_cs);
+    wide_load<MB>(tb, g.B, rb, n0, 0, g.b_cs);
+    wide_store<MA>(ta, sA);
+    wide_store<MB>(tb, sB);
+    __syncthreads();
+    const float *pa = MA == 1 ? sA + (wr * 64 + l16) * kWLd + lq : sA + lq * kWLdT + wr * 64 + l16;
+    const float *pb = MB == 1 ? sB + (wc * 64 + l16) * kWLd + lq : sB + lq * kWLdT + wc * 64 + l16;
+    const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask;
+    // ONE software pipeline over all (tile, k-chunk) pairs of the run: the next pair's global loads fly under this chunk's
+    // MFMAs, and a finished tile's stores drain under the next tile's MFMAs.
+    int c = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total, last = c == n_chunks - 1;
+        if (more) {
+            if (last) {
+                tile_origin<128>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
+                row_offsets(m1, n1);
+            }
+            const int k1 = last ? 0 : (c + 1) * kWK;
+            wide_load<MA>(ta, g.A, ra, m1, k1, g.a_cs);
+            wide_load<MB>(tb, g.B, rb, n1, k1, g.b_cs);
+        }
+        float av[2][4], bv[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[0][i] = wide_operand<MA>(pa, i, 0);
+            bv[0][i] = wide_operand<MB>(pb, i, 0);
+        }
+#pragma unroll
+        for (int st = 0; st < kWK / 4; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < kWK / 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[nxt][i] = wide_operand<MA>(pa, i, st + 1);
+                    bv[nxt][i] = wide_operand<MB>(pb, i, st + 1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        }
+        if (last) {
+            // tile finished.  Accumulator register r of a 16x16 block = row 4*(lane>>4) + r, column lane&15.
+            auto emit = [&](auto guarded) {
+                constexpr bool G = decltype(guarded)::value;   // partial tile: per-element bounds tests
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wr * 64 + i * 16 + 4 * lq + r;
+                        if (G && m >= g.M) continue;
+                        float *crow = g.C + (size_t)m * g.ldc + (n0 + wc * 64 + l16);
+                        const int n_left = g.N - (n0 + wc * 64 + l16);   // columns j*16 < n_left are inside C
+                        if (plain) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (!G || j * 16 < n_left) crow[j * 16] = acc[i][j][r];
+                        } else {
+                            const float rbias = g.row_bias ? g.row_bias[g.a_ridx ? g.a_ridx[m] : m] : 0.f;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = n0 + wc * 64 + j * 16 + l16;
+                                if (G && n >= g.N) continue;
+                                float s = acc[i][j][r];
+                                if (g.row_bias) s = ((s + rbias) + g.col_bias[n]) + g.const_add;
+                                else if (g.col_bias) s += g.col_bias[n];
+                                if (g.relu) s = s > 0.f ? s : 0.f;
+                                if (g.sigmoid) s = 1.f / (1.f + expf(-s));
+                                if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
+                                crow[j * 16] = s;
+                            }
+                        }
+                    }
+            };
+            if (m0 + 128 <= g.M && n0 + 128 <= g.N) emit(std::false_type{});
+            else emit(std::true_type{});
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m0 = m1; n0 = n1;
+            c = 0;
+        } else ++c;
+        __syncthreads();
+        if (more) {
+            wide_store<MA>(ta, sA);
+            wide_store<MB>(tb, sB);
+        }
+        __syncthreads();
+    }
+}
+
 // asynchronous launch; returns the hipError_t of the launch
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
@@ -630,6 +804,52 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         return hipGetLastError();
     }
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
+    {
+        // whole 128x128 tiles of aligned operands, K a multiple of 64: the wide kernel on the interior, this function again
+        // on the edge strips (they have fewer than 128 rows or columns, so they never come back here)
+        static const int no_wide = getenv("RK_GEMM_NO_WIDE") ? atoi(getenv("RK_GEMM_NO_WIDE")) : 0;   // A/B only
+        const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
+        // k-contiguous operands take a partial last tile (clamped row loads); row-contiguous ones need whole tiles
+        static const int strips = getenv("RK_GEMM_WIDE_STRIPS") ? atoi(getenv("RK_GEMM_WIDE_STRIPS")) : 0;   // A/B only
+        const int Mi = fa == 1 && !strips ? g.M : g.M / 128 * 128, Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
+        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= 2 * kWK && !g.a_rmod && !g.acc_init &&
+            !g.drop_thresh24) {
+            const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
+                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 2>)};
+            static bool wide_attr = false;
+            if (!wide_attr) {
+                for (const void *f : fn) {
+                    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wide_floats<2>() * (int)sizeof(float));
+                    if (e != hipSuccess) return e;
+                }
+                wide_attr = true;
+            }
+            int gx = (Ni + 127) / 128, gy = (Mi + 127) / 128;
+            const size_t lds = (size_t)((fa == 1 ? wide_floats<1>() : wide_floats<2>()) + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);
+            void *params[3] = {const_cast<GemmArgs *>(&g), &gx, &gy};
+            static const int wide_wgs = getenv("RK_GEMM_WIDE_WGS") ? atoi(getenv("RK_GEMM_WIDE_WGS")) : 512;   // tuning only: 2 per CU
+            hipError_t e = hipLaunchKernel(fn[(fa == 2 ? 2 : 0) + (fb == 2 ? 1 : 0)], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
+            if (e != hipSuccess) return e;
+            if (Ni < g.N) {   // right strip: all rows, columns [Ni, N)
+                GemmArgs e1 = g;
+                e1.N = g.N - Ni; e1.B = g.B + (long long)Ni * g.b_rs; e1.C = g.C + Ni;
+                if (g.col_bias) e1.col_bias = g.col_bias + Ni;
+                if (g.mask) e1.mask = g.mask + Ni;
+                e = gemm_f32_launch(e1, s);
+                if (e != hipSuccess) return e;
+            }
+            if (Mi < g.M) {   // bottom strip: rows [Mi, M), columns [0, Ni)
+                GemmArgs e2 = g;
+                e2.M = g.M - Mi; e2.N = Ni; e2.C = g.C + (size_t)Mi * g.ldc;
+                if (g.a_ridx) e2.a_ridx = g.a_ridx + Mi;
+                else { e2.A = g.A + (long long)Mi * g.a_rs; if (g.row_bias) e2.row_bias = g.row_bias + Mi; }
+                if (g.mask) e2.mask = g.mask + (size_t)Mi * g.ldmask;
+                e = gemm_f32_launch(e2, s);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+    }
     // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
     int tpb = (g.K <= 64) ? nwg128 / 1024 : 1;
     static const int tpb_env = getenv("RK_GEMM_TPB") ? atoi(getenv("RK_GEMM_TPB")) : 0;   // tuning only

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "../recad_amd/csrc/gemm.h"
 int main(int argc, char **argv)
 {
