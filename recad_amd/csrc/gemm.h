@@ -810,9 +810,10 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         static const int no_wide = getenv("RK_GEMM_NO_WIDE") ? atoi(getenv("RK_GEMM_NO_WIDE")) : 0;   // A/B only
         const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
         // k-contiguous operands take a partial last tile (clamped row loads); row-contiguous ones need whole tiles
+        static const int wide_min_k = getenv("RK_GEMM_WIDE_MINK") ? atoi(getenv("RK_GEMM_WIDE_MINK")) : kWK;   // tuning only
         static const int strips = getenv("RK_GEMM_WIDE_STRIPS") ? atoi(getenv("RK_GEMM_WIDE_STRIPS")) : 0;   // A/B only
         const int Mi = fa == 1 && !strips ? g.M : g.M / 128 * 128, Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
-        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= 2 * kWK && !g.a_rmod && !g.acc_init &&
+        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k && !g.a_rmod && !g.acc_init &&
             !g.drop_thresh24) {
             const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
                                  reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 2>)};
