@@ -342,6 +342,7 @@ inline int gemm_effective_splits(int K, int splits)
 // parked slices) as gemm_f32_kernel.  LDS rows are padded to 36 floats: the operand read of a k-step touches
 // 16 rows x 4 k's = banks 4*row + k, each exactly twice (the minimum for 64 lanes), and rows stay 16-byte aligned.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (rows of C with ldc % 4 != 0)
 static constexpr int kSLd = kGK + 4;
 static __global__ __launch_bounds__(256, 4) void gemm_f32_skinny_kernel(const GemmArgs g)
 {
@@ -702,40 +703,45 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][j], av[cur][i], acc[i][j], 0, 0, 0);   // the block TRANSPOSED
         }
         if (last) {
-            // tile finished.  Accumulator register r of a 16x16 block = row 4*(lane>>4) + r, column lane&15.
+            // tile finished.  The MFMAs took (B, A), so a 16x16 accumulator block holds C^T: register r of lane (l16, lq) is
+            // C[row l16][column 4*lq + r] -- four consecutive columns per lane, one 16-byte store (a quarter of the store
+            // instructions of the row-per-register layout; same products, same order, same bits).
             auto emit = [&](auto guarded) {
                 constexpr bool G = decltype(guarded)::value;   // partial tile: per-element bounds tests
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wr * 64 + i * 16 + l16;
+                    if (G && m >= g.M) continue;
+                    float *crow = g.C + (size_t)m * g.ldc;
+                    const float rbias = (!plain && g.row_bias) ? g.row_bias[g.a_ridx ? g.a_ridx[m] : m] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wr * 64 + i * 16 + 4 * lq + r;
-                        if (G && m >= g.M) continue;
-                        float *crow = g.C + (size_t)m * g.ldc + (n0 + wc * 64 + l16);
-                        const int n_left = g.N - (n0 + wc * 64 + l16);   // columns j*16 < n_left are inside C
-                        if (plain) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wc * 64 + j * 16 + 4 * lq;
+                        f32x4 v = acc[i][j];
+                        if (!plain) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (!G || j * 16 < n_left) crow[j * 16] = acc[i][j][r];
-                        } else {
-                            const float rbias = g.row_bias ? g.row_bias[g.a_ridx ? g.a_ridx[m] : m] : 0.f;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int n = n0 + wc * 64 + j * 16 + l16;
-                                if (G && n >= g.N) continue;
-                                float s = acc[i][j][r];
-                                if (g.row_bias) s = ((s + rbias) + g.col_bias[n]) + g.const_add;
-                                else if (g.col_bias) s += g.col_bias[n];
+                            for (int r = 0; r < 4; ++r) {
+                                if (G && n + r >= g.N) continue;
+                                float s = v[r];
+                                if (g.row_bias) s = ((s + rbias) + g.col_bias[n + r]) + g.const_add;
+                                else if (g.col_bias) s += g.col_bias[n + r];
                                 if (g.relu) s = s > 0.f ? s : 0.f;
                                 if (g.sigmoid) s = 1.f / (1.f + expf(-s));
-                                if (g.mask) s = g.mask[(size_t)m * g.ldmask + n] > 0.f ? s : 0.f;
-                                crow[j * 16] = s;
+                                if (g.mask) s = g.mask[(size_t)m * g.ldmask + n + r] > 0.f ? s : 0.f;
+                                v[r] = s;
                             }
                         }
+                        if (!G || n + 4 <= g.N) *reinterpret_cast<f32x4_u *>(crow + n) = v;
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < g.N) crow[n + r] = v[r];
+                        }
                     }
+                }
             };
             if (m0 + 128 <= g.M && n0 + 128 <= g.N) emit(std::false_type{});
             else emit(std::true_type{});
