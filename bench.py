@@ -458,7 +458,9 @@ def worker(args):
         cpu_aten = cpu_baseline_aten(d, args.graph, args.dim, args.layers, B, host_triplets)
 
     if rank == 0:
-        if world == 1:
+        if sharded is not None:
+            par = sharded.describe()
+        elif world == 1:
             par = "single GPU"
         elif sharded is None:
             par = "1 independent victim replica per GPU (no data-path collective)"
@@ -473,7 +475,8 @@ def worker(args):
             "config": {"workload": f"LightGCN victim, {args.workload}-shaped synthetic {ds.n_users}x{ds.n_items}, "
                                    f"{ds.traindataSize} train edges, graph={args.graph} (nnz {nnz}), dim={args.dim}, "
                                    f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
-                       "parallelism": par, "mode": "single" if world == 1 else args.parallel, "backend": args.backend if world > 1 else None,
+                       "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
+                       "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
             "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
