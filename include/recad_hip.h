@@ -202,7 +202,7 @@ int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v,
  * are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K] sorted by (score desc, item id
  * asc), padded with -1/-inf; for each target t its score and rank among the unseen items (hit@k <=> rank < k).
  * Two paths, identical results: GEMM into a [nb, n_items] matrix in `scratch` + a selection pass (the default while
- * such a matrix is sensible: n_items < 2^17), or ONE fused sweep over the catalogue that never materialises the
+ * such a matrix is sensible: n_items < 2^18), or ONE fused sweep over the catalogue that never materialises the
  * scores (recad_amd/csrc/score_select.h; K <= 256, n_targets <= 4, dim <= 128; 1025 floats of scratch per user;
  * the default for larger catalogues).  scratch: device float[rk_score_topk_scratch_floats(...)], 8-byte aligned. */
 int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets);

@@ -365,7 +365,7 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
 //   fused sweep (score_select.h): no score matrix, 1025 floats of candidate slots per user; needs K <= 256, at most 4
 //     targets, dim <= 128.  Measured on MI355X it is the SLOWER of the two wherever the score matrix fits comfortably
 //     (5893 x 3702 x 64: 198 vs 98 us; 54617 x 34474 x 128: 10.5 vs 7.7 ms -- DESIGN.md 4.3), so it is chosen by
-//     default only for catalogues of >= 2^17 items, where a block of users no longer fits a sensible score matrix;
+//     default only for catalogues of >= 2^18 items, where a block of users no longer fits a sensible score matrix;
 //   GEMM + selection over a materialised [nb, n_items] matrix otherwise.
 // RK_SEL_FORCE=1 forces the fused sweep wherever it is supported, RK_SEL_OFF=1 forbids it (tests run both; read per call).
 static bool use_fused(int n_items, int dim, int K, int n_targets)
@@ -373,7 +373,7 @@ static bool use_fused(int n_items, int dim, int K, int n_targets)
     const char *off = getenv("RK_SEL_OFF"), *force = getenv("RK_SEL_FORCE");
     if (off && atoi(off)) return false;
     if (!sel_supported(n_items, dim, K, n_targets)) return false;
-    return (force && atoi(force)) || n_items >= (1 << 17);
+    return (force && atoi(force)) || n_items >= (1 << 18);
 }
 
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)

@@ -864,6 +864,41 @@ def test_ncf_vs_oracle_shapes(gpu_device, f, L):
     assert np.allclose(losses, ref_losses, rtol=2e-3) and losses[-1] < losses[0]
 
 
+def test_ncf_large_batch_wide_gemm_forms(gpu_device):
+    """Batch 16 384 at f=192 / L=2 (layer 0: 768 -> 384): forward layer 0 (k-contiguous x k-contiguous, bias + ReLU epilogue),
+    dX of layer 0 and dX of layer 1 (k-contiguous x row-contiguous; ReLU-mask epilogue on layer 1) have >= 384 tiles of 128
+    and run gemm_f32_wide_kernel instead of the 64-tile kernels of the batch-1024 tests; dW stays on the deep 64-tile form
+    with K = 16 384.  Loss, logits and every gradient against the oracle on identical parameters."""
+    from recad_amd import dataset, model, synth
+    dd = synth.make("tiny")
+    ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"], need_graph=False,
+                             device=gpu_device, sample="pointwise", seed=5, pointwise_batch_size=16384)
+    torch.manual_seed(77)
+    f, L, nb = 192, 2, 16384
+    m = model.from_config("victim", "ncf", factor_num=f, num_layers=L).I(dataset=ds).to(gpu_device)
+    g = torch.Generator().manual_seed(3)
+    # Biases of +-(0.1 .. 0.5) against pre-activation dot products of ~1e-3: no unit sits on the ReLU edge.  (With the zero
+    # biases of the reference's init, 1 of these 6.3 M layer-0 pre-activations is zero to within an ulp and the oracle's
+    # mul + add and the MFMA's fused chain gate it differently -- one row of dW0 / db0 / two embedding rows off by 7e-3,
+    # with either GEMM kernel; tests/tools/dbg_ncf_large.py.)
+    with torch.no_grad():
+        for t in m._tensors()[4 + L:4 + 2 * L]:
+            t.copy_(((torch.rand(t.shape, generator=g) * 0.4 + 0.1) * (torch.randint(0, 2, t.shape, generator=g) * 2 - 1).float()).to(gpu_device))
+    ts = [t.detach().cpu().numpy().copy() for t in m._tensors()]
+    P = orc.NCFParams(f, L, ts[0], ts[1], ts[2], ts[3], ts[4:4 + L], ts[4 + L:4 + 2 * L], ts[-2], ts[-1])
+    users = torch.randint(0, ds.n_users, (nb,), generator=g).to(gpu_device)
+    items = torch.randint(0, ds.n_items, (nb,), generator=g).to(gpu_device)
+    labels = torch.randint(0, 2, (nb,), generator=g).to(gpu_device)
+    un, it, lb = users.cpu().numpy(), items.cpu().numpy(), labels.cpu().numpy()
+    pred = m(users[:4096], items[:4096]).cpu().numpy()
+    assert np.allclose(pred, orc.ncf_forward(P, un[:4096], it[:4096]), rtol=1e-5, atol=1e-7)
+    part = m._run_epoch(users, items, labels, nb, apply_update=False)
+    loss0, grads = orc.ncf_step(P, un, it, lb, apply_update=False)
+    assert abs(float(part.sum()) - loss0) <= 2e-5 * abs(loss0)
+    for got, ref in zip(m._ws["grad"], grads):
+        assert G.relerr(got.cpu().numpy(), ref.reshape(got.shape)) < 5e-5
+
+
 def _topk_rows_vs_oracle(dev, scores, seen, K, targets):
     """rk_topk_rows through the C-ABI against orc.topk_row, row by row, bit-exact."""
     from recad_amd import _lib
