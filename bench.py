@@ -481,6 +481,8 @@ def worker(args):
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
             "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
+        if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
+            same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_collectives:
         dist.barrier()
