@@ -54,6 +54,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true", help="skip the evaluation leg")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="ordered (bit-reproducible) gradient scatter instead of float atomics (single-GPU fused path; labelled in config)")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
     ap.add_argument("--parallel", default=None, choices=["rows", "replicas"],
                     help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default) or one "
@@ -282,7 +284,8 @@ def worker(args):
                              need_graph=True, device=dev, graph_source=args.graph, pairwise_batch_size=B,
                              seed=1234 + (0 if rows_mode else rank))
     torch.manual_seed(2023)
-    victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers).I(dataset=ds).to(dev)
+    victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers,
+                               deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
     victim.graph_steps = args.graph_steps
     g = ds.graph_csr()
     N, nnz = g.n_rows, g.nnz
@@ -477,7 +480,7 @@ def worker(args):
                                    f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
                        "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
-                       "graph_steps": args.graph_steps},
+                       "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
             "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }

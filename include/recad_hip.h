@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 4
+#define RK_ABI_VERSION 5
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -182,6 +182,15 @@ int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t
  * reference has no counterpart (its step is eager ATen, lightgcn.py:137-169). */
 int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
                         float *loss_partials, int32_t apply_update, int32_t graph_steps, void *stream);
+
+/* Ordered (reproducible) gradient scatter for rk_lightgcn_train_epoch.  The reference scatters the minibatch's embedding
+ * gradients through autograd's index_select backward (lightgcn.py:124-129,166): a sequential sum on CPU, float atomics on a
+ * GPU.  Default here: float atomics too (sum order not fixed; the loss is reproducible, gradients to ~1e-7).  on != 0:
+ * train_epoch first sorts the epoch's 3n (node row, triplet, role) incidences once (handle-owned buffers, 48 bytes per
+ * triplet) and every step adds each row's contributions in (triplet index, role) order with plain stores, one wave per
+ * touched row instead of one per triplet -- bit-identical gradients and parameters from run to run.  Limits: < 2^20 steps per epoch, < 2^24 node
+ * rows, batch < 349 525.  Not used by rk_bpr_rows (the row-sharded trainer). */
+int rk_lightgcn_set_deterministic(rk_lightgcn_t h, int32_t on);
 
 /* ---------------------------------------------------------------- shared ops ------- */
 /* out[b] = <utab[users[b]], itab[items[b]]> (+ ubias[users[b]] + ibias[items[b]] + mean when

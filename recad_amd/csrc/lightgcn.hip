@@ -2,6 +2,8 @@
 // (lightgcn.py:137-169) as 2L+1 launches per step, optionally replayed from a hipGraph.
 #include <algorithm>
 
+#include <hipcub/hipcub.hpp>
+
 #include "spmm.h"
 
 thread_local char rk_err_buf[512] = "";
@@ -12,6 +14,16 @@ struct rk_lightgcn {
     hipGraphExec_t exec = nullptr;
     int exec_steps = 0, exec_update = -1;
     const void *cap_key[4] = {nullptr, nullptr, nullptr, nullptr};  // pointers baked into exec
+    // ordered scatter (rk_lightgcn_set_deterministic): the epoch's 3n (row, triplet, role) incidences sorted by
+    // (step, row, 3b + role).  Owned by the handle.
+    int deterministic = 0;
+    unsigned long long *plan_keys[2] = {nullptr, nullptr};
+    size_t plan_cap = 0;
+    void *plan_tmp = nullptr;
+    size_t plan_tmp_bytes = 0;
+    const unsigned long long *plan_sorted = nullptr;   // baked into exec
+    const void *cap_plan = nullptr;
+    int cap_det = 0, cap_batch = 0;
 };
 
 __global__ void state_init_kernel(int *state, int step_base, int adam_t, long long n, int batch)
@@ -37,7 +49,13 @@ struct BprArgs {
     float lr, b1, b2;
     int nb_direct;  // state == nullptr: one batch of nb_direct triplets starting at users[0]
     int light_compact;  // light is a compact [3*nb, d] block: rows b, nb+b, 2nb+b of triplet b (row-sharded trainer)
+    // ordered mode (bpr_rows_kernel): the epoch plan, every row's incidences in the order they are added
+    const unsigned long long *keys;
 };
+
+// incidence key of the epoch plan: step (20 bits) | node row (24 bits) | 3*b + role (20 bits)
+static constexpr int kPlanIncBits = 20, kPlanRowBits = 24, kPlanStepBits = 20;
+__device__ __forceinline__ unsigned plan_row(unsigned long long key) { return (unsigned)(key >> kPlanIncBits) & ((1u << kPlanRowBits) - 1u); }
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
@@ -105,6 +123,126 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
         const float s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         const float r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         a.loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
+    }
+}
+
+// Ordered form of bpr_kernel (rk_lightgcn_set_deterministic): one wave per node row that occurs in the minibatch.  The row's
+// incidences are taken in the order of the plan -- triplet index, then role (user, positive, negative): the order a
+// sequential loop over the batch produces (oracle: orc_lightgcn_step_general) -- each one recomputes its triplet's two dot
+// products (three row reads from L2; cheaper than a second launch that would hand the coefficients over), and the row is
+// written with plain stores (gprop / gego are zero outside the minibatch's rows).  No atomics: gradients, and with them
+// the trained tables, are reproducible bit for bit.  The loss terms are added by the user-role incidences.
+static constexpr int kRowsWaves = 16;   // 256 workgroups (one loss partial each) x 16 waves: a wave per incidence of a 1024-triplet batch
+__global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs a)
+{
+    __shared__ float red[2][kRowsWaves];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int step = a.state[ST_STEP_BASE] + a.k;
+    const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
+    const int B = a.state[ST_BATCH];
+    const long long off = (long long)step * B;
+    const int nb = (int)max(0LL, min((long long)B, ntrip - off));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
+        a.coef[2 * a.k] = c.step_size;
+        a.coef[2 * a.k + 1] = c.bc2s;
+    }
+    const float invB = nb > 0 ? 1.0f / (float)nb : 0.f;
+    const float inv_layers = 1.0f / (float)(a.L + 1);
+    const float creg = a.lam * invB;
+    const int d = a.d, cnt = 3 * nb;
+    const unsigned long long *keys = a.keys + 3 * off;
+    const unsigned inc_mask = (1u << kPlanIncBits) - 1u;
+    float sp_sum = 0.f, reg_sum = 0.f;
+    for (int j = blockIdx.x * kRowsWaves + w; j < cnt; j += gridDim.x * kRowsWaves) {
+        const unsigned row = plan_row(keys[j]);
+        if (j > 0 && plan_row(keys[j - 1]) == row) continue;   // not the head of its row's run
+        float g[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f}, e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = (lane + 64 * q < d) ? a.emb[(size_t)row * d + lane + 64 * q] : 0.f;
+        // the run, four incidences at a time: their index and row loads are issued together (a popular item's run is a
+        // serial chain of dependent L2 round trips otherwise), the adds stay in plan order
+        constexpr int LA = 4;
+        for (int jj = j; jj < cnt; jj += LA) {
+            int role[LA];
+            long long uu[LA], pp[LA], nn[LA];
+            int nv = 0;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const unsigned long long kk = (jj + i < cnt) ? keys[jj + i] : ~0ULL;
+                const bool ok = nv == i && plan_row(kk) == row && jj + i < cnt;
+                nv += ok ? 1 : 0;
+                const unsigned inc = ok ? ((unsigned)kk & inc_mask) : 0u;
+                const int b = (int)(inc / 3u);
+                role[i] = (int)(inc - 3u * (unsigned)b);
+                uu[i] = a.users[off + b]; pp[i] = a.pos[off + b]; nn[i] = a.neg[off + b];
+            }
+            if (nv == 0) break;
+            float xu[LA][4], xp[LA][4], xn[LA][4];
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const float *lu = a.light + (size_t)uu[i] * d, *lp = a.light + (size_t)(a.U + pp[i]) * d, *ln = a.light + (size_t)(a.U + nn[i]) * d;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = lane + 64 * q;
+                    const bool in = k < d && i < nv;
+                    xu[i][q] = in ? lu[k] : 0.f; xp[i][q] = in ? lp[k] : 0.f; xn[i][q] = in ? ln[k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                if (i >= nv) break;
+                float ps = 0.f, ns = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ps += xu[i][q] * xp[i][q]; ns += xu[i][q] * xn[i][q]; }   // same lane-strided order as bpr_kernel
+                ps = wave_sum(ps); ns = wave_sum(ns);
+                const float x = ns - ps;
+                const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
+                if (role[i] == 0) {   // this triplet's loss terms, once
+                    const float *ep = a.emb + (size_t)(a.U + pp[i]) * d, *en = a.emb + (size_t)(a.U + nn[i]) * d;
+                    float r = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = lane + 64 * q;
+                        if (k < d) { const float a1 = ep[k], a2 = en[k]; r += e[q] * e[q] + a1 * a1 + a2 * a2; }
+                    }
+                    reg_sum += wave_sum(r);
+                    sp_sum += softplus_f(x);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float c = role[i] == 0 ? dx * (xn[i][q] - xp[i][q]) : role[i] == 1 ? -dx * xu[i][q] : dx * xu[i][q];
+                    g[q] += c;
+                    h[q] += c + creg * e[q];
+                }
+            }
+            if (nv < LA) break;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            if (k < d) { a.gprop[(size_t)row * d + k] = g[q]; a.gego[(size_t)row * d + k] = h[q]; }
+        }
+    }
+    if (lane == 0) { red[0][w] = sp_sum; red[1][w] = reg_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f, r = 0.f;
+        for (int q = 0; q < kRowsWaves; ++q) { s += red[0][q]; r += red[1][q]; }
+        a.loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
+    }
+}
+
+// incidence keys of a whole epoch, three per triplet (unsorted)
+__global__ void bpr_plan_keys_kernel(const int64_t *users, const int64_t *pos, const int64_t *neg, long long n, int batch, int U,
+                                     unsigned long long *keys)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long step = (unsigned long long)(t / batch), b3 = 3ULL * (unsigned long long)(t % batch);
+        const unsigned long long hi = step << (kPlanIncBits + kPlanRowBits);
+        keys[3 * t + 0] = hi | ((unsigned long long)users[t] << kPlanIncBits) | (b3 + 0);
+        keys[3 * t + 1] = hi | ((unsigned long long)(U + pos[t]) << kPlanIncBits) | (b3 + 1);
+        keys[3 * t + 2] = hi | ((unsigned long long)(U + neg[t]) << kPlanIncBits) | (b3 + 2);
     }
 }
 
@@ -202,6 +340,8 @@ RK_EXPORT int rk_lightgcn_destroy(rk_lightgcn_t h)
     if (!h) return RK_OK;
     if (h->exec) (void)hipGraphExecDestroy(h->exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (int i = 0; i < 2; ++i) if (h->plan_keys[i]) (void)hipFree(h->plan_keys[i]);
+    if (h->plan_tmp) (void)hipFree(h->plan_tmp);
     delete h;
     return RK_OK;
 }
@@ -324,8 +464,13 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
     return RK_OK;
 }
 
+struct OrderedRef {   // non-null keys: ordered scatter
+    const unsigned long long *keys;
+    int batch;
+};
+
 static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const int64_t *pos, const int64_t *neg,
-                       float *loss_partials, int k, int apply_update, int bump, hipStream_t s)
+                       float *loss_partials, int k, int apply_update, int bump, hipStream_t s, const OrderedRef &ord = OrderedRef{nullptr, 0})
 {
     const BatchRef br{users, pos, neg, k};
     int rc = launch_forward(d, s, &br, d.keep_prob > 0.f ? 1 : 0);
@@ -339,20 +484,29 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     b.state = d.state; b.coef = d.coef; b.k = k;
     b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
     b.nb_direct = 0; b.light_compact = 0;
-    hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
+    b.keys = ord.keys;
+    if (ord.keys) hipLaunchKernelGGL(bpr_rows_kernel, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+    else hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
     RK_CHECK_LAUNCH();
     return launch_backward(d, k, apply_update, bump, s);
 }
 
 // hipGraph of `graph_steps` train steps with users/pos/neg/loss_partials baked in; (re)captured when any of
 // them, the chunk length or the update flag changed.
+static OrderedRef ordered_ref(const rk_lightgcn *h, int batch)
+{
+    return h->deterministic ? OrderedRef{h->plan_sorted, batch} : OrderedRef{nullptr, 0};
+}
+
 static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
-                       int apply_update, int graph_steps)
+                       int apply_update, int graph_steps, int batch)
 {
     const rk_lightgcn_desc &d = h->d;
     const void **cap_key = h->cap_key;
+    const OrderedRef ord = ordered_ref(h, batch);
     const bool same = h->exec && h->exec_steps == graph_steps && h->exec_update == apply_update &&
-                      cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials;
+                      cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials &&
+                      h->cap_det == h->deterministic && (!h->deterministic || (h->cap_plan == ord.keys && h->cap_batch == batch));
     if (same) return RK_OK;
     if (h->exec) { (void)hipGraphExecDestroy(h->exec); h->exec = nullptr; }
     if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -360,7 +514,7 @@ static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos,
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = RK_OK;
     for (int k = 0; k < graph_steps && rc == RK_OK; ++k)
-        rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0, h->cap_stream);
+        rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0, h->cap_stream, ord);
     hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     RK_HIP(e);
@@ -368,6 +522,53 @@ static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos,
     (void)hipGraphDestroy(g);
     h->exec_steps = graph_steps; h->exec_update = apply_update;
     cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
+    h->cap_det = h->deterministic; h->cap_plan = ord.keys; h->cap_batch = batch;
+    return RK_OK;
+}
+
+// Ordered mode: (re)build the epoch's incidence plan.  Buffers are the handle's own, grown on demand (the first epoch of a
+// size pays a hipMalloc; rk_lightgcn_prepare with the epoch's n does it ahead of time).
+static int ensure_plan_capacity(rk_lightgcn *h, long long n)
+{
+    const size_t need = (size_t)3 * (size_t)n;
+    if (need > h->plan_cap) {
+        for (int i = 0; i < 2; ++i) { if (h->plan_keys[i]) (void)hipFree(h->plan_keys[i]); h->plan_keys[i] = nullptr; }
+        if (h->plan_tmp) { (void)hipFree(h->plan_tmp); h->plan_tmp = nullptr; }
+        h->plan_cap = 0;
+        RK_HIP(hipMalloc(&h->plan_keys[0], need * sizeof(unsigned long long)));
+        RK_HIP(hipMalloc(&h->plan_keys[1], need * sizeof(unsigned long long)));
+        hipcub::DoubleBuffer<unsigned long long> db(h->plan_keys[0], h->plan_keys[1]);
+        size_t bytes = 0;
+        RK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, (long long)need, 0, 64, (hipStream_t) nullptr));
+        RK_HIP(hipMalloc(&h->plan_tmp, std::max<size_t>(bytes, 16)));
+        h->plan_tmp_bytes = bytes;
+        h->plan_cap = need;
+    }
+    return RK_OK;
+}
+
+static int build_plan(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, long long n, int batch, hipStream_t s)
+{
+    const rk_lightgcn_desc &d = h->d;
+    const long long n_steps = (n + batch - 1) / batch;
+    if (n_steps >= (1LL << kPlanStepBits) || (long long)d.n_users + d.n_items >= (1LL << kPlanRowBits) || 3LL * batch >= (1LL << kPlanIncBits))
+        RK_FAIL(RK_EINVAL, "deterministic scatter: an epoch of < 2^20 steps, < 2^24 node rows and batches of < 349525 triplets is supported");
+    int rc = ensure_plan_capacity(h, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bpr_plan_keys_kernel, dim3((int)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, users, pos, neg, n, batch,
+                       d.n_users, h->plan_keys[0]);
+    RK_CHECK_LAUNCH();
+    hipcub::DoubleBuffer<unsigned long long> db(h->plan_keys[0], h->plan_keys[1]);
+    size_t bytes = h->plan_tmp_bytes;
+    RK_HIP(hipcub::DeviceRadixSort::SortKeys(h->plan_tmp, bytes, db, 3 * n, 0, 64, s));
+    h->plan_sorted = db.Current();
+    return RK_OK;
+}
+
+RK_EXPORT int rk_lightgcn_set_deterministic(rk_lightgcn_t h, int32_t on)
+{
+    if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_set_deterministic: null handle");
+    h->deterministic = on ? 1 : 0;
     return RK_OK;
 }
 
@@ -379,7 +580,8 @@ RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const i
     if (!apply_update && !h->d.grad) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: apply_update=0 needs desc.grad");
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
     if (graph_steps <= 1) return RK_OK;
-    int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps);
+    if (h->deterministic) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: in deterministic mode the graph depends on the epoch's plan; the first rk_lightgcn_train_epoch captures it");
+    int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps, 0);
     if (rc) return rc;
     RK_HIP(hipGraphUpload(h->exec, (hipStream_t)stream));
     return RK_OK;
@@ -417,15 +619,20 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(1), 0, s, d.state, 0, adam_t0, (long long)n, batch);
     RK_CHECK_LAUNCH();
 
+    if (h->deterministic) {
+        int rc = build_plan(h, users, pos, neg, n, batch, s);
+        if (rc) return rc;
+    }
     int done = 0;
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
     if (graph_steps > 1 && n_steps >= graph_steps) {
-        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps);
+        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps, batch);
         if (rc) return rc;
         for (; done + graph_steps <= n_steps; done += graph_steps) RK_HIP(hipGraphLaunch(h->exec, s));
     }
+    const OrderedRef ord = ordered_ref(h, batch);
     for (; done < n_steps; ++done) {
-        int rc = launch_step(d, users, pos, neg, loss_partials, 0, apply_update, 1, s);
+        int rc = launch_step(d, users, pos, neg, loss_partials, 0, apply_update, 1, s, ord);
         if (rc) return rc;
     }
     return RK_OK;
@@ -481,6 +688,7 @@ RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const flo
     b.light = light; b.emb = emb; b.gprop = gprop; b.gego = gego;
     b.users = rows_u; b.pos = rows_p; b.neg = rows_n;
     b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb; b.light_compact = light_compact ? 1 : 0;
+    b.keys = nullptr;
     hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, (hipStream_t)stream, b);
     RK_CHECK_LAUNCH();
     return RK_OK;

@@ -21,7 +21,8 @@ class LightGCN(BaseVictim):
     @classmethod
     def extra_user_args(cls, kwargs):
         # recad/model/victim/lightgcn.py:21-28 (pretrained tables are supplied by the caller)
-        return "user_emb, item_emb" if kwargs.get("pretrain", False) else ""
+        # + this build's own option: deterministic (ordered gradient scatter, rk_lightgcn_set_deterministic)
+        return "user_emb, item_emb, deterministic" if kwargs.get("pretrain", False) else "deterministic"
 
     def _build(self, **config):
         self.config = config
@@ -60,6 +61,9 @@ class LightGCN(BaseVictim):
         self.graph_steps = 8  # steps per hipGraph replay; 0/1 = plain launches
         # last forward layer only on the minibatch's rows (-4 us of 18 on ml1m)
         self.use_batch_sparsity = True
+        # ordered (bit-reproducible) gradient scatter instead of float atomics: one more launch per step and a sort of
+        # the epoch's triplets (rk_lightgcn_set_deterministic); not a reference option (its CUDA path is atomic too)
+        self.deterministic = bool(config.get("deterministic", False))
 
     # ------------------------------------------------------------------ C-ABI handle
     def _adam_state(self, p):
@@ -120,7 +124,8 @@ class LightGCN(BaseVictim):
         # the reference re-reads them every step
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
-               float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]))
+               float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
+               bool(self.deterministic))
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -154,6 +159,8 @@ class LightGCN(BaseVictim):
             drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]))
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
+        if self.deterministic:
+            _lib.check(_lib.lib().rk_lightgcn_set_deterministic(h, 1), "rk_lightgcn_set_deterministic")
         self._handle, self._handle_key, self._ws = h, key, ws
         return h
 
@@ -225,7 +232,7 @@ class LightGCN(BaseVictim):
         hipGraph now, so that no later epoch (or timed region) pays for either."""
         h = self._ensure_handle(want_grad=want_grad)
         st = self._staging(int(n_triplets), int(batch), self.embedding_user.weight.device)
-        if self._fused_adam and int(self.graph_steps) > 1:
+        if self._fused_adam and int(self.graph_steps) > 1 and not self.deterministic:   # (deterministic: the graph follows the epoch's plan)
             _lib.check(_lib.lib().rk_lightgcn_prepare(
                 h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), _lib.ptr(st["loss"]), 1,
                 int(self.graph_steps), _lib.stream_ptr()), "rk_lightgcn_prepare")
