@@ -188,7 +188,7 @@ int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *po
  * GPU.  Default here: float atomics too (sum order not fixed; the loss is reproducible, gradients to ~1e-7).  on != 0:
  * train_epoch first sorts the epoch's 3n (node row, triplet, role) incidences once (handle-owned buffers, 48 bytes per
  * triplet) and every step adds each row's contributions in (triplet index, role) order with plain stores, one wave per
- * touched row instead of one per triplet -- bit-identical gradients and parameters from run to run.  Limits: < 2^20 steps per epoch, < 2^24 node
+ * touched row instead of one per triplet -- bit-identical gradients and parameters from run to run (+5 % per ml1m step).  Limits: < 2^20 steps per epoch, < 2^24 node
  * rows, batch < 349 525.  Not used by rk_bpr_rows (the row-sharded trainer). */
 int rk_lightgcn_set_deterministic(rk_lightgcn_t h, int32_t on);
 

@@ -126,13 +126,21 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     }
 }
 
-// Ordered form of bpr_kernel (rk_lightgcn_set_deterministic): one wave per node row that occurs in the minibatch.  The row's
-// incidences are taken in the order of the plan -- triplet index, then role (user, positive, negative): the order a
-// sequential loop over the batch produces (oracle: orc_lightgcn_step_general) -- each one recomputes its triplet's two dot
-// products (three row reads from L2; cheaper than a second launch that would hand the coefficients over), and the row is
-// written with plain stores (gprop / gego are zero outside the minibatch's rows).  No atomics: gradients, and with them
-// the trained tables, are reproducible bit for bit.  The loss terms are added by the user-role incidences.
+// Ordered form of bpr_kernel (rk_lightgcn_set_deterministic): one wave per node row that occurs in the minibatch; the row's
+// incidences are added in the order of the plan -- triplet index, then role (user, positive, negative): the order a
+// sequential loop over the batch produces (oracle: orc_lightgcn_step_general) -- and the row is written with plain stores
+// (gprop / gego are zero outside the minibatch's rows).  No atomics: gradients, and with them the trained tables, are
+// reproducible bit for bit.
+// A popular item occurs 10-30 times in a 1024-triplet batch, and a wave that walks its run one incidence at a time
+// (ids -> rows -> two 64-lane reductions -> add) makes the launch 22 us instead of bpr_kernel's 6.  So, per run of up to
+// 64 incidences: (1) lane i loads key and triplet ids of incidence i (two dependent round trips for the whole run);
+// (2) the triplets' coefficients, sixteen at a time, one per 4-lane group (each triplet is recomputed by the up to three
+// rows it touches: cheaper than a second launch handing the coefficients over); (3) the adds, in plan order, LA row
+// loads in flight.  The loss terms are added by the user-role incidences.
+static constexpr int kRowsGL = 4, kRowsNG = 64 / kRowsGL;   // lanes per coefficient group, groups per wave (16 / 8 / 4 lanes measured: 104.0 / 103.4 / 103.1 us per step)
 static constexpr int kRowsWaves = 16;   // 256 workgroups (one loss partial each) x 16 waves: a wave per incidence of a 1024-triplet batch
+// Q = ceil(dim / 64) floats per lane and row; 16 / Q rows in flight in phase (3) (more spills at the 128-VGPR cap of a 1024-thread workgroup)
+template <int Q>
 __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs a)
 {
     __shared__ float red[2][kRowsWaves];
@@ -153,78 +161,121 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
     const int d = a.d, cnt = 3 * nb;
     const unsigned long long *keys = a.keys + 3 * off;
     const unsigned inc_mask = (1u << kPlanIncBits) - 1u;
-    float sp_sum = 0.f, reg_sum = 0.f;
+    const int l4 = lane % kRowsGL, grp = lane / kRowsGL;
+    const bool vec4 = (d & 3) == 0;   // rows are 16-byte aligned
+    float sp_sum = 0.f, reg_sum = 0.f;   // per 4-lane group; combined in group order at the end
     for (int j = blockIdx.x * kRowsWaves + w; j < cnt; j += gridDim.x * kRowsWaves) {
-        const unsigned row = plan_row(keys[j]);
-        if (j > 0 && plan_row(keys[j - 1]) == row) continue;   // not the head of its row's run
-        float g[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f}, e[4];
+        // lane i's key of the first 64 incidences from j on, and the one before j: one round trip decides "head of a run"
+        const unsigned long long kk0 = (j + lane < cnt) ? keys[j + lane] : ~0ULL;
+        const unsigned long long kprev = keys[max(j - 1, 0)];
+        const unsigned row = __shfl(plan_row(kk0), 0, 64);
+        if (j > 0 && plan_row(kprev) == row) continue;   // not the head of its row's run
+        float g[Q], h[Q], e[Q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = (lane + 64 * q < d) ? a.emb[(size_t)row * d + lane + 64 * q] : 0.f;
-        // the run, four incidences at a time: their index and row loads are issued together (a popular item's run is a
-        // serial chain of dependent L2 round trips otherwise), the adds stay in plan order
-        constexpr int LA = 4;
-        for (int jj = j; jj < cnt; jj += LA) {
-            int role[LA];
-            long long uu[LA], pp[LA], nn[LA];
-            int nv = 0;
+        for (int q = 0; q < Q; ++q) { g[q] = 0.f; h[q] = 0.f; }
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const unsigned long long kk = (jj + i < cnt) ? keys[jj + i] : ~0ULL;
-                const bool ok = nv == i && plan_row(kk) == row && jj + i < cnt;
-                nv += ok ? 1 : 0;
-                const unsigned inc = ok ? ((unsigned)kk & inc_mask) : 0u;
-                const int b = (int)(inc / 3u);
-                role[i] = (int)(inc - 3u * (unsigned)b);
-                uu[i] = a.users[off + b]; pp[i] = a.pos[off + b]; nn[i] = a.neg[off + b];
-            }
-            if (nv == 0) break;
-            float xu[LA][4], xp[LA][4], xn[LA][4];
+        for (int q = 0; q < Q; ++q) e[q] = (lane + 64 * q < d) ? a.emb[(size_t)row * d + lane + 64 * q] : 0.f;
+        for (int j0 = j; j0 < cnt; j0 += 64) {
+            // (1) lane i = incidence j0 + i
+            const unsigned long long kk = j0 == j ? kk0 : ((j0 + lane < cnt) ? keys[j0 + lane] : ~0ULL);
+            const unsigned long long same = __ballot(j0 + lane < cnt && plan_row(kk) == row);
+            const int len = (~same == 0ULL) ? 64 : (__ffsll((long long)~same) - 1);   // leading lanes of this row
+            if (len == 0) break;
+            const unsigned inc = (unsigned)kk & inc_mask;
+            const int b = (int)(inc / 3u), my_role = (int)(inc - 3u * (unsigned)b);
+            int iu = 0, ip = 0, in_ = 0;
+            if (lane < len) { iu = (int)a.users[off + b]; ip = a.U + (int)a.pos[off + b]; in_ = a.U + (int)a.neg[off + b]; }
+            // what lane i adds: coef * (A - B) with role user: dx * (ln - lp); positive: -dx * lu; negative: dx * lu
+            const int idx_a = my_role == 0 ? in_ : iu, idx_b = my_role == 0 ? ip : -1;
+            constexpr int LA = 16 / Q;
+            float xa[LA][Q], xb[LA][Q];
+            auto load_rows = [&](int c0) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const float *lu = a.light + (size_t)uu[i] * d, *lp = a.light + (size_t)(a.U + pp[i]) * d, *ln = a.light + (size_t)(a.U + nn[i]) * d;
+                for (int i = 0; i < LA; ++i) {
+                    const int src = min(c0 + i, len - 1);   // past the run: re-read its last incidence (unconditional loads issue back to back)
+                    const int ra = __shfl(idx_a, src, 64), rb = __shfl(idx_b, src, 64);
+                    const float *pa = a.light + (size_t)ra * d, *pb = a.light + (size_t)max(rb, 0) * d;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = lane + 64 * q;
-                    const bool in = k < d && i < nv;
-                    xu[i][q] = in ? lu[k] : 0.f; xp[i][q] = in ? lp[k] : 0.f; xn[i][q] = in ? ln[k] : 0.f;
+                    for (int q = 0; q < Q; ++q) {
+                        const int k = lane + 64 * q;
+                        xa[i][q] = k < d ? pa[k] : 0.f;
+                        xb[i][q] = (k < d && rb >= 0) ? pb[k] : 0.f;
+                    }
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                if (i >= nv) break;
+            };
+            load_rows(0);   // independent of the coefficients: in flight under phase (2)
+            // (2) coefficients: sixteen 4-lane groups, group `grp` takes incidence r + grp of every round r = 0, 16, 32, 48
+            float my_dx = 0.f;
+            for (int r = 0; r < len; r += kRowsNG) {
+                const int src = min(r + grp, len - 1);
+                const bool live = r + grp < len;
+                const int ru = __shfl(iu, src, 64), rp = __shfl(ip, src, 64), rn = __shfl(in_, src, 64), ro = __shfl(my_role, src, 64);
+                const float *lu = a.light + (size_t)ru * d, *lp = a.light + (size_t)rp * d, *ln = a.light + (size_t)rn * d;
                 float ps = 0.f, ns = 0.f;
+                if (vec4) {
+                    for (int k = l4 * 4; k < d; k += kRowsGL * 4) {
+                        const float4 xu = *reinterpret_cast<const float4 *>(lu + k), xp = *reinterpret_cast<const float4 *>(lp + k),
+                                     xn = *reinterpret_cast<const float4 *>(ln + k);
+                        ps += xu.x * xp.x; ps += xu.y * xp.y; ps += xu.z * xp.z; ps += xu.w * xp.w;
+                        ns += xu.x * xn.x; ns += xu.y * xn.y; ns += xu.z * xn.z; ns += xu.w * xn.w;
+                    }
+                } else {
+                    for (int k = l4; k < d; k += kRowsGL) { const float xu = lu[k]; ps += xu * lp[k]; ns += xu * ln[k]; }
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ps += xu[i][q] * xp[i][q]; ns += xu[i][q] * xn[i][q]; }   // same lane-strided order as bpr_kernel
-                ps = wave_sum(ps); ns = wave_sum(ns);
+                for (int o = kRowsGL / 2; o > 0; o >>= 1) { ps += __shfl_xor(ps, o, 64); ns += __shfl_xor(ns, o, 64); }
                 const float x = ns - ps;
                 const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
-                if (role[i] == 0) {   // this triplet's loss terms, once
-                    const float *ep = a.emb + (size_t)(a.U + pp[i]) * d, *en = a.emb + (size_t)(a.U + nn[i]) * d;
-                    float r = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int k = lane + 64 * q;
-                        if (k < d) { const float a1 = ep[k], a2 = en[k]; r += e[q] * e[q] + a1 * a1 + a2 * a2; }
+                if (live && ro == 0) {   // this triplet's loss terms, once
+                    const float *eu = a.emb + (size_t)ru * d, *ep = a.emb + (size_t)rp * d, *en = a.emb + (size_t)rn * d;
+                    float rr = 0.f;
+                    if (vec4) {
+                        for (int k = l4 * 4; k < d; k += kRowsGL * 4) {
+                            const float4 a0 = *reinterpret_cast<const float4 *>(eu + k), a1 = *reinterpret_cast<const float4 *>(ep + k),
+                                         a2 = *reinterpret_cast<const float4 *>(en + k);
+                            rr += a0.x * a0.x + a1.x * a1.x + a2.x * a2.x; rr += a0.y * a0.y + a1.y * a1.y + a2.y * a2.y;
+                            rr += a0.z * a0.z + a1.z * a1.z + a2.z * a2.z; rr += a0.w * a0.w + a1.w * a1.w + a2.w * a2.w;
+                        }
+                    } else {
+                        for (int k = l4; k < d; k += kRowsGL) { const float a0 = eu[k], a1 = ep[k], a2 = en[k]; rr += a0 * a0 + a1 * a1 + a2 * a2; }
                     }
-                    reg_sum += wave_sum(r);
+#pragma unroll
+                    for (int o = kRowsGL / 2; o > 0; o >>= 1) rr += __shfl_xor(rr, o, 64);
+                    reg_sum += rr;
                     sp_sum += softplus_f(x);
                 }
+                const float t = __shfl(dx, ((lane - r) & (kRowsNG - 1)) * kRowsGL, 64);   // incidence `lane` was computed by group lane - r
+                if (lane >= r && lane < r + kRowsNG) my_dx = t;
+            }
+            const float coef = my_role == 1 ? -my_dx : my_dx;
+            // (3) the adds, in plan order (the first LA incidences' rows were requested before phase (2))
+            for (int c0 = 0; c0 < len; c0 += LA) {
+                if (c0 > 0) load_rows(c0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float c = role[i] == 0 ? dx * (xn[i][q] - xp[i][q]) : role[i] == 1 ? -dx * xu[i][q] : dx * xu[i][q];
-                    g[q] += c;
-                    h[q] += c + creg * e[q];
+                for (int i = 0; i < LA; ++i) {
+                    if (c0 + i >= len) break;
+                    const float cf = __shfl(coef, c0 + i, 64);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float c = cf * (xa[i][q] - xb[i][q]);
+                        g[q] += c;
+                        h[q] += c + creg * e[q];
+                    }
                 }
             }
-            if (nv < LA) break;
+            if (len < 64) break;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int k = lane + 64 * q;
             if (k < d) { a.gprop[(size_t)row * d + k] = g[q]; a.gego[(size_t)row * d + k] = h[q]; }
         }
     }
-    if (lane == 0) { red[0][w] = sp_sum; red[1][w] = reg_sum; }
+    // the sixteen groups' loss terms in group order, then the waves' in wave order
+    float sp_w = 0.f, rg_w = 0.f;
+#pragma unroll
+    for (int q = 0; q < kRowsNG; ++q) { sp_w += __shfl(sp_sum, q * kRowsGL, 64); rg_w += __shfl(reg_sum, q * kRowsGL, 64); }
+    if (lane == 0) { red[0][w] = sp_w; red[1][w] = rg_w; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float s = 0.f, r = 0.f;
@@ -485,7 +536,11 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
     b.nb_direct = 0; b.light_compact = 0;
     b.keys = ord.keys;
-    if (ord.keys) hipLaunchKernelGGL(bpr_rows_kernel, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+    if (ord.keys) {
+        if (d.dim <= 64) hipLaunchKernelGGL(bpr_rows_kernel<1>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+        else if (d.dim <= 128) hipLaunchKernelGGL(bpr_rows_kernel<2>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+        else hipLaunchKernelGGL(bpr_rows_kernel<4>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+    }
     else hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
     RK_CHECK_LAUNCH();
     return launch_backward(d, k, apply_update, bump, s);
