@@ -171,12 +171,13 @@ int rk_lightgcn_propagate_dropout(rk_lightgcn_t h, uint64_t mask_seed, void *str
  * backward, dense Adam.  adam_t0 = optimizer steps already taken.  loss_partials: device
  * float[ceil(n/batch)*RK_LOSS_PARTIALS]; step s's loss is the sum of its RK_LOSS_PARTIALS
  * entries (fixed order => reproducible).  apply_update=0 leaves parameters untouched and
- * only fills desc.grad (testing).  graph_steps>1 replays a hipGraph of that many steps. */
+ * only fills desc.grad (testing).  graph_steps>1 replays hipGraphs of graph_steps, graph_steps/2, graph_steps/4, ... (>= 2)
+ * steps -- the longest chunks that fit -- so only a last single step is launched kernel by kernel. */
 int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
                             int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,
                             int32_t apply_update, int32_t graph_steps, void *stream);
 
-/* Optional: capture, instantiate and upload the hipGraph of `graph_steps` train steps for these (stable)
+/* Optional: capture, instantiate and upload the hipGraphs (graph_steps and its halves down to 2 train steps) for these (stable)
  * triplet / loss buffers ahead of the first rk_lightgcn_train_epoch call, so that no epoch pays for it.
  * The graph bakes the four pointers in; train_epoch re-captures by itself when they change.  The
  * reference has no counterpart (its step is eager ATen, lightgcn.py:137-169). */

@@ -11,8 +11,12 @@ thread_local char rk_err_buf[512] = "";
 struct rk_lightgcn {
     rk_lightgcn_desc d;
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int exec_steps = 0, exec_update = -1;
+    // hipGraphs of graph_steps, graph_steps/2, graph_steps/4, ... (>= 2) train steps: an epoch is replayed as the longest
+    // chunks that fit, so only a last single step is ever launched kernel by kernel
+    static constexpr int kExecSlots = 4;
+    hipGraphExec_t exec[kExecSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int exec_steps[kExecSlots] = {0, 0, 0, 0};
+    int exec_update = -1;
     const void *cap_key[4] = {nullptr, nullptr, nullptr, nullptr};  // pointers baked into exec
     // ordered scatter (rk_lightgcn_set_deterministic): the epoch's 3n (row, triplet, role) incidences sorted by
     // (step, row, 3b + role).  Owned by the handle.
@@ -389,7 +393,7 @@ RK_EXPORT int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *ou
 RK_EXPORT int rk_lightgcn_destroy(rk_lightgcn_t h)
 {
     if (!h) return RK_OK;
-    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    for (auto &e : h->exec) if (e) (void)hipGraphExecDestroy(e);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (int i = 0; i < 2; ++i) if (h->plan_keys[i]) (void)hipFree(h->plan_keys[i]);
     if (h->plan_tmp) (void)hipFree(h->plan_tmp);
@@ -554,16 +558,33 @@ static OrderedRef ordered_ref(const rk_lightgcn *h, int batch)
 }
 
 static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
-                       int apply_update, int graph_steps, int batch)
+                       int apply_update, int graph_steps, int batch, hipGraphExec_t *out)
 {
     const rk_lightgcn_desc &d = h->d;
     const void **cap_key = h->cap_key;
     const OrderedRef ord = ordered_ref(h, batch);
-    const bool same = h->exec && h->exec_steps == graph_steps && h->exec_update == apply_update &&
-                      cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials &&
-                      h->cap_det == h->deterministic && (!h->deterministic || (h->cap_plan == ord.keys && h->cap_batch == batch));
-    if (same) return RK_OK;
-    if (h->exec) { (void)hipGraphExecDestroy(h->exec); h->exec = nullptr; }
+    const bool same_key = h->exec_update == apply_update &&
+                          cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials &&
+                          h->cap_det == h->deterministic && (!h->deterministic || (h->cap_plan == ord.keys && h->cap_batch == batch));
+    if (!same_key) {   // everything baked into the graphs changed: drop them all
+        for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {
+            if (h->exec[i]) (void)hipGraphExecDestroy(h->exec[i]);
+            h->exec[i] = nullptr; h->exec_steps[i] = 0;
+        }
+        h->exec_update = apply_update;
+        cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
+        h->cap_det = h->deterministic; h->cap_plan = ord.keys; h->cap_batch = batch;
+    }
+    int slot = -1;
+    for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {
+        if (h->exec[i] && h->exec_steps[i] == graph_steps) { *out = h->exec[i]; return RK_OK; }
+        if (!h->exec[i] && slot < 0) slot = i;
+    }
+    if (slot < 0) {   // all slots taken by other chunk lengths (graph_steps changed between calls): recycle the last
+        slot = rk_lightgcn::kExecSlots - 1;
+        (void)hipGraphExecDestroy(h->exec[slot]);
+        h->exec[slot] = nullptr;
+    }
     if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t g = nullptr;
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -573,11 +594,24 @@ static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos,
     hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     RK_HIP(e);
-    RK_HIP(hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0));
+    RK_HIP(hipGraphInstantiate(&h->exec[slot], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    h->exec_steps = graph_steps; h->exec_update = apply_update;
-    cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
-    h->cap_det = h->deterministic; h->cap_plan = ord.keys; h->cap_batch = batch;
+    h->exec_steps[slot] = graph_steps;
+    *out = h->exec[slot];
+    return RK_OK;
+}
+
+// every chunk length an epoch can be cut into: graph_steps, then halves down to 2
+static int ensure_all_execs(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
+                            int apply_update, int graph_steps, int batch, hipStream_t upload_stream)
+{
+    int n = 0;
+    for (int c = graph_steps; c >= 2 && n < rk_lightgcn::kExecSlots; c /= 2, ++n) {
+        hipGraphExec_t ex = nullptr;
+        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, c, batch, &ex);
+        if (rc) return rc;
+        if (upload_stream) RK_HIP(hipGraphUpload(ex, upload_stream));
+    }
     return RK_OK;
 }
 
@@ -636,10 +670,10 @@ RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const i
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
     if (graph_steps <= 1) return RK_OK;
     if (h->deterministic) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: in deterministic mode the graph depends on the epoch's plan; the first rk_lightgcn_train_epoch captures it");
-    int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps, 0);
-    if (rc) return rc;
-    RK_HIP(hipGraphUpload(h->exec, (hipStream_t)stream));
-    return RK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipStream_t up = nullptr;
+    if (!s) { if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)); up = h->cap_stream; } else up = s;
+    return ensure_all_execs(h, users, pos, neg, loss_partials, apply_update, graph_steps, 0, up);
 }
 
 RK_EXPORT int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream)
@@ -680,10 +714,15 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     }
     int done = 0;
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
-    if (graph_steps > 1 && n_steps >= graph_steps) {
-        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, graph_steps, batch);
-        if (rc) return rc;
-        for (; done + graph_steps <= n_steps; done += graph_steps) RK_HIP(hipGraphLaunch(h->exec, s));
+    if (graph_steps > 1 && n_steps >= 2) {
+        int slots = 0;
+        for (int c = graph_steps; c >= 2 && slots < rk_lightgcn::kExecSlots; c /= 2, ++slots) {
+            if (done + c > n_steps) continue;
+            hipGraphExec_t ex = nullptr;
+            int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, c, batch, &ex);
+            if (rc) return rc;
+            for (; done + c <= n_steps; done += c) RK_HIP(hipGraphLaunch(ex, s));
+        }
     }
     const OrderedRef ord = ordered_ref(h, batch);
     for (; done < n_steps; ++done) {
