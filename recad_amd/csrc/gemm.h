@@ -642,10 +642,6 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     if (t_begin >= t_end) return;
     const int n_chunks = g.K / kWK, total = (t_end - t_begin) * n_chunks;
     f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int l16 = lane & 15, lq = lane >> 4;
     long long ra[8], rb[8];
     int m0, n0, m1, n1;   // origin of the tile being accumulated / of the tile whose chunk is being prefetched
@@ -654,13 +650,33 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int p = 0; p < 8; ++p) {
             // rows past the edge of a partial tile (k-contiguous operands only) re-read the last row; their results are not stored
             const int m = min(mt + p * 16 + (tid >> 4), g.M - 1);
-            ra[p] = (long long)(g.a_ridx ? g.a_ridx[m] : m) * g.a_rs;
+            ra[p] = (long long)(g.a_ridx ? g.a_ridx[m] : g.a_rmod ? (m + g.a_roff) % g.a_rmod : m) * g.a_rs;
             rb[p] = (long long)min(nt + p * 16 + (tid >> 4), g.N - 1) * g.b_rs;
+        }
+    };
+    // accumulators of the tile at (mt, nt): zero, or the per-user prefix the k-ordered chain continues (GemmArgs::acc_init);
+    // in the transposed block layout a lane owns C[mt + .. + l16][nt + .. + 4*lq + 0..3]
+    auto init_acc = [&](int mt, int nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *src = nullptr;
+            if (g.acc_init) {
+                const int m = min(mt + wr * 64 + i * 16 + l16, g.M - 1);
+                src = g.acc_init + (size_t)((m + g.a_roff) / g.a_rmod - g.init_base) * g.ld_init;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nt + wc * 64 + j * 16 + 4 * lq;
+                if (!src) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else if (n + 4 <= g.N) acc[i][j] = *reinterpret_cast<const f32x4_u *>(src + n);
+                else acc[i][j] = f32x4{n < g.N ? src[n] : 0.f, n + 1 < g.N ? src[n + 1] : 0.f, n + 2 < g.N ? src[n + 2] : 0.f, 0.f};
+            }
         }
     };
     tile_origin<128>(t_begin, gx, gy, m0, n0);
     m1 = m0; n1 = n0;
     row_offsets(m0, n0);
+    init_acc(m0, n0);
     DeepRegs ta, tb;
     wide_load<MA>(ta, g.A, ra, m0, 0, g.a_cs);
     wide_load<MB>(tb, g.B, rb, n0, 0, g.b_cs);
@@ -745,11 +761,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             };
             if (m0 + 128 <= g.M && n0 + 128 <= g.N) emit(std::false_type{});
             else emit(std::true_type{});
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             m0 = m1; n0 = n1;
+            if (more) init_acc(m0, n0);
             c = 0;
         } else ++c;
         __syncthreads();
@@ -819,7 +832,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         static const int wide_min_k = getenv("RK_GEMM_WIDE_MINK") ? atoi(getenv("RK_GEMM_WIDE_MINK")) : kWK;   // tuning only
         static const int strips = getenv("RK_GEMM_WIDE_STRIPS") ? atoi(getenv("RK_GEMM_WIDE_STRIPS")) : 0;   // A/B only
         const int Mi = fa == 1 && !strips ? g.M : g.M / 128 * 128, Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
-        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k && !g.a_rmod && !g.acc_init &&
+        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k && (fa == 1 || !g.a_rmod) && (!g.acc_init || g.a_rmod > 0) &&
             !g.drop_thresh24) {
             const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
                                  reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 2>)};
@@ -842,6 +855,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
                 e1.N = g.N - Ni; e1.B = g.B + (long long)Ni * g.b_rs; e1.C = g.C + Ni;
                 if (g.col_bias) e1.col_bias = g.col_bias + Ni;
                 if (g.mask) e1.mask = g.mask + Ni;
+                if (g.acc_init) e1.acc_init = g.acc_init + Ni;
                 e = gemm_f32_launch(e1, s);
                 if (e != hipSuccess) return e;
             }
