@@ -480,7 +480,7 @@ def worker(args):
                                    f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
                        "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
-                       "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
+                       "graph_steps": args.graph_steps, "scatter": "ordered" if (args.deterministic and sharded is None) else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
             "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
