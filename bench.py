@@ -163,6 +163,40 @@ def cpu_baseline_port(d, graph, dim, layers, batch, triplets, n_steps_req, budge
             "sample": f"{n} train steps of {batch} triplets on the same graph (oracle/recad_oracle.c, 1 thread, {el:.1f} s)"}
 
 
+def mfma_gemm_probe(dev, nb=8192, n_items=34474, dim=256, reps=40):
+    """The scoring GEMM at north_star's MFMA shape (a block of 8192 users x the yelp-sized catalogue at d = 256), timed live
+    with events on the launch stream: rk_score_matrix without biases is exactly the LightGCN scoring GEMM (gathered user
+    rows, fp32 in / fp32 accumulate).  Reported next to the SpMM roofline; profiles/r02_gemm_d256_wide_pmc.json has the
+    rocprofv3 / PMC view of the same launch."""
+    import torch
+    from recad_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(7)
+    utab = torch.randn(nb, dim, device=dev, generator=g) * 0.1
+    itab = torch.randn(n_items, dim, device=dev, generator=g) * 0.1
+    ids = torch.randperm(nb, device=dev, generator=g).to(torch.int32)
+    out = torch.empty(nb, n_items, device=dev)
+
+    def once():
+        _lib.check(_lib.lib().rk_score_matrix(dim, _lib.ptr(utab), nb, _lib.ptr(ids), _lib.ptr(itab), n_items, None, None, 0.0, 0.0, 0,
+                                              _lib.ptr(out), _lib.stream_ptr()), "rk_score_matrix")
+    for _ in range(8):
+        once()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    tf = 2.0 * nb * n_items * dim / us / 1e6
+    del out
+    return {"bound": "mfma", "kernel": "gemm_f32_wide_kernel<1,1>", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            "shape": f"C[{nb},{n_items}] = U[ids][{nb},{dim}] . I[{n_items},{dim}]^T, fp32 in / fp32 accumulate", "avg_launch_us": us,
+            "flops_per_launch": 2 * nb * n_items * dim,
+            "note": "secondary roofline: the scoring GEMM at d = 256 (dense fp32 MFMA peak 157.3 TFLOP/s at 2.4 GHz)"}
+
+
 def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
     """the reference's own op sequence (recad/model/victim/lightgcn.py:82-113,137-169) written
     against ATen on the host cores -- torch.sparse.mm on the coalesced COO graph, index gathers, softplus,
@@ -455,6 +489,9 @@ def worker(args):
                 "gemm_tflops_e2e": flops / ev_el / 1e12,
                 "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@{10,20,50,100} counts; inputs and outputs resident in HBM"}
 
+    mfma = None
+    if rank == 0 and world == 1 and not args.no_topk and not big and not args.force_collectives:
+        mfma = mfma_gemm_probe(dev)
     cpu = cpu_aten = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         cpu = cpu_baseline_port(d, args.graph, args.dim, args.layers, B, host_triplets, args.cpu_steps)
@@ -482,7 +519,7 @@ def worker(args):
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if (args.deterministic and sharded is None) else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
-            "cpu_baseline_aten": cpu_aten, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
+            "cpu_baseline_aten": cpu_aten, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
         if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
             same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]
