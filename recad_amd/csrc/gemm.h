@@ -701,6 +701,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             wide_load<MB>(tb, g.B, rb, n1, k1, g.b_cs);
         }
         float av[2][4], bv[2][4];
+        __builtin_amdgcn_s_setprio(1);   // the wave in its MFMA phase wins issue slots over the co-resident one's stores (+1.4 %)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             av[0][i] = wide_operand<MA>(pa, i, 0);
@@ -721,6 +722,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][j], av[cur][i], acc[i][j], 0, 0, 0);   // the block TRANSPOSED
         }
+        __builtin_amdgcn_s_setprio(0);
         if (last) {
             // tile finished.  The MFMAs took (B, A), so a 16x16 accumulator block holds C^T: register r of lane (l16, lq) is
             // C[row l16][column 4*lq + r] -- four consecutive columns per lane, one 16-byte store (a quarter of the store
