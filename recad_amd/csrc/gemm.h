@@ -587,8 +587,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2
 // Against gemm_f32_kernel: half the barrier pairs per k, b128 LDS stores (rows of 68 floats stay 16-byte aligned; the 33-float
 // rows of the 32x32x2 layout force scalar stores), operands of k-step s+1 read before step s issues, and 2 workgroups of
 // 256 VGPRs per CU instead of 3 squeezed under 168 (scratch spills).  Each wave owns 64x64 as 4x4 accumulators of
-// v_mfma_f32_16x16x4_f32; same k-ordered chain per element.  A partial last tile is taken for k-contiguous operands (row
-// loads clamped to the last row, stores guarded); for row-contiguous ones the launcher hands the edge strip to gemm_f32_kernel.
+// v_mfma_f32_16x16x4_f32; same k-ordered chain per element.  A is k-contiguous (scoring, tower forward, dX);
+// partial last tiles are taken for k-contiguous operands (row loads clamped to the last row, stores guarded); for a
+// row-contiguous B the launcher hands the edge strip to gemm_f32_kernel.
 static constexpr int kWK = 64, kWLd = kWK + 4, kWLdT = 128 + 16;
 template <int MODE> constexpr int wide_floats() { return MODE == 1 ? 128 * kWLd : kWK * kWLdT; }
 template <int MODE>
@@ -796,16 +797,17 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int chunks = (g.K + kGK - 1) / kGK, per = (chunks + splits - 1) / splits;
         static const int no_deep = getenv("RK_GEMM_NO_DEEP") ? atoi(getenv("RK_GEMM_NO_DEEP")) : 0;   // A/B only
         const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
-        const bool deep = !no_deep && variant != 4 && fa && fb && g.M % 64 == 0 && g.N % 64 == 0 && g.K % kDK == 0 && per % 4 == 0 &&
+        // (A row-contiguous with B k-contiguous has no caller: forward / dX / dW are <1,1>, <1,2>, <2,2>)
+        const bool deep = !no_deep && variant != 4 && fa && fb && !(fa == 2 && fb == 1) && g.M % 64 == 0 && g.N % 64 == 0 && g.K % kDK == 0 && per % 4 == 0 &&
                           per * kGK >= 512;
         if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
         else if (deep) {
             static const int no_half = getenv("RK_GEMM_NO_HALF") ? atoi(getenv("RK_GEMM_NO_HALF")) : 0;   // A/B only
             const bool half = nwg * splits < 256 && !no_half;   // fewer workgroups than CUs: 32-row tiles
-            const void *fn[8] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 64>),
-                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 64>),
+            const void *fn[6] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 64>),
+                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 64>),
                                  reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 32>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 32>),
-                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 1, 32>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 32>)};
+                                 reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 32>)};
             static bool deep_attr = false;
             if (!deep_attr) {
                 for (const void *f : fn) {
@@ -818,7 +820,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
             const int fl_b = fb == 1 ? deep_floats<1, 64>() : deep_floats<2, 64>();
             const size_t lds = (size_t)(fl_a + fl_b) * sizeof(float);
             const dim3 grid(half ? 2 * nwg : nwg, splits);
-            const int which = (half ? 4 : 0) + (fa == 2 ? 2 : 0) + (fb == 2 ? 1 : 0);
+            const int which = (half ? 3 : 0) + (fa == 2 ? 2 : fb == 2 ? 1 : 0);
             void *params[1] = {const_cast<GemmArgs *>(&g2)};
             return hipLaunchKernel(fn[which], grid, dim3(256), params, lds, s);
         } else hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3(nwg, splits), dim3(256), 0, s, g2);
@@ -826,18 +828,18 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     }
     if (g.split_k > 1) return hipErrorInvalidValue;  // split-K is only wired for the 64-tile form
     {
-        // whole 128x128 tiles of aligned operands, K a multiple of 64: the wide kernel on the interior, this function again
-        // on the edge strips (they have fewer than 128 rows or columns, so they never come back here)
+        // many 128-tiles, aligned operands, A k-contiguous (scoring, tower forward, dX), K a multiple of 64: the wide kernel.
+        // A k-contiguous B takes a partial last tile (clamped row loads); a row-contiguous B (dX) needs whole column tiles
+        // and leaves the edge strip to this function again (fewer than 128 columns: it never comes back here).
         static const int no_wide = getenv("RK_GEMM_NO_WIDE") ? atoi(getenv("RK_GEMM_NO_WIDE")) : 0;   // A/B only
-        const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
-        // k-contiguous operands take a partial last tile (clamped row loads); row-contiguous ones need whole tiles
         static const int wide_min_k = getenv("RK_GEMM_WIDE_MINK") ? atoi(getenv("RK_GEMM_WIDE_MINK")) : kWK;   // tuning only
         static const int strips = getenv("RK_GEMM_WIDE_STRIPS") ? atoi(getenv("RK_GEMM_WIDE_STRIPS")) : 0;   // A/B only
-        const int Mi = fa == 1 && !strips ? g.M : g.M / 128 * 128, Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
-        if (!no_wide && variant == 0 && fa && fb && (fa == 1 || !g.a_ridx) && Mi >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k && (fa == 1 || !g.a_rmod) && (!g.acc_init || g.a_rmod > 0) &&
-            !g.drop_thresh24) {
-            const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
-                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<2, 2>)};
+        static const int wide_wgs = getenv("RK_GEMM_WIDE_WGS") ? atoi(getenv("RK_GEMM_WIDE_WGS")) : 512;   // tuning only: 2 per CU
+        const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
+        const int Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
+        if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
+            (!g.acc_init || g.a_rmod > 0) && !g.drop_thresh24) {
+            const void *fn[2] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>)};
             static bool wide_attr = false;
             if (!wide_attr) {
                 for (const void *f : fn) {
@@ -846,11 +848,10 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
                 }
                 wide_attr = true;
             }
-            int gx = (Ni + 127) / 128, gy = (Mi + 127) / 128;
-            const size_t lds = (size_t)((fa == 1 ? wide_floats<1>() : wide_floats<2>()) + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);
+            int gx = (Ni + 127) / 128, gy = (g.M + 127) / 128;
+            const size_t lds = (size_t)(wide_floats<1>() + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);
             void *params[3] = {const_cast<GemmArgs *>(&g), &gx, &gy};
-            static const int wide_wgs = getenv("RK_GEMM_WIDE_WGS") ? atoi(getenv("RK_GEMM_WIDE_WGS")) : 512;   // tuning only: 2 per CU
-            hipError_t e = hipLaunchKernel(fn[(fa == 2 ? 2 : 0) + (fb == 2 ? 1 : 0)], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
+            hipError_t e = hipLaunchKernel(fn[fb == 2 ? 1 : 0], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
             if (e != hipSuccess) return e;
             if (Ni < g.N) {   // right strip: all rows, columns [Ni, N)
                 GemmArgs e1 = g;
@@ -859,15 +860,6 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
                 if (g.mask) e1.mask = g.mask + Ni;
                 if (g.acc_init) e1.acc_init = g.acc_init + Ni;
                 e = gemm_f32_launch(e1, s);
-                if (e != hipSuccess) return e;
-            }
-            if (Mi < g.M) {   // bottom strip: rows [Mi, M), columns [0, Ni)
-                GemmArgs e2 = g;
-                e2.M = g.M - Mi; e2.N = Ni; e2.C = g.C + (size_t)Mi * g.ldc;
-                if (g.a_ridx) e2.a_ridx = g.a_ridx + Mi;
-                else { e2.A = g.A + (long long)Mi * g.a_rs; if (g.row_bias) e2.row_bias = g.row_bias + Mi; }
-                if (g.mask) e2.mask = g.mask + (size_t)Mi * g.ldmask;
-                e = gemm_f32_launch(e2, s);
                 if (e != hipSuccess) return e;
             }
             return hipSuccess;
