@@ -1287,6 +1287,33 @@ def test_get_users_rating_vs_oracle(gpu_device):
     assert torch.equal(lu, keep)
 
 
+@pytest.mark.parametrize("nb,I,d", [(300, 1000, 128), (512, 384, 64), (1000, 2077, 256)])
+def test_wide_gemm_epilogues_vs_oracle(gpu_device, nb, I, d):
+    """gemm_f32_wide_kernel (>= 128 rows and columns, d a multiple of 64) through the C-ABI entry points that use its
+    non-plain epilogues, partial edge tiles in both directions: rk_score_matrix with biases (MF scoring) is bit-identical
+    to the oracle's k-ordered fmaf chain + bias order, rk_users_rating (LightGCN.getUsersRating) is its sigmoid."""
+    from recad_amd import _lib
+    rng = np.random.default_rng(nb + I + d)
+    nu = nb + 37
+    utab = rng.standard_normal((nu, d), dtype=np.float32) * 0.3
+    itab = rng.standard_normal((I, d), dtype=np.float32) * 0.3
+    ub, ib = rng.standard_normal(nu, dtype=np.float32), rng.standard_normal(I, dtype=np.float32)
+    ids = rng.permutation(nu)[:nb].astype(np.int32)
+    t = lambda a: torch.as_tensor(a, device=gpu_device).contiguous()
+    tu, ti, tub, tib, tid = t(utab), t(itab), t(ub), t(ib), t(ids)
+    out = torch.empty(nb, I, device=gpu_device)
+    _lib.check(_lib.lib().rk_score_matrix(d, _lib.ptr(tu), nb, _lib.ptr(tid), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.25, 0.0, 0,
+                                          _lib.ptr(out), _lib.stream_ptr()), "rk_score_matrix")
+    ref = orc.score_rows(utab[ids], itab, ub[ids], ib, 0.25)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    _lib.check(_lib.lib().rk_score_matrix(d, _lib.ptr(tu), nb, _lib.ptr(tid), _lib.ptr(ti), I, None, None, 0.0, 0.0, 0,
+                                          _lib.ptr(out), _lib.stream_ptr()), "rk_score_matrix")
+    plain = orc.score_rows(utab[ids], itab)
+    assert np.array_equal(out.cpu().numpy(), plain)
+    _lib.check(_lib.lib().rk_users_rating(d, _lib.ptr(tu), nb, _lib.ptr(tid), _lib.ptr(ti), I, _lib.ptr(out), _lib.stream_ptr()), "rk_users_rating")
+    assert np.abs(out.cpu().numpy() - 1.0 / (1.0 + np.exp(-plain.astype(np.float64)))).max() < 3e-7
+
+
 def test_device_eval_plumbing(gpu_device):
     """f3: the target-present filter and the pred_shift reduction on the device equal the host restatements."""
     from recad_amd.evaluate import eligible_users, eligible_users_device, pred_shift
