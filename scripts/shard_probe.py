@@ -1,0 +1,59 @@
+"""Per-rank compute of the row-sharded step, measured on ONE GPU: rank 0's slab of a W-way round-robin partition
+(recad_amd/sharded.py: RowLayout + build_slab_chunks + HipOps.spmm), W = 1, 2, 4, 8.  What a rank computes per layer
+(its chunked local SpMMs over the full gathered table) is timed with no collective at all -- the compute side of the
+strong-scaling curve that the driver's multi-GPU run would complete with the all-gather side.
+    python3 scripts/shard_probe.py [workload=config4] [dim=64] [reps=10] [chunks=2]"""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from recad_amd import dataset, synth
+from recad_amd.sharded import HipOps, RowLayout, build_slab_chunks
+
+name = sys.argv[1] if len(sys.argv) > 1 else "config4"
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+n_chunks = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+dev = torch.device("cuda:0")
+big = name in ("c4s", "config4")
+if big:
+    dd = synth.make_device(name, dev)
+    d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+    del dd
+else:
+    d = synth.make(name)
+ds = dataset.from_config("implicit", name, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], device=dev, graph_source="train")
+g = ds.graph_csr()
+N = ds.n_users + ds.n_items
+ops = HipOps()
+out = {"workload": name, "dim": dim, "n_rows": N, "nnz": int(g.col.numel()), "per_layer_ms": {}}
+x_full = None
+for W in (1, 2, 4, 8):
+    lay = RowLayout(N, W, chunks=n_chunks if W > 1 else 1)
+    slabs = [ops.make_slab(rp, cl, vl, dev) for rp, cl, vl in build_slab_chunks(g.rowptr, g.col, g.val, 0, lay)]
+    x = torch.randn(W * lay.M, dim, device=dev) * 0.1          # the gathered table every rank reads
+    ys = [torch.empty(lay.Mc, dim, device=dev) for _ in slabs]  # this rank's chunk outputs
+    for s, y in zip(slabs, ys):
+        ops.spmm(s, x, y=y)                                      # builds the schedules
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for s, y in zip(slabs, ys):
+            ops.spmm(s, x, y=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nnz_local = sum(int(s["col"].numel()) for s in slabs)
+    out["per_layer_ms"][str(W)] = {"ms": ms, "local_rows": lay.M, "local_nnz": nnz_local, "chunks": len(slabs),
+                                   "allgather_bytes_per_rank_out": lay.M * dim * 4, "allgather_bytes_per_rank_in": (W - 1) * lay.M * dim * 4}
+    print(f"W={W}: rank-0 local SpMM per layer {ms:.3f} ms  ({nnz_local} nnz, {lay.M} rows, {len(slabs)} chunk(s)); "
+          f"all-gather receives {(W - 1) * lay.M * dim * 4 / 1e6:.1f} MB per layer", flush=True)
+    del slabs, x, ys
+    torch.cuda.empty_cache()
+base = out["per_layer_ms"]["1"]["ms"]
+for W, v in out["per_layer_ms"].items():
+    v["compute_speedup"] = base / v["ms"]
+print(json.dumps(out))
