@@ -190,7 +190,7 @@ class ShardedLightGCN:
             # Overlap only pays when there is a collective to hide and the slab is big.  The gather of the last chunk of a
             # layer is exposed (about 1/C of the layer's communication) and the local SpMM pays for being cut: measured on one
             # GPU for rank 0 of W = 8 at config 4 (scripts/shard_probe.py): 1.00 / 1.12 / 1.26 ms per layer at C = 2 / 4 / 8,
-            # against ~0.75-1.1 ms to receive the other ranks' 336 MB over xGMI => C = 4 for slabs of >= 128 K rows.
+            # against >= 0.62 ms to receive the other ranks' 336 MB over 7 xGMI links => C = 4 for slabs of >= 128 K rows.
             per_rank = self.N // self.world
             collective = self.world > 1 or force_collectives
             chunks = 4 if (collective and per_rank >= (1 << 17)) else 2 if (collective and per_rank >= 4096) else 1
