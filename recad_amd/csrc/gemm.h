@@ -793,13 +793,15 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         GemmArgs g2 = g;
         const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);
-        // whole 64 x 128 chunks of aligned operands and >= 512 of K per slice: the 128-deep chunk loop (MFMA-rate)
+        // whole 64 x 128 chunks of aligned operands: the 128-deep chunk loop (even a single chunk gains from the half tiles,
+        // the b128 LDS stores and the pipelined operand reads: 1024 x 512 x 256 14.1 -> 8.4 us, 1024 x 256 x 128 9.2 -> 5.8 us)
         const int chunks = (g.K + kGK - 1) / kGK, per = (chunks + splits - 1) / splits;
         static const int no_deep = getenv("RK_GEMM_NO_DEEP") ? atoi(getenv("RK_GEMM_NO_DEEP")) : 0;   // A/B only
+        static const int deep_min_k = getenv("RK_GEMM_DEEP_MINK") ? atoi(getenv("RK_GEMM_DEEP_MINK")) : 128;   // tuning only
         const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
         // (A row-contiguous with B k-contiguous has no caller: forward / dX / dW are <1,1>, <1,2>, <2,2>)
         const bool deep = !no_deep && variant != 4 && fa && fb && !(fa == 2 && fb == 1) && g.M % 64 == 0 && g.N % 64 == 0 && g.K % kDK == 0 && per % 4 == 0 &&
-                          per * kGK >= 512;
+                          per * kGK >= deep_min_k;
         if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
         else if (deep) {
             static const int no_half = getenv("RK_GEMM_NO_HALF") ? atoi(getenv("RK_GEMM_NO_HALF")) : 0;   // A/B only

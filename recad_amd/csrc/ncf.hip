@@ -24,6 +24,10 @@ static int pick_splits(int M, int N, int K, long long cap_floats)
 {
     const long long nwg128 = (long long)((N + 127) / 128) * ((M + 127) / 128);
     if (nwg128 >= 384) return 1;  // the 128-tile form takes it
+    // whole-K on the deep 64-tile kernel beats K-slices + the slice-adding pass wherever that kernel applies (measured,
+    // scripts/gemm_probe.hip, dX forms at batch 1024: 1024 x 512 x 256 8.4 us against 8.5 + 4.7; 1024 x 1024 x 512 18.4
+    // against 15.4 + 5; 1024 x 256 x 128 5.8 against 6.3 + 4.7)
+    if (M % 64 == 0 && N % 64 == 0 && K % 128 == 0) return 1;
     const long long tiles = (long long)((N + 63) / 64) * ((M + 63) / 64);
     long long sp = std::min<long long>(512 / std::max<long long>(tiles, 1), (K + 63) / 64);
     sp = std::min<long long>(sp, cap_floats / std::max<long long>((long long)M * N, 1));
@@ -231,20 +235,25 @@ __global__ __launch_bounds__(1024) void ncf_predict_wgrad_kernel(PairSrc p, int 
         part[(size_t)blockIdx.y * (PS + 1) + k] = t;
     }
 }
-__global__ void ncf_predict_wgrad_finish_kernel(int PS, int n_slabs, const float *__restrict__ part, float *gpw, float *gpb)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > PS) return;
-    float t = 0.f;
-    for (int q = 0; q < n_slabs; ++q) t += part[(size_t)q * (PS + 1) + k];
-    if (k == PS) gpb[0] += t; else gpw[k] += t;
-}
-
-// db[n] += sum_m dY[m,n]: 64 columns x 16 row groups per workgroup, fixed-order LDS combine (deterministic,
-// see above), eight independent loads in flight per thread.
-__global__ __launch_bounds__(1024) void colsum_kernel(int M, int N, const float *__restrict__ dY, float *db)
+// Column sums of one train step in ONE launch (job = blockIdx.y): db_l[n] += sum_m dY_l[m, n] for every tower layer -- the
+// dY's of all layers are still in the activation workspace after the backward sweep -- and, as one more job, the slab
+// partials of the predict-layer weight gradient (gpw[k] / gpb += sum_slab part[slab, k]).  Per job: 64 columns x 16 row
+// groups per workgroup, fixed-order LDS combine (deterministic, see above), eight independent loads in flight per
+// thread.  (One launch per layer plus the finish kernel were 5-6 launches of ~5 us each.)
+struct ColsumJobs {
+    int n_jobs;
+    int M[RK_NCF_MAX_LAYERS + 1], N[RK_NCF_MAX_LAYERS + 1];
+    const float *src[RK_NCF_MAX_LAYERS + 1];
+    float *dst[RK_NCF_MAX_LAYERS + 1];
+    float *dst_last[RK_NCF_MAX_LAYERS + 1];   // optional: column N-1 goes here instead of dst[N-1] (gpb)
+};
+__global__ __launch_bounds__(1024) void colsum_jobs_kernel(const ColsumJobs j)
 {
     __shared__ float red[16][64];
+    const int job = blockIdx.y;
+    const int M = j.M[job], N = j.N[job];
+    if ((int)blockIdx.x * 64 >= N) return;
+    const float *__restrict__ dY = j.src[job];
     const int nc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + nc;
     float s = 0.f;
@@ -252,12 +261,12 @@ __global__ __launch_bounds__(1024) void colsum_kernel(int M, int N, const float 
         for (int m0 = rg; m0 < M; m0 += 16 * 8) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + 16 * j;
-                v[j] = m < M ? dY[(size_t)m * N + n] : 0.f;
+            for (int q = 0; q < 8; ++q) {
+                const int m = m0 + 16 * q;
+                v[q] = m < M ? dY[(size_t)m * N + n] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
+            for (int q = 0; q < 8; ++q) s += v[q];
         }
     }
     red[rg][nc] = s;
@@ -265,7 +274,8 @@ __global__ __launch_bounds__(1024) void colsum_kernel(int M, int N, const float 
     if (rg == 0 && n < N) {
         float t = red[0][nc];
         for (int q = 1; q < 16; ++q) t += red[q][nc];
-        db[n] += t;
+        float *out = (j.dst_last[job] && n == N - 1) ? j.dst_last[job] : j.dst[job] + n;
+        *out += t;
     }
 }
 
@@ -468,9 +478,6 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
             hipLaunchKernelGGL(ncf_predict_wgrad_kernel, dim3((PS + 1 + 63) / 64, n_slabs), dim3(1024), 0, s, p, nb, f, d.mode, d.ug, d.ig, xl,
                                d.d0, d.wgrad_part);
             RK_CHECK_LAUNCH();
-            hipLaunchKernelGGL(ncf_predict_wgrad_finish_kernel, dim3((PS + 1 + 255) / 256), dim3(256), 0, s, PS, n_slabs, d.wgrad_part,
-                               d.grad[4 + 2 * L], d.grad[5 + 2 * L]);
-            RK_CHECK_LAUNCH();
         }
         // tower backward.  dY of the top layer was masked by its own ReLU in the predict kernel; for the layers below
         // the mask (x > 0, x = the previous layer's ReLU output) is applied in the dX GEMM's epilogue.
@@ -484,8 +491,6 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
             const int splits = ((out + 127) / 128) * ((in + 127) / 128) < 384 ? std::max(1, std::min((nb + 31) / 32, 512 / std::max(tiles, 1))) : 1;
             rc = gemm(s, out, in, nb, dy, 1, out, x, 1, in, d.grad[4 + l], in, nullptr, 0, nullptr, 0, splits);
             if (rc) return rc;
-            hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(1024), 0, s, nb, out, dy, d.grad[4 + L + l]);
-            RK_CHECK_LAUNCH();
             // dX[nb,in] = dY W, masked by (x > 0) for l >= 1 (x is the previous layer's ReLU output)
             rc = gemm_auto(s, nb, in, out, dy, out, 1, d.W[l], 1, in, dx, nullptr, 0, l >= 1 ? x : nullptr, d.gemm_scratch, d.gemm_scratch_floats);
             if (rc) return rc;
@@ -499,6 +504,24 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         }
         if (d.mode != RK_NCF_GMF) {
             hipLaunchKernelGGL(ncf_scatter_kernel, dim3(wgrid), dim3(256), 0, s, p, nb, E, d.dacts, d.grad[2], d.grad[3]);
+            RK_CHECK_LAUNCH();
+        }
+        {
+            // bias gradients of every layer + the predict layer's weight-gradient slabs: one launch
+            ColsumJobs cj;
+            memset(&cj, 0, sizeof(cj));
+            int widest = 0;
+            if (d.mode != RK_NCF_GMF)
+                for (int l = 0; l < L; ++l) {
+                    const int out = in_of(d, l) / 2, q = cj.n_jobs++;
+                    cj.M[q] = nb; cj.N[q] = out; cj.src[q] = d.dacts + act_off(d, l + 1, d.max_batch); cj.dst[q] = d.grad[4 + L + l];
+                    widest = std::max(widest, out);
+                }
+            const int q = cj.n_jobs++;
+            cj.M[q] = (nb + kWgradSlab - 1) / kWgradSlab; cj.N[q] = PS + 1; cj.src[q] = d.wgrad_part;
+            cj.dst[q] = d.grad[4 + 2 * L]; cj.dst_last[q] = d.grad[5 + 2 * L];
+            widest = std::max(widest, PS + 1);
+            hipLaunchKernelGGL(colsum_jobs_kernel, dim3((widest + 63) / 64, cj.n_jobs), dim3(1024), 0, s, cj);
             RK_CHECK_LAUNCH();
         }
         if (!apply_update) break;
