@@ -59,7 +59,7 @@ def _worker(rank, world, port, name, out_path, chunks, gather):
 
 
 @pytest.mark.parametrize("world,chunks,gather", [(1, 1, "collective"), (2, 1, "collective"), (2, 3, "collective"),
-                                                 (3, 2, "collective"), (3, 2, "direct")])
+                                                 (3, 2, "collective"), (3, 2, "direct"), (2, 4, "direct")])
 def test_sharded_matches_oracle(tmp_path, world, chunks, gather):
     name = "lightgcn_game_d64_tg"
     out = str(tmp_path / f"w{world}.npz")
