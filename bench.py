@@ -264,9 +264,36 @@ def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
         for s in range(1, n + 1):
             last = step(s)
         el = time.perf_counter() - t0
+        # the per-user evaluation loop of Normal.user_item_model_generate (normal.py:57-93): for EVERY user the reference calls
+        # model(users, items), i.e. computer() -- L sparse mm -- then the pair scores of the user's unseen items and a sort
+        tr_ptr, tr_idx = (np.asarray(a) for a in d["train"])
+        n_eval = 0
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            for u in range(0, U, max(1, U // 24)):
+                seen = np.zeros(I, dtype=bool)
+                seen[tr_idx[tr_ptr[u]:tr_ptr[u + 1]]] = True
+                items_t = torch.from_numpy(np.nonzero(~seen)[0])
+                all_emb = torch.cat([eu, ei])
+                embs = [all_emb]
+                for _ in range(layers):
+                    all_emb = torch.sparse.mm(G, all_emb)
+                    embs.append(all_emb)
+                light = torch.mean(torch.stack(embs, dim=1), dim=1)
+                lu, li = torch.split(light, [U, I])
+                scores = (lu[u].unsqueeze(0) * li[items_t]).sum(1)
+                order = torch.argsort(scores, descending=True)[:100]
+                _ = items_t[order]
+                n_eval += 1
+                if time.perf_counter() - t1 > 6.0:
+                    break
+        el_eval = time.perf_counter() - t1
         return {"value": n * batch / el, "unit": "interactions/s", "cores": k, "kind": "port",
                 "sample": f"{n} train steps of {batch} triplets, the reference's ATen op sequence (torch.sparse.mm COO, "
-                          f"autograd, torch.optim.Adam) on {k} of {ncpu} host threads (fastest of 8/16/32/64), {el:.1f} s; last loss {last:.5f}"}
+                          f"autograd, torch.optim.Adam) on {k} of {ncpu} host threads (fastest of 8/16/32/64), {el:.1f} s; last loss {last:.5f}",
+                "eval_users_per_s": n_eval / el_eval,
+                "eval_sample": f"{n_eval} users through the reference's per-user loop (computer() = {layers} sparse mm per user, "
+                               f"pair scores of the unseen items, sort, top-100), same {k} threads, {el_eval:.1f} s"}
     finally:
         torch.set_num_threads(prev)
 
