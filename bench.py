@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true", help="skip the evaluation leg")
     ap.add_argument("--deterministic", action="store_true",
-                    help="ordered (bit-reproducible) gradient scatter instead of float atomics (single-GPU fused path; labelled in config)")
+                    help="ordered (bit-reproducible) gradient scatter instead of float atomics (fused and row-sharded paths; labelled in config)")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
     ap.add_argument("--parallel", default=None, choices=["rows", "replicas"],
                     help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default) or one "
@@ -378,7 +378,8 @@ def worker(args):
             raise SystemExit("bench.py: the ranks generated different graphs (synthetic workload not reproducible across ranks)")
         sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
                                   victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
-                                  gather=args.gather, force_collectives=args.force_collectives)
+                                  gather=args.gather, force_collectives=args.force_collectives,
+                                  deterministic=bool(args.deterministic))
         sharded.reserve(max(args.steps, args.warmup) * B, B)
     else:
         victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
@@ -544,7 +545,7 @@ def worker(args):
                                    f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
                        "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
-                       "graph_steps": args.graph_steps, "scatter": "ordered" if (args.deterministic and sharded is None) else "float atomics"},
+                       "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
             "cpu_baseline_aten": cpu_aten, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }

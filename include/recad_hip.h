@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 5
+#define RK_ABI_VERSION 6
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -113,6 +113,15 @@ int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, co
 int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light, int32_t light_compact,
                 const float *emb, float *gprop, float *gego, const int64_t *rows_u, const int64_t *rows_p,
                 const int64_t *rows_n, int32_t nb, float *loss_partials, void *stream);
+
+/* The same minibatch with the ordered scatter of rk_lightgcn_set_deterministic (no atomics: plain stores, one wave per
+ * touched row; gprop / gego must be zero on the minibatch's rows): light is always the compact [3*nb, dim] block, and
+ * keys = device uint64[3*nb], the batch's incidences (row << 20) | (3*b + role), role 0/1/2 = user/positive/negative,
+ * SORTED ascending -- the caller's sort (the row-sharded trainer sorts a whole epoch with one batched torch.sort).
+ * Every rank that runs it on the same triplets gets bit-identical gradient rows. */
+int rk_bpr_rows_ordered(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb, float *gprop,
+                        float *gego, const int64_t *rows_u, const int64_t *rows_p, const int64_t *rows_n, int32_t nb,
+                        const uint64_t *keys, float *loss_partials, void *stream);
 
 /* ---------------------------------------------------------------- LightGCN --------- */
 typedef struct rk_lightgcn_desc {

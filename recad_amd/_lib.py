@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryMissing(RuntimeError):
@@ -87,6 +87,7 @@ _SIGNATURES = {
     "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P],
     "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
     "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
+    "rk_bpr_rows_ordered": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
     "rk_lightgcn_propagate": [_P, _P],

@@ -144,20 +144,26 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
 static constexpr int kRowsGL = 4, kRowsNG = 64 / kRowsGL;   // lanes per coefficient group, groups per wave (16 / 8 / 4 lanes measured: 104.0 / 103.4 / 103.1 us per step)
 static constexpr int kRowsWaves = 16;   // 256 workgroups (one loss partial each) x 16 waves: a wave per incidence of a 1024-triplet batch
 // Q = ceil(dim / 64) floats per lane and row; 16 / Q rows in flight in phase (3) (more spills at the 128-VGPR cap of a 1024-thread workgroup)
-template <int Q>
+// DIRECT: the op-level form (rk_bpr_rows_ordered, row-sharded trainer): one batch of nb_direct triplets whose node ids are
+// gathered positions, `keys` is that batch's sorted plan, light is the compact [3*nb, d] block (rows b, nb+b, 2nb+b).
+template <int Q, bool DIRECT = false>
 __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs a)
 {
     __shared__ float red[2][kRowsWaves];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int step = a.state[ST_STEP_BASE] + a.k;
-    const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
-    const int B = a.state[ST_BATCH];
-    const long long off = (long long)step * B;
-    const int nb = (int)max(0LL, min((long long)B, ntrip - off));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
-        a.coef[2 * a.k] = c.step_size;
-        a.coef[2 * a.k + 1] = c.bc2s;
+    int step = 0, nb = a.nb_direct;
+    long long off = 0;
+    if (!DIRECT) {
+        step = a.state[ST_STEP_BASE] + a.k;
+        const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
+        const int B = a.state[ST_BATCH];
+        off = (long long)step * B;
+        nb = (int)max(0LL, min((long long)B, ntrip - off));
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
+            a.coef[2 * a.k] = c.step_size;
+            a.coef[2 * a.k + 1] = c.bc2s;
+        }
     }
     const float invB = nb > 0 ? 1.0f / (float)nb : 0.f;
     const float inv_layers = 1.0f / (float)(a.L + 1);
@@ -187,10 +193,11 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
             if (len == 0) break;
             const unsigned inc = (unsigned)kk & inc_mask;
             const int b = (int)(inc / 3u), my_role = (int)(inc - 3u * (unsigned)b);
-            int iu = 0, ip = 0, in_ = 0;
+            int iu = 0, ip = 0, in_ = 0;   // node rows of the triplet (emb / gradient rows)
             if (lane < len) { iu = (int)a.users[off + b]; ip = a.U + (int)a.pos[off + b]; in_ = a.U + (int)a.neg[off + b]; }
+            const int xu = DIRECT ? b : iu, xp = DIRECT ? nb + b : ip, xn = DIRECT ? 2 * nb + b : in_;   // their light rows
             // what lane i adds: coef * (A - B) with role user: dx * (ln - lp); positive: -dx * lu; negative: dx * lu
-            const int idx_a = my_role == 0 ? in_ : iu, idx_b = my_role == 0 ? ip : -1;
+            const int idx_a = my_role == 0 ? xn : xu, idx_b = my_role == 0 ? xp : -1;
             constexpr int LA = 16 / Q;
             float xa[LA][Q], xb[LA][Q];
             auto load_rows = [&](int c0) {
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
             for (int r = 0; r < len; r += kRowsNG) {
                 const int src = min(r + grp, len - 1);
                 const bool live = r + grp < len;
-                const int ru = __shfl(iu, src, 64), rp = __shfl(ip, src, 64), rn = __shfl(in_, src, 64), ro = __shfl(my_role, src, 64);
+                const int ru = __shfl(xu, src, 64), rp = __shfl(xp, src, 64), rn = __shfl(xn, src, 64), ro = __shfl(my_role, src, 64);
                 const float *lu = a.light + (size_t)ru * d, *lp = a.light + (size_t)rp * d, *ln = a.light + (size_t)rn * d;
                 float ps = 0.f, ns = 0.f;
                 if (vec4) {
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
                 const float x = ns - ps;
                 const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
                 if (live && ro == 0) {   // this triplet's loss terms, once
-                    const float *eu = a.emb + (size_t)ru * d, *ep = a.emb + (size_t)rp * d, *en = a.emb + (size_t)rn * d;
+                    const int nu = DIRECT ? __shfl(iu, src, 64) : ru, np_ = DIRECT ? __shfl(ip, src, 64) : rp, nn = DIRECT ? __shfl(in_, src, 64) : rn;
+                    const float *eu = a.emb + (size_t)nu * d, *ep = a.emb + (size_t)np_ * d, *en = a.emb + (size_t)nn * d;
                     float rr = 0.f;
                     if (vec4) {
                         for (int k = l4 * 4; k < d; k += kRowsGL * 4) {
@@ -784,6 +792,28 @@ RK_EXPORT int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const flo
     b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb; b.light_compact = light_compact ? 1 : 0;
     b.keys = nullptr;
     hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, (hipStream_t)stream, b);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+RK_EXPORT int rk_bpr_rows_ordered(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb, float *gprop,
+                                  float *gego, const int64_t *rows_u, const int64_t *rows_p, const int64_t *rows_n, int32_t nb,
+                                  const uint64_t *keys, float *loss_partials, void *stream)
+{
+    if (dim <= 0 || dim > 256 || n_layers < 0 || !light || !emb || !gprop || !gego || !rows_u || !rows_p || !rows_n || nb <= 0 || !keys || !loss_partials)
+        RK_FAIL(RK_EINVAL, "rk_bpr_rows_ordered: bad arguments");
+    if (3LL * nb >= (1LL << kPlanIncBits)) RK_FAIL(RK_EINVAL, "rk_bpr_rows_ordered: batch of < 349525 triplets");
+    BprArgs b;
+    memset(&b, 0, sizeof(b));
+    b.U = 0; b.d = dim; b.L = n_layers; b.lam = lambda;
+    b.light = light; b.emb = emb; b.gprop = gprop; b.gego = gego;
+    b.users = rows_u; b.pos = rows_p; b.neg = rows_n;
+    b.loss_partials = loss_partials; b.state = nullptr; b.coef = nullptr; b.k = 0; b.nb_direct = nb; b.light_compact = 1;
+    b.keys = reinterpret_cast<const unsigned long long *>(keys);
+    hipStream_t s = (hipStream_t)stream;
+    if (dim <= 64) hipLaunchKernelGGL((bpr_rows_kernel<1, true>), dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+    else if (dim <= 128) hipLaunchKernelGGL((bpr_rows_kernel<2, true>), dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
+    else hipLaunchKernelGGL((bpr_rows_kernel<4, true>), dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
     RK_CHECK_LAUNCH();
     return RK_OK;
 }

@@ -146,9 +146,15 @@ class HipOps:
                                              _lib.ptr(desc), n_blocks, _lib.ptr(scratch), x.shape[1], _lib.ptr(x), x.shape[0],
                                              C.byref(e), _lib.stream_ptr()), "rk_spmm_csr_ex")
 
-    def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials):
+    def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials, keys=None):
         """light_rows: compact [3*nb, d] (users, positives, negatives of the minibatch, in that order);
-        emb / gprop / gego are indexed by the gathered positions ru / rp / rn."""
+        emb / gprop / gego are indexed by the gathered positions ru / rp / rn.  keys (int64[3*nb], the batch's sorted
+        incidence plan): the ordered scatter instead of float atomics."""
+        if keys is not None:
+            _lib.check(_lib.lib().rk_bpr_rows_ordered(dim, n_layers, float(lam), _lib.ptr(light_rows), _lib.ptr(emb), _lib.ptr(gprop),
+                                                      _lib.ptr(gego), _lib.ptr(ru), _lib.ptr(rp), _lib.ptr(rn), ru.numel(), _lib.ptr(keys),
+                                                      _lib.ptr(loss_partials), _lib.stream_ptr()), "rk_bpr_rows_ordered")
+            return
         _lib.check(_lib.lib().rk_bpr_rows(dim, n_layers, float(lam), _lib.ptr(light_rows), 1, _lib.ptr(emb), _lib.ptr(gprop),
                                           _lib.ptr(gego), _lib.ptr(ru), _lib.ptr(rp), _lib.ptr(rn), ru.numel(),
                                           _lib.ptr(loss_partials), _lib.stream_ptr()), "rk_bpr_rows")
@@ -175,7 +181,8 @@ class ShardedLightGCN:
     in place: the slab is cut on the device)."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective", force_collectives=False):
+                 eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective", force_collectives=False,
+                 deterministic=False):
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -199,6 +206,7 @@ class ShardedLightGCN:
         # W == 1 normally short-circuits every collective to a copy; force_collectives keeps them (a one-rank RCCL
         # group on a single-GPU box exercises the real collective calls, their async handles and stream ordering)
         self.force_collectives = bool(force_collectives) and on
+        self.deterministic = bool(deterministic)   # ordered gradient scatter (rk_bpr_rows_ordered): bit-identical on every rank and run
         self.device = torch.device(device) if device is not None else user_emb.device
         if hasattr(csr, "rowptr"):
             rowptr, col, val = csr.rowptr, csr.col, csr.val
@@ -331,7 +339,21 @@ class ShardedLightGCN:
         posn = lay.pos(nodes).contiguous()                                                        # gathered positions
         own_f = ((nodes % self.world) == self.rank).to(torch.float32)
         local = (nodes // self.world)
-        return {"pos": posn, "own_f": own_f, "local": local}
+        ep = {"pos": posn, "own_f": own_f, "local": local}
+        if self.deterministic:
+            # ordered scatter: every step's 3*nb incidences (gathered row << 20 | 3*b + role) sorted once per epoch, the ragged
+            # last step padded with keys that sort behind everything (the kernel reads the first 3*nb of a step)
+            n = posn.shape[1]
+            n_steps = (n + batch - 1) // batch
+            if 3 * batch >= (1 << 20):
+                raise ValueError("deterministic scatter: batches of < 349525 triplets")
+            b_in = torch.arange(n, device=dev) % batch
+            keys = (posn << 20) | (3 * b_in.unsqueeze(0) + torch.arange(3, device=dev).unsqueeze(1))          # [3, n]
+            padded = torch.full((3, n_steps * batch), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+            padded[:, :n] = keys
+            per_step = padded.view(3, n_steps, batch).permute(1, 0, 2).reshape(n_steps, 3 * batch)
+            ep["keys"] = torch.sort(per_step, dim=1).values.contiguous()
+        return ep
 
     def step(self, plan, ep, s0, nb, k):
         """One train step on triplets [s0, s0+nb) of the epoch plan; writes its loss partials to plan['loss'][k]."""
@@ -346,7 +368,8 @@ class ShardedLightGCN:
             self._all_reduce(rows)
         ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
         lp = plan["loss"][k]
-        ops.bpr(self.d, L, self.lam, rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp)
+        ops.bpr(self.d, L, self.lam, rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp,
+                keys=ep["keys"][k] if self.deterministic else None)
         # backward + Adam on the owned rows
         self.t += 1
         adam = {"t": self.t, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}

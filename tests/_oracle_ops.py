@@ -36,7 +36,7 @@ class OracleOps:
             for k, arr in (("p", p), ("m", m), ("v", vv)):
                 adam[k].copy_(torch.from_numpy(arr))
 
-    def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials):
+    def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials, keys=None):   # keys: the HIP ops' ordered plan; this loop is ordered anyway
         """light_rows: compact [3B, d] (users, positives, negatives); emb/gprop/gego indexed by ru/rp/rn."""
         R = light_rows.numpy()
         E = emb.numpy()

@@ -493,7 +493,7 @@ def _check_sharded_eval(ev, g, csr, users, items):
     assert abs(ev["target_score_mean"][0] - rows[0::T, 1].mean()) <= 1e-5 * max(1e-3, abs(rows[0::T, 1].mean()))
 
 
-def _sharded_two_rank_worker(rank, world, port, name, out_path):
+def _sharded_two_rank_worker(rank, world, port, name, out_path, deterministic=False):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -504,7 +504,7 @@ def _sharded_two_rank_worker(rank, world, port, name, out_path):
     U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u0, i0 = G.lightgcn_init(g)
-    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(dev), torch.from_numpy(i0).to(dev), chunks=2)
+    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(dev), torch.from_numpy(i0).to(dev), chunks=2, deterministic=deterministic)
     losses = []
     for s in range(len(g["batch_len"])):
         n = int(g["batch_len"][s])
@@ -542,6 +542,33 @@ def test_sharded_trainer_two_ranks_hip(gpu_device, tmp_path):
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     _check_sharded_eval({"eligible_users": int(res["n_users"]), "hit_counts": res["hits"], "target_score_mean": res["tmean"]}, g, csr,
                         res["users"], res["items"])
+
+
+def test_sharded_ordered_scatter_same_bits_for_every_world_size(gpu_device, tmp_path):
+    """rk_bpr_rows_ordered in the row-sharded trainer (deterministic=True): no float atomics anywhere in the step, every
+    per-row sum in a fixed order that does not depend on the partition -- so the trained tables are bit-identical between a
+    one-rank and a two-rank run (real HIP ops; two processes share the GPU, gloo host-staged collectives), and equal to the
+    reference's goldens like the atomic path's.  (Losses agree to rounding only: which workgroup adds which triplet's loss
+    term follows the gathered row numbering.)"""
+    import socket
+    import torch.multiprocessing as mp
+    name = "lightgcn_game_d64_tg"
+    res = {}
+    for world in (1, 2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = str(tmp_path / f"det_w{world}.npz")
+        mp.spawn(_sharded_two_rank_worker, args=(world, port, name, out, True), nprocs=world, join=True)
+        res[world] = np.load(out)
+    assert np.array_equal(res[1]["users"], res[2]["users"]) and np.array_equal(res[1]["items"], res[2]["items"])
+    assert np.allclose(res[1]["losses"], res[2]["losses"], rtol=1e-6)
+    g = G.load(name)
+    rs = int(g["row_stride"])
+    for s_ in range(len(g["losses"])):
+        assert abs(res[2]["losses"][s_] - g["losses"][s_]) <= LOSS_RTOL * abs(g["losses"][s_])
+    assert G.relerr(res[2]["users"][::rs], g["final_user"]) < TABLE_RTOL
+    assert G.relerr(res[2]["items"][::rs], g["final_item"]) < TABLE_RTOL
 
 
 def test_device_samplers(gpu_device):
