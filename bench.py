@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument("--dim", type=int, default=None, help="default 64 (128 for --workload yelp, BASELINE config 3)")
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--graph-steps", type=int, default=8, help="train steps per hipGraph replay (0 = plain launches)")
+    ap.add_argument("--graph-steps", type=int, default=32, help="train steps per hipGraph replay (0 = plain launches)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true", help="skip the evaluation leg")

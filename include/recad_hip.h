@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 6
+#define RK_ABI_VERSION 7
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -103,6 +103,52 @@ int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, co
                    const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
                    int64_t x_rows, const rk_spmm_epilogue *epi, void *stream);
 
+/* ---- LDS-resident sliced SpMM (recad_amd/csrc/spmm_lds.h): the fast form of the same torch.sparse.mm
+ * (lightgcn.py:107) for bipartite D^-1/2 A D^-1/2 graphs whose class tables fit a CU's 160 KB LDS (ml1m / Amazon-game
+ * size: <= ~9 K rows per class at 4 floats per slice).  Y[:, s] = A . X[:, s] is computed per column slice: a workgroup
+ * stages the source class's whole slice in LDS once and every nonzero becomes one ds_read_b128; the matrix shrinks to a
+ * 16-bit column stream because A is binary: y[r] = dinv[r] * sum_c dinv[c] * x[c], dinv = deg^-1/2 (implicit.py:259-277;
+ * differs from the stored-value product by rounding only, ~1e-7 relative).
+ * Gathered operands use a SLICED layout: users block [dim/Su][U][Su] followed by the items block [dim/Si][I][Si]
+ * (Su = 1 << lsu, Si = 1 << lsi floats); rk_lds_pack / rk_lds_unpack convert from / to row-major [U+I, dim].
+ * _build reads rowptr / col / val back (synchronous), checks that the graph qualifies and returns *n_words == 0 when it
+ * does not (callers then keep rk_spmm_csr); otherwise the plan goes into a 16-byte aligned READ-ONLY device buffer of
+ * n_words int32 (_upload), shareable by any number of handles and streams -- the kernel has no global scratch. */
+typedef struct rk_lds_info {
+    int32_t n_wg, lds_bytes, lpa, lpb;        /* launch shape: workgroups, dynamic LDS bytes, lanes per entry of the two halves */
+    int32_t n_users, n_items, dim, lsu, lsi;  /* sliced-layout parameters */
+    int32_t chunk;                            /* chunk caps (half 0 | half 1 << 16), informational */
+    int32_t reserved[6];
+} rk_lds_info;
+typedef struct rk_lds_plan *rk_lds_plan_t;
+int rk_lds_plan_build(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val /*nullable*/,
+                      int32_t dim, void *stream, rk_lds_plan_t *out, int64_t *n_words, rk_lds_info *info);
+/* the same from HOST arrays, no HIP call (n_cu = compute units to fill): what the CPU tests drive */
+int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val,
+                           int32_t dim, int32_t n_cu, rk_lds_plan_t *out, int64_t *n_words, rk_lds_info *info);
+int rk_lds_plan_words(rk_lds_plan_t plan, int32_t *host_out /*[n_words]*/);
+int rk_lds_plan_upload(rk_lds_plan_t plan, int32_t *dev /*[n_words], 16-byte aligned*/, void *stream);
+int rk_lds_plan_destroy(rk_lds_plan_t plan);
+/* n_arrays arrays of (U+I)*dim floats, `stride` floats apart, converted in one launch */
+int rk_lds_pack(const rk_lds_info *info, const float *row_major, float *sliced, int32_t n_arrays, int64_t stride, void *stream);
+int rk_lds_unpack(const rk_lds_info *info, const float *sliced, float *row_major, int32_t n_arrays, int64_t stride, void *stream);
+/* v = A.x (+ add); y = v; sum_out = (sum_in + v) * sum_scale; zero1 = zero2 = 0; Adam as in rk_spmm_csr_ex.
+ * x, add, sum_in, zero1, zero2, adam_shadow: sliced.  y / sum_out: sliced unless their *_row_major flag is set.
+ * adam_p / m / v: row-major; adam_shadow (nullable) receives a sliced copy of the updated parameters. */
+typedef struct rk_lds_epilogue {
+    const float *add;
+    float *y;
+    const float *sum_in;
+    float *sum_out;
+    float sum_scale;
+    int32_t y_row_major, sum_out_row_major, adam_t;
+    float *zero1, *zero2;
+    float *adam_p, *adam_m, *adam_v, *adam_shadow, *coef_scratch;
+    float lr, beta1, beta2, eps;
+    uint64_t *stamps;   /* diagnostic, nullable: device uint64[4 * n_wg], wall-clock stamps (start, staged, gathered, done) per workgroup */
+} rk_lds_epilogue;
+int rk_spmm_lds(const rk_lds_info *info, const int32_t *plan, const float *x, const rk_lds_epilogue *epi, void *stream);
+
 /* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
  * index emb/gprop/gego directly (item rows already offset), and light too unless light_compact != 0:
  * then light is a compact [3*nb, dim] block holding the propagated rows of the minibatch in the order
@@ -142,7 +188,7 @@ typedef struct rk_lightgcn_desc {
     /* workspace, each float[N*dim] (device) */
     float *buf_a, *buf_b, *light, *gprop, *gego;
     float *grad;                              /* nullable: receives dLoss/dE0 [N*dim] */
-    int32_t *state;                           /* device int32[16], owned by the handle's user */
+    int32_t *state;                           /* device int32[16], 8-byte aligned, owned by the handle's user */
     float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] */
     int32_t *spmm_scratch;                    /* int32[scratch_words] of rk_csr_schedule_build, zero-filled, owned by this
                                                * handle's user (NULL when scratch_words == 0) */
@@ -159,6 +205,15 @@ typedef struct rk_lightgcn_desc {
     int32_t reserved3;
     uint64_t drop_seed;
     const int32_t *tpos;
+    /* optional LDS-resident propagation (rk_lds_plan_*): lds_plan != NULL switches every SpMM of this handle to
+     * rk_spmm_lds's kernel (not with graph dropout).  buf_a / buf_b / gprop / gego then hold SLICED data (same sizes),
+     * lsum, e0s, ms, vs are four more float[N*dim] work buffers: the running layer sum and the SLICED working copies of
+     * E0 and the Adam moments -- refreshed from user_emb / m_user / v_user at the start of every train_epoch call (e0s
+     * also by propagate), updated by the fused Adam, written back to the row-major tensors at the end of the call.
+     * row_bits is unused. */
+    const int32_t *lds_plan;
+    rk_lds_info lds_info;
+    float *lsum, *e0s, *ms, *vs;
 } rk_lightgcn_desc;
 #define RK_MAX_GRAPH_STEPS 64
 
@@ -180,18 +235,20 @@ int rk_lightgcn_propagate_dropout(rk_lightgcn_t h, uint64_t mask_seed, void *str
  * backward, dense Adam.  adam_t0 = optimizer steps already taken.  loss_partials: device
  * float[ceil(n/batch)*RK_LOSS_PARTIALS]; step s's loss is the sum of its RK_LOSS_PARTIALS
  * entries (fixed order => reproducible).  apply_update=0 leaves parameters untouched and
- * only fills desc.grad (testing).  graph_steps>1 replays hipGraphs of graph_steps, graph_steps/2, graph_steps/4, ... (>= 2)
- * steps -- the longest chunks that fit -- so only a last single step is launched kernel by kernel. */
+ * only fills desc.grad (testing).
+ * graph_steps > 1 replays captured hipGraphs: an epoch of <= RK_MAX_GRAPH_STEPS steps is ONE replay of a whole-call graph
+ * (scatter-target zeroing and, on the LDS path, the layout conversions included); a longer one is replayed in chunks of
+ * graph_steps steps plus one remainder graph (a single trailing step is launched kernel by kernel).  The triplet and loss
+ * pointers reach the kernels through desc.state, not through the captured launches, so the graphs (cached per handle, 8
+ * LRU slots) serve any buffers; they must stay valid until the stream has run the call. */
 int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
                             int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,
                             int32_t apply_update, int32_t graph_steps, void *stream);
 
-/* Optional: capture, instantiate and upload the hipGraphs (graph_steps and its halves down to 2 train steps) for these (stable)
- * triplet / loss buffers ahead of the first rk_lightgcn_train_epoch call, so that no epoch pays for it.
- * The graph bakes the four pointers in; train_epoch re-captures by itself when they change.  The
- * reference has no counterpart (its step is eager ATen, lightgcn.py:137-169). */
-int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
-                        float *loss_partials, int32_t apply_update, int32_t graph_steps, void *stream);
+/* Optional: capture, instantiate and upload ahead of time the hipGraphs that an epoch of n triplets in batches of `batch`
+ * will replay, so that no epoch (or timed region) pays for it.  The reference has no counterpart (its step is eager ATen,
+ * lightgcn.py:137-169). */
+int rk_lightgcn_prepare(rk_lightgcn_t h, int64_t n, int32_t batch, int32_t apply_update, int32_t graph_steps, void *stream);
 
 /* Ordered (reproducible) gradient scatter for rk_lightgcn_train_epoch.  The reference scatters the minibatch's embedding
  * gradients through autograd's index_select backward (lightgcn.py:124-129,166): a sequential sum on CPU, float atomics on a

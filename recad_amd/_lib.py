@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryMissing(RuntimeError):
@@ -23,6 +23,29 @@ class HipLibraryMissing(RuntimeError):
 
 class HipCallError(RuntimeError):
     pass
+
+
+class LdsInfo(C.Structure):
+    """rk_lds_info (include/recad_hip.h)."""
+
+    _fields_ = [
+        ("n_wg", C.c_int32), ("lds_bytes", C.c_int32), ("lpa", C.c_int32), ("lpb", C.c_int32),
+        ("n_users", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("lsu", C.c_int32), ("lsi", C.c_int32),
+        ("chunk", C.c_int32), ("reserved", C.c_int32 * 6),
+    ]
+
+
+class LdsEpilogue(C.Structure):
+    """rk_lds_epilogue (include/recad_hip.h)."""
+
+    _fields_ = [
+        ("add", C.c_void_p), ("y", C.c_void_p), ("sum_in", C.c_void_p), ("sum_out", C.c_void_p),
+        ("sum_scale", C.c_float), ("y_row_major", C.c_int32), ("sum_out_row_major", C.c_int32), ("adam_t", C.c_int32),
+        ("zero1", C.c_void_p), ("zero2", C.c_void_p),
+        ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_shadow", C.c_void_p), ("coef_scratch", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("stamps", C.c_void_p),
+    ]
 
 
 class LightGCNDesc(C.Structure):
@@ -41,6 +64,7 @@ class LightGCNDesc(C.Structure):
         ("spmm_scratch", C.c_void_p),
         ("row_bits", C.c_void_p),
         ("keep_prob", C.c_float), ("reserved3", C.c_int32), ("drop_seed", C.c_uint64), ("tpos", C.c_void_p),
+        ("lds_plan", C.c_void_p), ("lds_info", LdsInfo), ("lsum", C.c_void_p), ("e0s", C.c_void_p), ("ms", C.c_void_p), ("vs", C.c_void_p),
     ]
 
 
@@ -86,6 +110,14 @@ _SIGNATURES = {
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rk_spmm_csr": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P],
     "rk_spmm_csr_ex": [_I32, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, C.POINTER(SpmmEpilogue), _P],
+    "rk_lds_plan_build": [_I32, _I32, _P, _P, _P, _I32, _P, C.POINTER(_P), C.POINTER(_I64), C.POINTER(LdsInfo)],
+    "rk_lds_plan_build_host": [_I32, _I32, _P, _P, _P, _I32, _I32, C.POINTER(_P), C.POINTER(_I64), C.POINTER(LdsInfo)],
+    "rk_lds_plan_words": [_P, _P],
+    "rk_lds_plan_upload": [_P, _P, _P],
+    "rk_lds_plan_destroy": [_P],
+    "rk_lds_pack": [C.POINTER(LdsInfo), _P, _P, _I32, _I64, _P],
+    "rk_lds_unpack": [C.POINTER(LdsInfo), _P, _P, _I32, _I64, _P],
+    "rk_spmm_lds": [C.POINTER(LdsInfo), _P, _P, C.POINTER(LdsEpilogue), _P],
     "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_bpr_rows_ordered": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
@@ -93,7 +125,7 @@ _SIGNATURES = {
     "rk_lightgcn_propagate": [_P, _P],
     "rk_lightgcn_propagate_dropout": [_P, C.c_uint64, _P],
     "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],
-    "rk_lightgcn_prepare": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "rk_lightgcn_prepare": [_P, _I64, _I32, _I32, _I32, _P],
     "rk_lightgcn_set_deterministic": [_P, _I32],
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _F, C.c_uint64, _P],
     "rk_score_matrix": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _F, C.c_uint64, _P, _P],

@@ -93,7 +93,15 @@ __device__ __forceinline__ void adam_elem(float &p, float &m, float &v, float g,
 }
 
 // device state words (int32) shared by the kernels of a training epoch
-enum { ST_STEP_BASE = 0, ST_ADAM_T = 1, ST_NTRIP_LO = 2, ST_NTRIP_HI = 3, ST_BATCH = 4, ST_DROP_LO = 5, ST_DROP_HI = 6, ST_WORDS = 16 };
+enum { ST_STEP_BASE = 0, ST_ADAM_T = 1, ST_NTRIP_LO = 2, ST_NTRIP_HI = 3, ST_BATCH = 4, ST_DROP_LO = 5, ST_DROP_HI = 6,
+       // 64-bit device pointers of the epoch's triplets and loss partials: the kernels of a train step read them from here, so a
+       // captured hipGraph is independent of the caller's buffers
+       ST_PTR_USERS = 8, ST_PTR_POS = 10, ST_PTR_NEG = 12, ST_PTR_LOSS = 14, ST_WORDS = 16 };
+template <typename T>
+__device__ __forceinline__ T *st_ptr(const int *state, int word)
+{
+    return reinterpret_cast<T *>(*reinterpret_cast<const unsigned long long *>(state + word));
+}
 
 // splitmix64 finaliser: the counter-based RNG of the samplers and of the graph dropout
 __host__ __device__ __forceinline__ unsigned long long rk_mix64(unsigned long long z)

@@ -5,19 +5,25 @@
 #include <hipcub/hipcub.hpp>
 
 #include "spmm.h"
+#include "spmm_lds.h"
 
 thread_local char rk_err_buf[512] = "";
 
 struct rk_lightgcn {
     rk_lightgcn_desc d;
     hipStream_t cap_stream = nullptr;
-    // hipGraphs of graph_steps, graph_steps/2, graph_steps/4, ... (>= 2) train steps: an epoch is replayed as the longest
-    // chunks that fit, so only a last single step is ever launched kernel by kernel
-    static constexpr int kExecSlots = 4;
-    hipGraphExec_t exec[kExecSlots] = {nullptr, nullptr, nullptr, nullptr};
-    int exec_steps[kExecSlots] = {0, 0, 0, 0};
-    int exec_update = -1;
-    const void *cap_key[4] = {nullptr, nullptr, nullptr, nullptr};  // pointers baked into exec
+    // Captured train steps.  Nothing the caller passes per epoch is baked in (the triplet / loss pointers travel through the
+    // device state block), so an exec stays valid for the life of the handle.  `whole` graphs are one complete
+    // rk_lightgcn_train_epoch call of n_steps steps (zeroing of the scatter targets and -- LDS path -- the layout
+    // conversions included); the others are chunks of a longer epoch.  LRU over kExecSlots.
+    static constexpr int kExecSlots = 8;
+    struct Exec {
+        hipGraphExec_t exec = nullptr;
+        int n_steps = 0, whole = 0, update = 0, det = 0, batch = 0;
+        const void *plan = nullptr;
+        unsigned long long stamp = 0;
+    } exec[kExecSlots];
+    unsigned long long clock = 0;
     // ordered scatter (rk_lightgcn_set_deterministic): the epoch's 3n (row, triplet, role) incidences sorted by
     // (step, row, 3b + role).  Owned by the handle.
     int deterministic = 0;
@@ -26,17 +32,21 @@ struct rk_lightgcn {
     void *plan_tmp = nullptr;
     size_t plan_tmp_bytes = 0;
     const unsigned long long *plan_sorted = nullptr;   // baked into exec
-    const void *cap_plan = nullptr;
-    int cap_det = 0, cap_batch = 0;
 };
 
-__global__ void state_init_kernel(int *state, int step_base, int adam_t, long long n, int batch)
+__global__ void state_init_kernel(int *state, int step_base, int adam_t, long long n, int batch, const int64_t *users,
+                                  const int64_t *pos, const int64_t *neg, float *loss_partials)
 {
     state[ST_STEP_BASE] = step_base;
     state[ST_ADAM_T] = adam_t;
     state[ST_NTRIP_LO] = (int)(unsigned)(n & 0xffffffffLL);
     state[ST_NTRIP_HI] = (int)(n >> 32);
     state[ST_BATCH] = batch;
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(state);
+    q[ST_PTR_USERS / 2] = reinterpret_cast<unsigned long long>(users);
+    q[ST_PTR_POS / 2] = reinterpret_cast<unsigned long long>(pos);
+    q[ST_PTR_NEG / 2] = reinterpret_cast<unsigned long long>(neg);
+    q[ST_PTR_LOSS / 2] = reinterpret_cast<unsigned long long>(loss_partials);
 }
 
 // ---------------------------------------------------------------- BPR forward+backward
@@ -55,7 +65,16 @@ struct BprArgs {
     int light_compact;  // light is a compact [3*nb, d] block: rows b, nb+b, 2nb+b of triplet b (row-sharded trainer)
     // ordered mode (bpr_rows_kernel): the epoch plan, every row's incidences in the order they are added
     const unsigned long long *keys;
+    // gprop / gego in the sliced layout of spmm_lds.h (the LDS-resident propagation gathers them by slice)
+    int sliced;
+    LdsDims sl;
 };
+
+// float offset of element (row, k) of a gradient buffer
+__device__ __forceinline__ size_t grad_off(const BprArgs &a, int row, int k)
+{
+    return a.sliced ? sl_off(a.sl, row, k) : (size_t)row * a.d + k;
+}
 
 // incidence key of the epoch plan: step (20 bits) | node row (24 bits) | 3*b + role (20 bits)
 static constexpr int kPlanIncBits = 20, kPlanRowBits = 24, kPlanStepBits = 20;
@@ -72,12 +91,16 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int step = 0, nb = a.nb_direct;
     long long off = 0;
-    if (a.state) {
+    const int64_t *users = a.users, *pos = a.pos, *neg = a.neg;
+    float *loss_partials = a.loss_partials;
+    if (a.state) {   // a train step of an epoch: batch window and buffers come from the device state block
         step = a.state[ST_STEP_BASE] + a.k;
         const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
         const int B = a.state[ST_BATCH];
         off = (long long)step * B;
         nb = (int)max(0LL, min((long long)B, ntrip - off));
+        users = st_ptr<const int64_t>(a.state, ST_PTR_USERS); pos = st_ptr<const int64_t>(a.state, ST_PTR_POS);
+        neg = st_ptr<const int64_t>(a.state, ST_PTR_NEG); loss_partials = st_ptr<float>(a.state, ST_PTR_LOSS);
     }
     if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
         const AdamCoef c = adam_coef(a.state[ST_ADAM_T] + a.k + 1, a.lr, a.b1, a.b2);
@@ -91,16 +114,15 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     float sp_sum = 0.f, reg_sum = 0.f;
     const int wave_id = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
     for (int b = wave_id; b < nb; b += n_waves) {
-        const long long u = a.users[off + b], p = a.pos[off + b], n = a.neg[off + b];
+        const long long u = users[off + b], p = pos[off + b], n = neg[off + b];
         const float *lu = a.light + (size_t)u * d, *lp = a.light + (size_t)(a.U + p) * d, *ln = a.light + (size_t)(a.U + n) * d;
         if (a.light_compact) { lu = a.light + (size_t)b * d; lp = a.light + (size_t)(nb + b) * d; ln = a.light + (size_t)(2 * nb + b) * d; }
-        const float *eu = a.emb + (size_t)u * d, *ep = a.emb + (size_t)(a.U + p) * d, *en = a.emb + (size_t)(a.U + n) * d;
         float ps = 0.f, ns = 0.f, r = 0.f;
         for (int k = lane; k < d; k += 64) {
             const float xu = lu[k];
             ps += xu * lp[k];
             ns += xu * ln[k];
-            const float a0 = eu[k], a1 = ep[k], a2 = en[k];
+            const float a0 = a.emb[grad_off(a, (int)u, k)], a1 = a.emb[grad_off(a, a.U + (int)p, k)], a2 = a.emb[grad_off(a, a.U + (int)n, k)];
             r += a0 * a0 + a1 * a1 + a2 * a2;
         }
         ps = wave_sum(ps); ns = wave_sum(ns); r = wave_sum(r);
@@ -108,17 +130,16 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
         sp_sum += softplus_f(x);
         reg_sum += r;
         const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
-        float *gu = a.gprop + (size_t)u * d, *gp = a.gprop + (size_t)(a.U + p) * d, *gn = a.gprop + (size_t)(a.U + n) * d;
-        float *hu = a.gego + (size_t)u * d, *hp = a.gego + (size_t)(a.U + p) * d, *hn = a.gego + (size_t)(a.U + n) * d;
         for (int k = lane; k < d; k += 64) {
             const float xu = lu[k];
             const float du = dx * (ln[k] - lp[k]), dp = -dx * xu, dn = dx * xu;
-            unsafeAtomicAdd(gu + k, du);
-            unsafeAtomicAdd(gp + k, dp);
-            unsafeAtomicAdd(gn + k, dn);
-            unsafeAtomicAdd(hu + k, du + creg * eu[k]);
-            unsafeAtomicAdd(hp + k, dp + creg * ep[k]);
-            unsafeAtomicAdd(hn + k, dn + creg * en[k]);
+            const size_t ou = grad_off(a, (int)u, k), op = grad_off(a, a.U + (int)p, k), on = grad_off(a, a.U + (int)n, k);
+            unsafeAtomicAdd(a.gprop + ou, du);
+            unsafeAtomicAdd(a.gprop + op, dp);
+            unsafeAtomicAdd(a.gprop + on, dn);
+            unsafeAtomicAdd(a.gego + ou, du + creg * a.emb[ou]);
+            unsafeAtomicAdd(a.gego + op, dp + creg * a.emb[op]);
+            unsafeAtomicAdd(a.gego + on, dn + creg * a.emb[on]);
         }
     }
     if (lane == 0) { red[0][w] = sp_sum; red[1][w] = reg_sum; }
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     if (threadIdx.x == 0) {
         const float s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         const float r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        a.loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
+        loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
     }
 }
 
@@ -153,7 +174,11 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int step = 0, nb = a.nb_direct;
     long long off = 0;
+    const int64_t *users = a.users, *pos = a.pos, *neg = a.neg;
+    float *loss_partials = a.loss_partials;
     if (!DIRECT) {
+        users = st_ptr<const int64_t>(a.state, ST_PTR_USERS); pos = st_ptr<const int64_t>(a.state, ST_PTR_POS);
+        neg = st_ptr<const int64_t>(a.state, ST_PTR_NEG); loss_partials = st_ptr<float>(a.state, ST_PTR_LOSS);
         step = a.state[ST_STEP_BASE] + a.k;
         const long long ntrip = ((long long)(unsigned)a.state[ST_NTRIP_LO]) | ((long long)a.state[ST_NTRIP_HI] << 32);
         const int B = a.state[ST_BATCH];
@@ -184,7 +209,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
 #pragma unroll
         for (int q = 0; q < Q; ++q) { g[q] = 0.f; h[q] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < Q; ++q) e[q] = (lane + 64 * q < d) ? a.emb[(size_t)row * d + lane + 64 * q] : 0.f;
+        for (int q = 0; q < Q; ++q) e[q] = (lane + 64 * q < d) ? a.emb[grad_off(a, (int)row, lane + 64 * q)] : 0.f;
         for (int j0 = j; j0 < cnt; j0 += 64) {
             // (1) lane i = incidence j0 + i
             const unsigned long long kk = j0 == j ? kk0 : ((j0 + lane < cnt) ? keys[j0 + lane] : ~0ULL);
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
             const unsigned inc = (unsigned)kk & inc_mask;
             const int b = (int)(inc / 3u), my_role = (int)(inc - 3u * (unsigned)b);
             int iu = 0, ip = 0, in_ = 0;   // node rows of the triplet (emb / gradient rows)
-            if (lane < len) { iu = (int)a.users[off + b]; ip = a.U + (int)a.pos[off + b]; in_ = a.U + (int)a.neg[off + b]; }
+            if (lane < len) { iu = (int)users[off + b]; ip = a.U + (int)pos[off + b]; in_ = a.U + (int)neg[off + b]; }
             const int xu = DIRECT ? b : iu, xp = DIRECT ? nb + b : ip, xn = DIRECT ? 2 * nb + b : in_;   // their light rows
             // what lane i adds: coef * (A - B) with role user: dx * (ln - lp); positive: -dx * lu; negative: dx * lu
             const int idx_a = my_role == 0 ? xn : xu, idx_b = my_role == 0 ? xp : -1;
@@ -239,17 +264,16 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
                 const float dx = (x > 20.f ? 1.f : 1.f / (1.f + expf(-x))) * invB * inv_layers;
                 if (live && ro == 0) {   // this triplet's loss terms, once
                     const int nu = DIRECT ? __shfl(iu, src, 64) : ru, np_ = DIRECT ? __shfl(ip, src, 64) : rp, nn = DIRECT ? __shfl(in_, src, 64) : rn;
-                    const float *eu = a.emb + (size_t)nu * d, *ep = a.emb + (size_t)np_ * d, *en = a.emb + (size_t)nn * d;
                     float rr = 0.f;
-                    if (vec4) {
+                    if (vec4) {   // (four consecutive columns from a multiple of 4 are contiguous in the sliced layout too)
                         for (int k = l4 * 4; k < d; k += kRowsGL * 4) {
-                            const float4 a0 = *reinterpret_cast<const float4 *>(eu + k), a1 = *reinterpret_cast<const float4 *>(ep + k),
-                                         a2 = *reinterpret_cast<const float4 *>(en + k);
+                            const float4 a0 = *reinterpret_cast<const float4 *>(a.emb + grad_off(a, nu, k)), a1 = *reinterpret_cast<const float4 *>(a.emb + grad_off(a, np_, k)),
+                                         a2 = *reinterpret_cast<const float4 *>(a.emb + grad_off(a, nn, k));
                             rr += a0.x * a0.x + a1.x * a1.x + a2.x * a2.x; rr += a0.y * a0.y + a1.y * a1.y + a2.y * a2.y;
                             rr += a0.z * a0.z + a1.z * a1.z + a2.z * a2.z; rr += a0.w * a0.w + a1.w * a1.w + a2.w * a2.w;
                         }
                     } else {
-                        for (int k = l4; k < d; k += kRowsGL) { const float a0 = eu[k], a1 = ep[k], a2 = en[k]; rr += a0 * a0 + a1 * a1 + a2 * a2; }
+                        for (int k = l4; k < d; k += kRowsGL) { const float a0 = a.emb[grad_off(a, nu, k)], a1 = a.emb[grad_off(a, np_, k)], a2 = a.emb[grad_off(a, nn, k)]; rr += a0 * a0 + a1 * a1 + a2 * a2; }
                     }
 #pragma unroll
                     for (int o = kRowsGL / 2; o > 0; o >>= 1) rr += __shfl_xor(rr, o, 64);
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int k = lane + 64 * q;
-            if (k < d) { a.gprop[(size_t)row * d + k] = g[q]; a.gego[(size_t)row * d + k] = h[q]; }
+            if (k < d) { const size_t o = grad_off(a, (int)row, k); a.gprop[o] = g[q]; a.gego[o] = h[q]; }
         }
     }
     // the sixteen groups' loss terms in group order, then the waves' in wave order
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void bpr_rows_kernel(const BprArgs
     if (threadIdx.x == 0) {
         float s = 0.f, r = 0.f;
         for (int q = 0; q < kRowsWaves; ++q) { s += red[0][q]; r += red[1][q]; }
-        a.loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
+        loss_partials[(size_t)step * RK_LOSS_PARTIALS + blockIdx.x] = s * invB + a.lam * (0.5f * r * invB);
     }
 }
 
@@ -382,6 +406,12 @@ static int check_desc(const rk_lightgcn_desc &d)
                            "(one [U+I, dim] allocation; the kernels address E0 with a single base)");
     if (d.keep_prob != 0.f && (!(d.keep_prob > 0.f) || d.keep_prob > 1.f || !d.tpos))
         RK_FAIL(RK_EINVAL, "lightgcn: graph dropout needs 0 < keep_prob <= 1 and the transpose index tpos");
+    if (d.lds_plan) {
+        if (!d.lsum || !d.e0s || !d.ms || !d.vs) RK_FAIL(RK_EINVAL, "lightgcn: lds_plan needs the lsum, e0s, ms and vs work buffers");
+        if (d.lds_info.n_users != d.n_users || d.lds_info.n_items != d.n_items || d.lds_info.dim != d.dim || d.lds_info.n_wg <= 0)
+            RK_FAIL(RK_EINVAL, "lightgcn: lds_info does not describe this graph / dim");
+        if (reinterpret_cast<uintptr_t>(d.lds_plan) & 15) RK_FAIL(RK_EINVAL, "lightgcn: lds_plan must be 16-byte aligned");
+    }
     if (((size_t)d.n_users + d.n_items) * d.dim * sizeof(float) >= (1ULL << 32))
         RK_FAIL(RK_EINVAL, "lightgcn: (U+I)*dim*4 must be < 4 GiB (32-bit gather offsets)");
     return RK_OK;
@@ -401,7 +431,7 @@ RK_EXPORT int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *ou
 RK_EXPORT int rk_lightgcn_destroy(rk_lightgcn_t h)
 {
     if (!h) return RK_OK;
-    for (auto &e : h->exec) if (e) (void)hipGraphExecDestroy(e);
+    for (auto &e : h->exec) if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (int i = 0; i < 2; ++i) if (h->plan_keys[i]) (void)hipFree(h->plan_keys[i]);
     if (h->plan_tmp) (void)hipFree(h->plan_tmp);
@@ -431,10 +461,101 @@ static void set_dropout(SpmmArgs &a, const rk_lightgcn_desc &d, int mode, int k,
     a.drop_tpos = transposed ? d.tpos : nullptr;
 }
 
+// ---------------------------------------------------------------- LDS-resident propagation (spmm_lds.h)
+// Used when desc.lds_plan is given, the graph is not dropped out and L >= 1.  buf_a / buf_b / gprop / gego / lsum / e0s are
+// SLICED; E0 / m / v / light / grad stay row-major.
+static bool use_lds(const rk_lightgcn_desc &d) { return d.lds_plan && d.n_layers >= 1 && !(d.keep_prob > 0.f); }
+
+static LdsInfo lds_info(const rk_lightgcn_desc &d)
+{
+    LdsInfo li;
+    li.n_wg = d.lds_info.n_wg; li.lds_bytes = d.lds_info.lds_bytes; li.lpa = d.lds_info.lpa; li.lpb = d.lds_info.lpb;
+    li.U = d.n_users; li.I = d.n_items; li.d = d.dim; li.lsu = d.lds_info.lsu; li.lsi = d.lds_info.lsi;
+    return li;
+}
+
+// Sliced working copies.  During a train_epoch call E0 and the Adam moments LIVE in e0s / ms / vs (the fused Adam's
+// 32-byte pieces of row-major rows cost the last backward launch 7 of 17.6 us); the row-major tensors the caller owns
+// are read once at the start of the call (with_moments) and written back once at its end.  A propagate call only needs e0s.
+static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced, hipStream_t s)
+{
+    const LdsInfo li = lds_info(d);
+    const LdsDims g{li.U, li.I, li.d, li.lsu, li.lsi};
+    const long long n = (long long)(li.U + li.I) * (li.d / 4);
+    LdsPackJob job;
+    memset(&job, 0, sizeof(job));
+    job.n = with_moments ? 3 : 1;
+    job.rm[0] = d.user_emb; job.sl[0] = d.e0s;
+    job.rm[1] = d.m_user; job.sl[1] = d.ms;
+    job.rm[2] = d.v_user; job.sl[2] = d.vs;
+    hipLaunchKernelGGL(lds_pack_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, g, job, to_sliced);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s)
+{
+    const int L = d.n_layers;
+    const LdsInfo li = lds_info(d);
+    float *bufs[2] = {d.buf_a, d.buf_b};
+    for (int l = 1; l <= L; ++l) {
+        LdsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.plan = d.lds_plan;
+        a.x = (l == 1) ? d.e0s : bufs[l & 1];
+        a.e.y = (l < L) ? bufs[(l + 1) & 1] : nullptr;
+        a.e.sum_in = (l == 1) ? d.e0s : d.lsum;
+        a.e.sum_out = (l == L) ? d.light : d.lsum;
+        a.e.sum_rm = (l == L) ? 1 : 0;
+        a.e.sum_scale = (l == L) ? 1.0f / (float)(L + 1) : 1.0f;
+        RK_HIP(spmm_lds_launch(li, a, s));
+    }
+    return RK_OK;
+}
+
+static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s)
+{
+    const int N = d.n_users + d.n_items, L = d.n_layers;
+    const LdsInfo li = lds_info(d);
+    float *bufs[2] = {d.buf_a, d.buf_b};
+    for (int j = 1; j <= L; ++j) {
+        LdsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.plan = d.lds_plan;
+        a.x = (j == 1) ? d.gprop : bufs[j & 1];
+        const bool last = (j == L);
+        a.e.add = last ? d.gego : d.gprop;
+        a.e.sum_scale = 1.0f;
+        if (last) {
+            a.e.zero1 = d.gego;
+            a.e.zero2 = (L >= 2) ? d.gprop : nullptr;
+            if (apply_update) {
+                a.e.adam = 1;
+                a.e.p = d.e0s; a.e.m = d.ms; a.e.v = d.vs;   // sliced working copies (lds_sync)
+                a.e.coef = d.coef + 2 * k;
+                a.e.b1 = d.beta1; a.e.b2 = d.beta2; a.e.eps = d.eps;
+            }
+            a.e.y = d.grad;  // nullable, row-major
+            a.e.y_rm = 1;
+            a.e.state = d.state;
+            a.e.bump = bump;
+        } else {
+            a.e.y = bufs[(j + 1) & 1];
+        }
+        RK_HIP(spmm_lds_launch(li, a, s));
+    }
+    if (L == 1) {   // gprop is the gather operand of the only backward SpMM: cleaned by a kernel (see launch_backward)
+        const long long n4 = (long long)N * d.dim / 4;
+        hipLaunchKernelGGL(zero_f4_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s,
+                           reinterpret_cast<float4 *>(d.gprop), n4, d.gprop, (long long)N * d.dim);
+        RK_CHECK_LAUNCH();
+    }
+    return RK_OK;
+}
+
 // forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
 struct BatchRef {
-    const int64_t *users, *pos, *neg;
-    int k;
+    int k;   // step of the chunk (the triplets themselves are found through the state block)
 };
 
 // forward: light = mean_l A^l E0.  With a BatchRef (training) the first layer marks the minibatch's
@@ -445,6 +566,7 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
 {
     const int L = d.n_layers;
     const float inv = 1.0f / (float)(L + 1);
+    if (use_lds(d) && drop == 0) return launch_forward_lds(d, s);
     if (L == 0) {
         RK_HIP(hipMemcpyAsync(d.light, d.user_emb, sizeof(float) * (size_t)d.n_users * d.dim, hipMemcpyDeviceToDevice, s));
         RK_HIP(hipMemcpyAsync(d.light + (size_t)d.n_users * d.dim, d.item_emb, sizeof(float) * (size_t)d.n_items * d.dim,
@@ -462,7 +584,6 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
         if (batch && d.row_bits && L >= 2) {
             if (l == 1) {
                 a.mark_bits = d.row_bits; a.mark_U = d.n_users; a.mark_k = batch->k; a.mark_state = d.state;
-                a.mark_users = batch->users; a.mark_pos = batch->pos; a.mark_neg = batch->neg;
             }
             if (l == L) a.row_filter = d.row_bits;
         }
@@ -477,6 +598,7 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
 static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s)
 {
     const int N = d.n_users + d.n_items, L = d.n_layers;
+    if (use_lds(d)) return launch_backward_lds(d, k, apply_update, bump, s);
     float *bufs[2] = {d.buf_a, d.buf_b};
     auto fill_adam = [&](SpmmEpi &e) {
         if (apply_update) {
@@ -532,22 +654,22 @@ struct OrderedRef {   // non-null keys: ordered scatter
     int batch;
 };
 
-static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const int64_t *pos, const int64_t *neg,
-                       float *loss_partials, int k, int apply_update, int bump, hipStream_t s, const OrderedRef &ord = OrderedRef{nullptr, 0})
+static int launch_step(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s, const OrderedRef &ord = OrderedRef{nullptr, 0})
 {
-    const BatchRef br{users, pos, neg, k};
+    const BatchRef br{k};
     int rc = launch_forward(d, s, &br, d.keep_prob > 0.f ? 1 : 0);
     if (rc) return rc;
     BprArgs b;
+    memset(&b, 0, sizeof(b));
     b.U = d.n_users; b.d = d.dim; b.L = d.n_layers; b.lam = d.lambda;
-    b.light = d.light; b.emb = d.user_emb;
+    b.light = d.light; b.emb = use_lds(d) ? d.e0s : d.user_emb;   // (LDS path: E0 lives in its sliced copy during an epoch)
     b.gprop = d.gprop; b.gego = d.gego;
-    b.users = users; b.pos = pos; b.neg = neg;
-    b.loss_partials = loss_partials;
     b.state = d.state; b.coef = d.coef; b.k = k;
     b.lr = d.lr; b.b1 = d.beta1; b.b2 = d.beta2;
     b.nb_direct = 0; b.light_compact = 0;
     b.keys = ord.keys;
+    b.sliced = use_lds(d) ? 1 : 0;
+    b.sl = LdsDims{d.n_users, d.n_items, d.dim, d.lds_info.lsu, d.lds_info.lsi};
     if (ord.keys) {
         if (d.dim <= 64) hipLaunchKernelGGL(bpr_rows_kernel<1>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
         else if (d.dim <= 128) hipLaunchKernelGGL(bpr_rows_kernel<2>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
@@ -558,68 +680,67 @@ static int launch_step(const rk_lightgcn_desc &d, const int64_t *users, const in
     return launch_backward(d, k, apply_update, bump, s);
 }
 
-// hipGraph of `graph_steps` train steps with users/pos/neg/loss_partials baked in; (re)captured when any of
-// them, the chunk length or the update flag changed.
 static OrderedRef ordered_ref(const rk_lightgcn *h, int batch)
 {
     return h->deterministic ? OrderedRef{h->plan_sorted, batch} : OrderedRef{nullptr, 0};
 }
 
-static int ensure_exec(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
-                       int apply_update, int graph_steps, int batch, hipGraphExec_t *out)
+// what every train_epoch call does before its first step: scatter targets start (and, by the self-cleaning epilogues, stay)
+// zero; LDS path: sliced working copies of E0 / m / v.  Kernels, not memset nodes (see common.h rk_zero_async).
+static int launch_prologue(const rk_lightgcn_desc &d, int apply_update, hipStream_t s)
+{
+    const int N = d.n_users + d.n_items;
+    RK_HIP(rk_zero_async(d.gprop, sizeof(float) * (size_t)N * d.dim, s));
+    RK_HIP(rk_zero_async(d.gego, sizeof(float) * (size_t)N * d.dim, s));
+    if (d.row_bits && !use_lds(d)) RK_HIP(rk_zero_async(d.row_bits, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
+    if (use_lds(d)) return lds_sync(d, apply_update != 0, 1, s);
+    return RK_OK;
+}
+
+static int launch_epilogue(const rk_lightgcn_desc &d, int apply_update, hipStream_t s)
+{
+    if (use_lds(d) && apply_update) return lds_sync(d, true, 0, s);   // back to the caller's row-major tensors
+    return RK_OK;
+}
+
+// hipGraph of n_steps train steps (whole: a complete epoch call, prologue and epilogue included)
+static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update, int batch, hipStream_t upload_stream, hipGraphExec_t *out)
 {
     const rk_lightgcn_desc &d = h->d;
-    const void **cap_key = h->cap_key;
     const OrderedRef ord = ordered_ref(h, batch);
-    const bool same_key = h->exec_update == apply_update &&
-                          cap_key[0] == users && cap_key[1] == pos && cap_key[2] == neg && cap_key[3] == loss_partials &&
-                          h->cap_det == h->deterministic && (!h->deterministic || (h->cap_plan == ord.keys && h->cap_batch == batch));
-    if (!same_key) {   // everything baked into the graphs changed: drop them all
-        for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {
-            if (h->exec[i]) (void)hipGraphExecDestroy(h->exec[i]);
-            h->exec[i] = nullptr; h->exec_steps[i] = 0;
-        }
-        h->exec_update = apply_update;
-        cap_key[0] = users; cap_key[1] = pos; cap_key[2] = neg; cap_key[3] = loss_partials;
-        h->cap_det = h->deterministic; h->cap_plan = ord.keys; h->cap_batch = batch;
-    }
     int slot = -1;
     for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {
-        if (h->exec[i] && h->exec_steps[i] == graph_steps) { *out = h->exec[i]; return RK_OK; }
-        if (!h->exec[i] && slot < 0) slot = i;
+        rk_lightgcn::Exec &e = h->exec[i];
+        if (e.exec && e.n_steps == n_steps && e.whole == whole && e.update == apply_update && e.det == h->deterministic &&
+            (!h->deterministic || (e.plan == ord.keys && e.batch == batch))) {
+            e.stamp = ++h->clock;
+            *out = e.exec;
+            return RK_OK;
+        }
     }
-    if (slot < 0) {   // all slots taken by other chunk lengths (graph_steps changed between calls): recycle the last
-        slot = rk_lightgcn::kExecSlots - 1;
-        (void)hipGraphExecDestroy(h->exec[slot]);
-        h->exec[slot] = nullptr;
+    for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {   // a free slot, else the least recently used
+        if (!h->exec[i].exec) { slot = i; break; }
+        if (slot < 0 || h->exec[i].stamp < h->exec[slot].stamp) slot = i;
     }
+    rk_lightgcn::Exec &e = h->exec[slot];
+    if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
     if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t g = nullptr;
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = RK_OK;
-    for (int k = 0; k < graph_steps && rc == RK_OK; ++k)
-        rc = launch_step(d, users, pos, neg, loss_partials, k, apply_update, k == graph_steps - 1 ? graph_steps : 0, h->cap_stream, ord);
-    hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+    if (whole) rc = launch_prologue(d, apply_update, h->cap_stream);
+    for (int k = 0; k < n_steps && rc == RK_OK; ++k)
+        rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, ord);
+    if (whole && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
+    hipError_t err = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    RK_HIP(e);
-    RK_HIP(hipGraphInstantiate(&h->exec[slot], g, nullptr, nullptr, 0));
+    RK_HIP(err);
+    RK_HIP(hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    h->exec_steps[slot] = graph_steps;
-    *out = h->exec[slot];
-    return RK_OK;
-}
-
-// every chunk length an epoch can be cut into: graph_steps, then halves down to 2
-static int ensure_all_execs(rk_lightgcn *h, const int64_t *users, const int64_t *pos, const int64_t *neg, float *loss_partials,
-                            int apply_update, int graph_steps, int batch, hipStream_t upload_stream)
-{
-    int n = 0;
-    for (int c = graph_steps; c >= 2 && n < rk_lightgcn::kExecSlots; c /= 2, ++n) {
-        hipGraphExec_t ex = nullptr;
-        int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, c, batch, &ex);
-        if (rc) return rc;
-        if (upload_stream) RK_HIP(hipGraphUpload(ex, upload_stream));
-    }
+    e.n_steps = n_steps; e.whole = whole; e.update = apply_update; e.det = h->deterministic; e.plan = ord.keys; e.batch = batch;
+    e.stamp = ++h->clock;
+    if (upload_stream) RK_HIP(hipGraphUpload(e.exec, upload_stream));
+    *out = e.exec;
     return RK_OK;
 }
 
@@ -669,11 +790,14 @@ RK_EXPORT int rk_lightgcn_set_deterministic(rk_lightgcn_t h, int32_t on)
     return RK_OK;
 }
 
-RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
-                                  float *loss_partials, int32_t apply_update, int32_t graph_steps, void *stream)
+// How an epoch of n_steps is cut: n_steps <= RK_MAX_GRAPH_STEPS (and graph replay wanted): ONE whole-call graph;
+// otherwise chunks of graph_steps steps and one remainder graph.
+static bool whole_call(int n_steps, int graph_steps) { return graph_steps > 1 && n_steps >= 1 && n_steps <= RK_MAX_GRAPH_STEPS; }
+
+RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, int64_t n, int32_t batch, int32_t apply_update, int32_t graph_steps, void *stream)
 {
     if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: null handle");
-    if (!users || !pos || !neg || !loss_partials) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: bad arguments");
+    if (n <= 0 || batch <= 0) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: bad arguments");
     if (!apply_update && !h->d.grad) RK_FAIL(RK_EINVAL, "rk_lightgcn_prepare: apply_update=0 needs desc.grad");
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
     if (graph_steps <= 1) return RK_OK;
@@ -681,12 +805,20 @@ RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, const int64_t *users, const i
     hipStream_t s = (hipStream_t)stream;
     hipStream_t up = nullptr;
     if (!s) { if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)); up = h->cap_stream; } else up = s;
-    return ensure_all_execs(h, users, pos, neg, loss_partials, apply_update, graph_steps, 0, up);
+    const int n_steps = (int)std::min<long long>((n + batch - 1) / batch, 1LL << 30);
+    hipGraphExec_t ex = nullptr;
+    if (whole_call(n_steps, graph_steps)) return ensure_exec(h, n_steps, 1, apply_update, batch, up, &ex);
+    int rc = ensure_exec(h, graph_steps, 0, apply_update, batch, up, &ex);
+    if (rc) return rc;
+    const int rem = n_steps % graph_steps;
+    if (rem >= 2) rc = ensure_exec(h, rem, 0, apply_update, batch, up, &ex);
+    return rc;
 }
 
 RK_EXPORT int rk_lightgcn_propagate(rk_lightgcn_t h, void *stream)
 {
     if (!h) RK_FAIL(RK_EINVAL, "rk_lightgcn_propagate: null handle");
+    if (use_lds(h->d)) { int rc = lds_sync(h->d, false, 1, (hipStream_t)stream); if (rc) return rc; }
     return launch_forward(h->d, (hipStream_t)stream);
 }
 
@@ -708,36 +840,44 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     hipStream_t s = (hipStream_t)stream;
     const rk_lightgcn_desc &d = h->d;
     const int n_steps = (int)((n + batch - 1) / batch);
-    const int N = d.n_users + d.n_items;
-    // scatter targets start (and, by the self-cleaning epilogues, stay) zero
-    RK_HIP(hipMemsetAsync(d.gprop, 0, sizeof(float) * (size_t)N * d.dim, s));
-    RK_HIP(hipMemsetAsync(d.gego, 0, sizeof(float) * (size_t)N * d.dim, s));
-    if (d.row_bits) RK_HIP(hipMemsetAsync(d.row_bits, 0, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
-    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(1), 0, s, d.state, 0, adam_t0, (long long)n, batch);
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(1), 0, s, d.state, 0, adam_t0, (long long)n, batch, users, pos, neg, loss_partials);
     RK_CHECK_LAUNCH();
-
     if (h->deterministic) {
         int rc = build_plan(h, users, pos, neg, n, batch, s);
         if (rc) return rc;
     }
-    int done = 0;
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
-    if (graph_steps > 1 && n_steps >= 2) {
-        int slots = 0;
-        for (int c = graph_steps; c >= 2 && slots < rk_lightgcn::kExecSlots; c /= 2, ++slots) {
-            if (done + c > n_steps) continue;
-            hipGraphExec_t ex = nullptr;
-            int rc = ensure_exec(h, users, pos, neg, loss_partials, apply_update, c, batch, &ex);
+    if (whole_call(n_steps, graph_steps)) {   // the whole call is one replay
+        hipGraphExec_t ex = nullptr;
+        int rc = ensure_exec(h, n_steps, 1, apply_update, batch, nullptr, &ex);
+        if (rc) return rc;
+        RK_HIP(hipGraphLaunch(ex, s));
+        return RK_OK;
+    }
+    int rc = launch_prologue(d, apply_update, s);
+    if (rc) return rc;
+    int done = 0;
+    if (graph_steps > 1) {
+        hipGraphExec_t ex = nullptr;
+        if (n_steps >= graph_steps) {
+            rc = ensure_exec(h, graph_steps, 0, apply_update, batch, nullptr, &ex);
             if (rc) return rc;
-            for (; done + c <= n_steps; done += c) RK_HIP(hipGraphLaunch(ex, s));
+            for (; done + graph_steps <= n_steps; done += graph_steps) RK_HIP(hipGraphLaunch(ex, s));
+        }
+        const int rem = n_steps - done;
+        if (rem >= 2) {
+            rc = ensure_exec(h, rem, 0, apply_update, batch, nullptr, &ex);
+            if (rc) return rc;
+            RK_HIP(hipGraphLaunch(ex, s));
+            done += rem;
         }
     }
     const OrderedRef ord = ordered_ref(h, batch);
     for (; done < n_steps; ++done) {
-        int rc = launch_step(d, users, pos, neg, loss_partials, 0, apply_update, 1, s, ord);
+        rc = launch_step(d, 0, apply_update, 1, s, ord);
         if (rc) return rc;
     }
-    return RK_OK;
+    return launch_epilogue(d, apply_update, s);
 }
 
 

@@ -56,7 +56,6 @@ struct SpmmArgs {
     unsigned *mark_bits;         // set the bits of the current minibatch (first forward layer)
     unsigned *clear_bits;        // zero the bitmap (last backward layer)
     int n_words, mark_U, mark_k;
-    const int64_t *mark_users, *mark_pos, *mark_neg;
     const int *mark_state;
     // Graph dropout of a training forward/backward (lightgcn.py:62-80): drop_thresh24 = keep_prob * 2^24
     // (0 = off); every stored entry e is kept iff rk_drop_keep(seed_step, id, thresh) and scaled by
@@ -315,8 +314,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         const int B = a.mark_state[ST_BATCH];
         const long long off = (long long)step * B;
         const int nb = (int)max(0LL, min((long long)B, ntrip - off));
+        const int64_t *mu = st_ptr<const int64_t>(a.mark_state, ST_PTR_USERS), *mp = st_ptr<const int64_t>(a.mark_state, ST_PTR_POS),
+                      *mn = st_ptr<const int64_t>(a.mark_state, ST_PTR_NEG);
         for (int b = blockIdx.x * (WAVES * 64) + threadIdx.x; b < nb; b += gridDim.x * WAVES * 64) {
-            const int r0 = (int)a.mark_users[off + b], r1 = a.mark_U + (int)a.mark_pos[off + b], r2 = a.mark_U + (int)a.mark_neg[off + b];
+            const int r0 = (int)mu[off + b], r1 = a.mark_U + (int)mp[off + b], r2 = a.mark_U + (int)mn[off + b];
             atomicOr(&a.mark_bits[r0 >> 5], 1u << (r0 & 31));
             atomicOr(&a.mark_bits[r1 >> 5], 1u << (r1 & 31));
             atomicOr(&a.mark_bits[r2 >> 5], 1u << (r2 & 31));

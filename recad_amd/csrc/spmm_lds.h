@@ -1,0 +1,361 @@
+// LDS-resident, d-sliced SpMM for bipartite D^-1/2 A D^-1/2 graphs whose class tables fit a CU's LDS
+// (ml1m / Amazon-game sized).  Replaces torch.sparse.mm at recad/model/victim/lightgcn.py:107 (and its
+// autograd twin) on the graphs where spmm.h's row-gather kernel sits at the L2 gather rate.
+//
+// Idea: Y[:, s] = A . X[:, s] for every column slice s independently.  A workgroup owns
+// (class half, slice s of S floats, contiguous block of output rows); it stages the WHOLE source-class
+// slice -- n_src x S floats, pre-multiplied by D^-1/2 of the source rows -- into LDS once (coalesced), then
+// every nonzero is one ds_read_b128 instead of a 256-byte row gather from L2, and the sum is multiplied by
+// D^-1/2 of the output row:  y[r] = dinv[r] * sum_c (dinv[c] * x[c])  (A is binary, implicit.py:259-277:
+// val = dinv[r]*dinv[c]; the factored form differs from the stored-value form by rounding only, ~1e-7 rel).
+// The matrix therefore shrinks to a 16-bit column stream, laid out SELL-style in the order the lanes consume
+// it: rows are cut into chunks of <= C nonzeros, chunks sorted by length, 64/LP chunks form a task that one
+// wave walks (LP = S/4 lanes per entry, 8 entries per 16-byte stream load); waves pop tasks longest-first
+// from an LDS counter; chunk partial sums meet in LDS and a second phase adds each row's chunks in CSR order
+// and runs the fused epilogue (spmm.h's, plus layouts).  Every sum has a fixed order => bit-reproducible.
+//
+// Buffers that are gathered (E_l, the backward's t_l, gprop) live in a SLICED layout: per class block,
+// [d/Sc][n_c][Sc] floats (Sc = slice width used when THAT class is the source), so a slice table is one
+// contiguous run.  E0 / m / v / light stay row-major (they are the caller's tensors).
+#pragma once
+#include "common.h"
+
+struct LdsDims {
+    int U, I, d;
+    int lsu, lsi;  // log2 of the users / items block slice width (floats)
+};
+// float offset of element (node r, column k) of a sliced [U+I, d] buffer
+__host__ __device__ __forceinline__ size_t sl_off(const LdsDims &g, int r, int k)
+{
+    if (r < g.U) return ((((size_t)(k >> g.lsu)) * (size_t)g.U + (size_t)r) << g.lsu) + (size_t)(k & ((1 << g.lsu) - 1));
+    return (size_t)g.U * (size_t)g.d + ((((size_t)(k >> g.lsi)) * (size_t)g.I + (size_t)(r - g.U)) << g.lsi) + (size_t)(k & ((1 << g.lsi) - 1));
+}
+
+// plan buffer (device int32 words), header words
+enum {
+    LP_MAGIC = 0, LP_NWG, LP_U, LP_I, LP_D, LP_LSU, LP_LSI, LP_NBLK0, LP_NBLK1, LP_WG_OFS, LP_BLK_OFS, LP_DINV_OFS,
+    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_HDR_WORDS = 32
+};
+static constexpr int kLdsMagic = 0x4c445331;  // "LDS1"
+// block descriptor words (one per (half, row block), shared by all slices)
+enum { LB_ROW0 = 0, LB_NROWS, LB_NPART, LB_NTASKS, LB_TASK_OFS, LB_DST_OFS, LB_PP_OFS, LB_STREAM_OFS, LB_WORDS = 8 };
+static constexpr int kLdsThreads = 1024;
+static constexpr int kLdsMaxBytes = 160 * 1024;
+
+struct LdsEpi {
+    // v = dinv[r] * acc (+ add[r])          add: sliced
+    const float *add;
+    float *y;            // nullable; sliced unless y_rm
+    const float *sum_in; // sliced
+    float *sum_out;      // sliced unless sum_rm:  sum_out[r] = (sum_in[r] + v) * sum_scale
+    float sum_scale;
+    int y_rm, sum_rm;
+    float *zero1, *zero2;  // sliced, nullable: set to 0 after the addend was read
+    int adam;              // Adam on p/m/v with gradient v (sliced, or row-major when adam_rm); shadow (sliced, nullable)
+    int adam_rm;           // receives the new p
+    float *p, *m, *v, *shadow;
+    const float *coef;
+    float b1, b2, eps;
+    int *state;
+    int bump;
+    unsigned long long *stamps;  // diagnostic, nullable: 4 wall-clock stamps per workgroup (start, staged, gathered, done)
+};
+
+struct LdsArgs {
+    const int *plan;
+    const float *x;  // sliced [N, d]
+    LdsEpi e;
+};
+
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4_plus(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
+// the row's sum is ready
+// LDS (address space 3) pointer to a float4: lets an absolute LDS byte address be dereferenced without a base add
+typedef float lds_f4n __attribute__((ext_vector_type(4)));
+typedef const lds_f4n __attribute__((address_space(3))) *lds_f4_ptr;
+
+struct LdsRowOps {
+    int p0, p1;
+    float dr;
+    float4 addv, sumv;
+    size_t so, ro;
+};
+
+template <int LP>
+__device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds)
+{
+    constexpr int SL = 64 / LP, S = 4 * LP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane / LP, pj = lane % LP;
+    const int U = plan[LP_U], I = plan[LP_I], d = plan[LP_D];
+    const int n_src = half ? U : I, n_dst = half ? I : U;
+    const int *bd = plan + plan[LP_BLK_OFS] + ((half ? plan[LP_NBLK0] : 0) + rb) * LB_WORDS;
+    const float *dinv = reinterpret_cast<const float *>(plan + plan[LP_DINV_OFS]);
+    const float *dsrc = dinv + (half ? 0 : U), *ddst = dinv + (half ? U : 0);
+    // the source class's slice table: n_src * S contiguous floats
+    const float4 *s4 = reinterpret_cast<const float4 *>(a.x + (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S);
+    const int n4 = n_src * LP;
+    const int n_tasks = bd[LB_NTASKS];
+    const int2 *tasks = reinterpret_cast<const int2 *>(plan + bd[LB_TASK_OFS]);
+    const int *dstv = plan + bd[LB_DST_OFS];
+    const uint4 *stream = reinterpret_cast<const uint4 *>(plan) + bd[LB_STREAM_OFS];
+    const int n_rows = bd[LB_NROWS], row0 = bd[LB_ROW0];
+    const int *pp = plan + bd[LB_PP_OFS];
+    const LdsEpi &e = a.e;
+    const int lso = half ? plan[LP_LSI] : plan[LP_LSU];  // slice width (log2) of the OUTPUT class's block
+    const size_t cls_base = half ? (size_t)U * d : 0;
+    const int node0 = half ? U : 0;
+    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 0] = wall_clock64();
+    // LDS layout: [slice table][16 / LP zero rows, one per bank class][chunk partials][task descriptors (int2)][queue head]
+    // (the table sits at LDS address 0, so an entry's address is its stream word shifted)
+    float4 *tab = lds;
+    float4 *part = tab + n4 + 16;
+    int2 *ltask = reinterpret_cast<int2 *>(part + bd[LB_NPART] * LP);
+    int *qhead = reinterpret_cast<int *>(ltask + n_tasks);
+    if (tid == 0) *qhead = 0;
+    for (int t = tid; t < n_tasks; t += kLdsThreads) ltask[t] = tasks[t];
+    auto row_ops = [&](int i) {
+        LdsRowOps o;
+        const int lr = i / LP, j = i % LP;
+        const int r = row0 + lr;            // class-local output row
+        const int k0 = slice * S + 4 * j;   // first of this thread's four columns
+        o.so = cls_base + ((((size_t)(k0 >> lso)) * (size_t)n_dst + (size_t)r) << lso) + (size_t)(k0 & ((1 << lso) - 1));
+        o.ro = (size_t)(node0 + r) * d + k0;
+        o.p0 = pp[lr]; o.p1 = pp[lr + 1];
+        o.dr = ddst[r];
+        o.addv = make_float4(0.f, 0.f, 0.f, 0.f); o.sumv = o.addv;
+        if (e.add) o.addv = *reinterpret_cast<const float4 *>(e.add + o.so);
+        if (e.sum_out) o.sumv = *reinterpret_cast<const float4 *>(e.sum_in + o.so);
+        return o;
+    };
+    // this thread's first epilogue row: its operand loads fly under the staging and the gather
+    LdsRowOps ops0{};
+    if (tid < n_rows * LP) ops0 = row_ops(tid);
+    // ---- phase 1: stage the slice table, pre-scaled by dinv of the source rows
+    constexpr int UN = 8;
+    for (int i0 = tid; i0 < n4; i0 += kLdsThreads * UN) {
+        float4 v[UN];
+        float s[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * kLdsThreads;
+            if (i < n4) { v[u] = s4[i]; s[u] = dsrc[i / LP]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * kLdsThreads;
+            if (i < n4) tab[i] = f4_scale(v[u], s[u]);
+        }
+    }
+    if (tid < 16) tab[n4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding entries' rows
+    __syncthreads();
+    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 1] = wall_clock64();
+    // ---- phase 2: tasks, longest first, popped from an LDS counter; the next task's descriptor, destination and
+    // first stream block are requested while the current one is walked
+    auto pop = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(qhead, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    // byte address of the table row named by the low / high 16 bits of a stream word.  LP == 1: the table sits at LDS
+    // address 0 and a row is 16 bytes, so the address is the word's half shifted by 4 -- ONE VALU instruction with SDWA
+    // operand selection (the compiler emits v_and / v_bfe + v_lshl_add: the gather loop is VALU-bound, SQ_INSTS_VALU,
+    // and the address arithmetic was half of it).
+    auto row_lo = [&](unsigned w) -> lds_f4_ptr {
+        if (LP == 1) {
+            unsigned r;
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(4u), "v"(w));
+            return (lds_f4_ptr)r;
+        }
+        return (lds_f4_ptr)(tab + (w & 0xffffu) * LP + pj);
+    };
+    auto row_hi = [&](unsigned w) -> lds_f4_ptr {
+        if (LP == 1) {
+            unsigned r;
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(4u), "v"(w));
+            return (lds_f4_ptr)r;
+        }
+        return (lds_f4_ptr)(tab + (w >> 16) * LP + pj);
+    };
+    auto read8 = [&](float4 (&xv)[8], uint4 c) {
+        const unsigned wv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const lds_f4n lo = *row_lo(wv[k]), hi = *row_hi(wv[k]);
+            xv[2 * k] = make_float4(lo.x, lo.y, lo.z, lo.w);
+            xv[2 * k + 1] = make_float4(hi.x, hi.y, hi.z, hi.w);
+        }
+    };
+    auto add8 = [&](float4 acc, const float4 (&xv)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = f4_plus(acc, xv[k]);
+        return acc;
+    };
+    int t = pop();
+    int2 tk = make_int2(0, 0);
+    int my_dst = -1;
+    const uint4 *st = stream;
+    uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
+    if (t < n_tasks) {
+        tk = ltask[t];
+        st = stream + tk.x + q;
+        my_dst = dstv[t * SL + q];
+        c0 = st[0];
+        if (tk.y > 1) c1 = st[SL];
+    }
+    while (t < n_tasks) {
+        const int tn = pop();
+        int2 tkn = make_int2(0, 0);
+        int dstn = -1;
+        const uint4 *stn = stream;
+        uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
+        if (tn < n_tasks) {
+            tkn = ltask[tn];
+            stn = stream + tkn.x + q;
+            dstn = dstv[tn * SL + q];
+            n0 = stn[0];
+            if (tkn.y > 1) n1 = stn[SL];
+        }
+        // Two 8-entry blocks per round: all sixteen table reads are issued before the first add, so a wave keeps the LDS
+        // pipe fed while it adds (with one block per round LDS-array and VALU time of the sixteen waves added up: the
+        // array was busy 55 % of the gather phase).  The stream words of the next round are already in flight.
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int b = 0;
+        for (; b + 2 <= tk.y; b += 2) {
+            uint4 d0 = c0, d1 = c1;
+            if (b + 2 < tk.y) d0 = st[(size_t)(b + 2) * SL];
+            if (b + 3 < tk.y) d1 = st[(size_t)(b + 3) * SL];
+            float4 xa[8], xb[8];
+            read8(xa, c0);
+            read8(xb, c1);
+            acc = add8(acc, xa);
+            acc = add8(acc, xb);
+            c0 = d0; c1 = d1;
+        }
+        if (b < tk.y) {
+            float4 xa[8];
+            read8(xa, c0);
+            acc = add8(acc, xa);
+        }
+        if (my_dst >= 0) part[my_dst * LP + pj] = acc;
+        t = tn; tk = tkn; st = stn; my_dst = dstn; c0 = n0; c1 = n1;
+    }
+    __syncthreads();
+    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    // ---- phase 3: per output row, chunk partials in CSR order, dinv of the row, fused epilogue
+    for (int i = tid; i < n_rows * LP; i += kLdsThreads) {
+        const int j = i % LP;
+        const LdsRowOps o = (i == tid) ? ops0 : row_ops(i);
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), mw = pw, vw = pw;
+        if (e.adam) {   // (requested here, not before the gather: twelve registers the gather loop needs)
+            const size_t ao = e.adam_rm ? o.ro : o.so;
+            pw = *reinterpret_cast<const float4 *>(e.p + ao);
+            mw = *reinterpret_cast<const float4 *>(e.m + ao);
+            vw = *reinterpret_cast<const float4 *>(e.v + ao);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = o.p0;
+        for (; p + 8 <= o.p1; p += 8) {   // long rows: eight partials in flight, added in chunk order
+            float4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = part[(p + k) * LP + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = f4_plus(acc, t[k]);
+        }
+        for (; p < o.p1; ++p) acc = f4_plus(acc, part[p * LP + j]);
+        float4 v = f4_scale(acc, o.dr);
+        if (e.add) v = f4_plus(v, o.addv);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e.zero1) *reinterpret_cast<float4 *>(e.zero1 + o.so) = z;
+        if (e.zero2) *reinterpret_cast<float4 *>(e.zero2 + o.so) = z;
+        if (e.y) *reinterpret_cast<float4 *>(e.y + (e.y_rm ? o.ro : o.so)) = v;
+        if (e.sum_out) *reinterpret_cast<float4 *>(e.sum_out + (e.sum_rm ? o.ro : o.so)) = f4_scale(f4_plus(o.sumv, v), e.sum_scale);
+        if (e.adam) {
+            const float step_size = e.coef[0], bc2s = e.coef[1];
+            const float w1 = (float)(1.0 - (double)e.b1), w2 = (float)(1.0 - (double)e.b2);
+            adam_elem(pw.x, mw.x, vw.x, v.x, w1, e.b2, w2, step_size, bc2s, e.eps);
+            adam_elem(pw.y, mw.y, vw.y, v.y, w1, e.b2, w2, step_size, bc2s, e.eps);
+            adam_elem(pw.z, mw.z, vw.z, v.z, w1, e.b2, w2, step_size, bc2s, e.eps);
+            adam_elem(pw.w, mw.w, vw.w, v.w, w1, e.b2, w2, step_size, bc2s, e.eps);
+            const size_t ao = e.adam_rm ? o.ro : o.so;
+            *reinterpret_cast<float4 *>(e.p + ao) = pw;
+            *reinterpret_cast<float4 *>(e.m + ao) = mw;
+            *reinterpret_cast<float4 *>(e.v + ao) = vw;
+            if (e.shadow) *reinterpret_cast<float4 *>(e.shadow + o.so) = pw;
+        }
+    }
+    if (e.stamps) {
+        __syncthreads();
+        if (tid == 0) e.stamps[blockIdx.x * 4 + 3] = wall_clock64();
+    }
+}
+
+// LPA / LPB: lanes per entry (= slice width / 4) of the user-row half (gathers the items table) and of the
+// item-row half (gathers the users table)
+template <int LPA, int LPB>
+__global__ __launch_bounds__(kLdsThreads) void spmm_lds_kernel(const LdsArgs a)
+{
+    extern __shared__ float4 lds_dyn[];
+    const int *__restrict__ plan = a.plan;
+    if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.e.state[ST_STEP_BASE] += a.e.bump;
+        a.e.state[ST_ADAM_T] += a.e.bump;
+    }
+    const int4 wg = reinterpret_cast<const int4 *>(plan + plan[LP_WG_OFS])[blockIdx.x];  // {half, slice, row block, 0}
+    if (wg.x == 0) lds_body<LPA>(a, plan, 0, wg.y, wg.z, lds_dyn);
+    else lds_body<LPB>(a, plan, 1, wg.y, wg.z, lds_dyn);
+}
+
+// row-major [N, d] <-> sliced; one float4 per thread
+struct LdsPackJob {
+    float *rm[3], *sl[3];   // up to three (row-major, sliced) pairs converted by one launch
+    int n;
+};
+static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
+{
+    const int d4 = g.d / 4;
+    const long long n = (long long)(g.U + g.I) * d4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d4), k = (int)(i % d4) * 4;
+        const size_t so = sl_off(g, r, k), ro = (size_t)r * g.d + k;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q >= job.n) break;
+            if (to_sliced) *reinterpret_cast<float4 *>(job.sl[q] + so) = *reinterpret_cast<const float4 *>(job.rm[q] + ro);
+            else *reinterpret_cast<float4 *>(job.rm[q] + ro) = *reinterpret_cast<const float4 *>(job.sl[q] + so);
+        }
+    }
+}
+
+// Host-side description of an uploaded plan (what the launch needs without reading the device buffer)
+struct LdsInfo {
+    int n_wg, lds_bytes, lpa, lpb, U, I, d, lsu, lsi;
+};
+
+inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStream_t s)
+{
+    const dim3 grid(info.n_wg), block(kLdsThreads);
+#define RK_LDS_CASE(A, B)                                                                                                  \
+    do {                                                                                                                    \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>),                      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes - 64);             \
+            if (e_ != hipSuccess) return e_;                                                                                \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((spmm_lds_kernel<A, B>), grid, block, (size_t)info.lds_bytes, s, a);                              \
+    } while (0)
+    if (info.lpa == 2 && info.lpb == 1) RK_LDS_CASE(2, 1);
+    else if (info.lpa == 1 && info.lpb == 2) RK_LDS_CASE(1, 2);
+    else if (info.lpa == 1 && info.lpb == 1) RK_LDS_CASE(1, 1);
+    else if (info.lpa == 2 && info.lpb == 2) RK_LDS_CASE(2, 2);
+    else if (info.lpa == 4 && info.lpb == 4) RK_LDS_CASE(4, 4);
+    else if (info.lpa == 4 && info.lpb == 2) RK_LDS_CASE(4, 2);
+    else if (info.lpa == 2 && info.lpb == 4) RK_LDS_CASE(2, 4);
+    else return hipErrorInvalidValue;
+#undef RK_LDS_CASE
+    return hipGetLastError();
+}

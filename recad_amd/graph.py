@@ -31,6 +31,50 @@ class CsrGraph:
         words = self._sched[dim][2]
         return torch.zeros(words, device=self.device, dtype=torch.int32) if words else None
 
+    def lds_plan(self, dim):
+        """(plan int32 device tensor, _lib.LdsInfo) of the LDS-resident sliced SpMM (rk_lds_plan_*) for this dim, or None
+        when the graph does not qualify (not the bipartite normalised binary adjacency, or a class table does not fit a
+        CU's LDS).  Cached, read-only, shareable."""
+        if not self.class_split:
+            return None
+        cache = self.__dict__.setdefault("_lds", {})
+        if dim not in cache:
+            plan, n_words, info = C.c_void_p(), C.c_int64(0), _lib.LdsInfo()
+            _lib.check(_lib.lib().rk_lds_plan_build(self.class_split, self.n_rows - self.class_split, _lib.ptr(self.rowptr),
+                                                    _lib.ptr(self.col), _lib.ptr(self.val), dim, _lib.stream_ptr(), C.byref(plan),
+                                                    C.byref(n_words), C.byref(info)), "rk_lds_plan_build")
+            if n_words.value == 0:
+                cache[dim] = None
+            else:
+                try:
+                    buf = torch.zeros(int(n_words.value) + 4, device=self.device, dtype=torch.int32)
+                    buf = buf[((-buf.data_ptr() // 4) % 4):][: int(n_words.value)]   # 16-byte aligned view
+                    _lib.check(_lib.lib().rk_lds_plan_upload(plan, _lib.ptr(buf), _lib.stream_ptr()), "rk_lds_plan_upload")
+                finally:
+                    _lib.lib().rk_lds_plan_destroy(plan)
+                cache[dim] = (buf, info)
+        return cache[dim]
+
+    def spmm_lds(self, x, add=None):
+        """y = A.x (+ add) through the LDS-resident kernel (row-major in and out: packs / unpacks around it)."""
+        got = self.lds_plan(x.shape[1])
+        if got is None:
+            raise _lib.HipCallError("this graph has no LDS plan")
+        plan, info = got
+        x = x.contiguous()
+        xs, ys = torch.empty_like(x), torch.empty_like(x)
+        L = _lib.lib()
+        _lib.check(L.rk_lds_pack(C.byref(info), _lib.ptr(x), _lib.ptr(xs), 1, 0, _lib.stream_ptr()), "rk_lds_pack")
+        adds = None
+        if add is not None:
+            adds = torch.empty_like(x)
+            _lib.check(L.rk_lds_pack(C.byref(info), _lib.ptr(add.contiguous()), _lib.ptr(adds), 1, 0, _lib.stream_ptr()), "rk_lds_pack")
+        epi = _lib.LdsEpilogue(add=_lib.ptr(adds), y=_lib.ptr(ys), sum_scale=1.0)
+        _lib.check(L.rk_spmm_lds(C.byref(info), _lib.ptr(plan), _lib.ptr(xs), C.byref(epi), _lib.stream_ptr()), "rk_spmm_lds")
+        y = torch.empty_like(x)
+        _lib.check(L.rk_lds_unpack(C.byref(info), _lib.ptr(ys), _lib.ptr(y), 1, 0, _lib.stream_ptr()), "rk_lds_unpack")
+        return y
+
     def transpose_index(self):
         """tpos[e] = position of the transposed entry (col[e], row(e)) in this CSR (int32 device tensor, cached).
         The adjacency is structurally symmetric and sorted by (row, col), so listing the entries in

@@ -5,6 +5,7 @@ orchestration only: parameter ownership (nn.Embedding, so .to()/state_dict() beh
 the reference), the optimizer object, and the C-ABI handle.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -58,9 +59,11 @@ class LightGCN(BaseVictim):
         self._handle = None
         self._handle_key = None
         self._ws = None
-        self.graph_steps = 8  # steps per hipGraph replay; 0/1 = plain launches
+        self.graph_steps = 32  # steps per hipGraph replay of a long epoch (<= 64-step epochs are one replay); 0/1 = plain launches
         # last forward layer only on the minibatch's rows (-4 us of 18 on ml1m)
         self.use_batch_sparsity = True
+        # LDS-resident sliced SpMM on graphs that qualify (csrc/spmm_lds.h)
+        self.use_lds = True
         # ordered (bit-reproducible) gradient scatter instead of float atomics: one more launch per step and a sort of
         # the epoch's triplets (rk_lightgcn_set_deterministic); not a reference option (its CUDA path is atomic too)
         self.deterministic = bool(config.get("deterministic", False))
@@ -125,7 +128,7 @@ class LightGCN(BaseVictim):
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
-               bool(self.deterministic))
+               bool(self.deterministic), bool(self.use_lds))
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -141,6 +144,15 @@ class LightGCN(BaseVictim):
             self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ws["tpos"] = g.transpose_index() if self.graph_dropout else None
         ws["spmm_scratch"] = g.new_scratch(d)  # this handle's own long-row counters / partial slots
+        # LDS-resident sliced propagation (csrc/spmm_lds.h) when the graph qualifies: bipartite normalised binary adjacency
+        # whose class tables fit a CU's LDS (ml1m / Amazon-game size); RK_LDS_OFF=1 keeps the row-gather kernel (A/B)
+        lds = None
+        if self.use_lds and self.n_layers >= 1 and not self.graph_dropout and not os.environ.get("RK_LDS_OFF"):
+            lds = g.lds_plan(d)
+        ws["lds"] = lds
+        ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
+        for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
+            ws[k] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         desc = _lib.LightGCNDesc(
             n_users=self.num_users, n_items=self.num_items, dim=d, n_layers=self.n_layers,
             lam=float(self.config["lambda"]), lr=float(grp["lr"]), beta1=float(betas[0]), beta2=float(betas[1]),
@@ -156,7 +168,9 @@ class LightGCN(BaseVictim):
             spmm_scratch=_lib.ptr(ws["spmm_scratch"]),
             row_bits=_lib.ptr(ws["row_bits"]),
             keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
-            drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]))
+            drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]),
+            lds_plan=_lib.ptr(lds[0]) if lds else None, lds_info=lds[1] if lds else _lib.LdsInfo(),
+            lsum=_lib.ptr(ws["lsum"]), e0s=_lib.ptr(ws["e0s"]), ms=_lib.ptr(ws["ms"]), vs=_lib.ptr(ws["vs"]))
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         if self.deterministic:
@@ -214,45 +228,39 @@ class LightGCN(BaseVictim):
         return (all_users[users], all_items[pos_items], all_items[neg_items], self.embedding_user(users),
                 self.embedding_item(pos_items), self.embedding_item(neg_items))
 
-    def _staging(self, n, batch, device):
-        """Stable staging buffers: the hipGraph bakes the triplet / loss pointers in, so copying each
-        epoch's indices into the same allocations lets one captured graph serve every epoch."""
-        st = self._ws.get("staging")
+    def _loss_buffer(self, n, batch, device):
+        """Per-step loss partials of an epoch.  (The triplet tensors are handed to the library as they are: their pointers
+        reach the kernels through the device state block, so the captured hipGraphs do not depend on them.)"""
         n_steps = (n + batch - 1) // batch
-        if (st is None or st["idx"].shape[1] < n or st["loss"].numel() < (n_steps + 1) * _lib.RK_LOSS_PARTIALS
-                or st["idx"].device != device):
-            cap = max(n, int(1.25 * n) if st is not None else n)
-            st = {"idx": torch.empty(3, cap, device=device, dtype=torch.int64),
-                  "loss": torch.empty(((cap + batch - 1) // batch + 1) * _lib.RK_LOSS_PARTIALS, device=device, dtype=torch.float32)}
-            self._ws["staging"] = st
-        return st
+        buf = self._ws.get("loss")
+        if buf is None or buf.numel() < n_steps * _lib.RK_LOSS_PARTIALS or buf.device != device:
+            buf = torch.empty(max(n_steps, int(1.25 * n_steps) if buf is not None else n_steps) * _lib.RK_LOSS_PARTIALS,
+                              device=device, dtype=torch.float32)
+            self._ws["loss"] = buf
+        return buf
 
     def reserve(self, n_triplets, batch, want_grad=False):
-        """Size the staging buffers for epochs of up to n_triplets and capture + upload the train-step
-        hipGraph now, so that no later epoch (or timed region) pays for either."""
+        """Capture + upload the hipGraphs an epoch of n_triplets will replay now, so that no later epoch (or timed region)
+        pays for it."""
         h = self._ensure_handle(want_grad=want_grad)
-        st = self._staging(int(n_triplets), int(batch), self.embedding_user.weight.device)
+        self._loss_buffer(int(n_triplets), int(batch), self.embedding_user.weight.device)
         if self._fused_adam and int(self.graph_steps) > 1 and not self.deterministic:   # (deterministic: the graph follows the epoch's plan)
-            _lib.check(_lib.lib().rk_lightgcn_prepare(
-                h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), _lib.ptr(st["loss"]), 1,
-                int(self.graph_steps), _lib.stream_ptr()), "rk_lightgcn_prepare")
-        return st
+            _lib.check(_lib.lib().rk_lightgcn_prepare(h, int(n_triplets), int(batch), 1, int(self.graph_steps), _lib.stream_ptr()),
+                       "rk_lightgcn_prepare")
 
     def _run_epoch(self, users, pos, neg, batch, apply_update=True, want_grad=False):
         h = self._ensure_handle(want_grad=want_grad)
         n = users.numel()
         n_steps = (n + batch - 1) // batch
-        st = self._staging(n, batch, users.device)
-        st["idx"][0, :n].copy_(users)
-        st["idx"][1, :n].copy_(pos)
-        st["idx"][2, :n].copy_(neg)
-        loss_partials = st["loss"]
+        users, pos, neg = (t.contiguous() for t in (users, pos, neg))
+        loss_partials = self._loss_buffer(n, batch, users.device)
         su = self._adam_state(self.embedding_user.weight)
         t0 = int(su["step"].item()) if apply_update else 0
         _lib.check(_lib.lib().rk_lightgcn_train_epoch(
-            h, _lib.ptr(st["idx"][0]), _lib.ptr(st["idx"][1]), _lib.ptr(st["idx"][2]), n, batch, t0, _lib.ptr(loss_partials),
+            h, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch, t0, _lib.ptr(loss_partials),
             1 if apply_update else 0, int(self.graph_steps) if apply_update else 0, _lib.stream_ptr()),
             "rk_lightgcn_train_epoch")
+        self._ws["epoch_inputs"] = (users, pos, neg)   # alive until the next call: the stream may still be reading them
         if apply_update:
             for p in (self.embedding_user.weight, self.embedding_item.weight):
                 self.optimizer.state[p]["step"] += n_steps

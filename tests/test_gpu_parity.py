@@ -46,36 +46,149 @@ def test_spmm_matches_oracle(gpu_device, d):
     assert np.array_equal(y2, y3), "SpMM must be bit-reproducible run to run"
 
 
+def _bipartite_csr(shape):
+    """rowptr / col / val (val = dinv[r]*dinv[c] in float32, implicit.py:259-277) of a synthetic bipartite adjacency."""
+    from recad_amd import synth
+    from tests.test_lds_plan_cpu import norm_adj_csr
+    data = synth.make(shape)
+    U, I = data["n_users"], data["n_items"]
+    return (U, I) + norm_adj_csr(U, I, *data["train"]) + (data["train"],)
+
+
+@pytest.mark.parametrize("shape,d", [("tiny", 64), ("tiny", 32), ("tiny", 128), ("tiny", 256), ("ml1m", 64)])
+def test_spmm_lds_matches_oracle(gpu_device, shape, d):
+    """The LDS-resident sliced SpMM (rk_spmm_lds) through pack / unpack against the oracle's CSR product with the stored
+    values, every epilogue of the train step (addend, running sum with a row-major output, zeroing, Adam), and
+    bit-reproducibility (fixed summation order)."""
+    import ctypes as C
+    from recad_amd import _lib
+    from recad_amd.graph import CsrGraph
+    U, I, rowptr, col, val, train = _bipartite_csr(shape)
+    N = U + I
+    g = CsrGraph.from_user_item_csr(U, I, train[0], train[1], gpu_device)
+    got = g.lds_plan(d)
+    assert got is not None
+    plan, info = got
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((N, d), dtype=np.float32)
+    add = rng.standard_normal((N, d), dtype=np.float32)
+    xt, at = torch.from_numpy(x).to(gpu_device), torch.from_numpy(add).to(gpu_device)
+    ref = orc.spmm(rowptr, col, val, x)
+    y = g.spmm_lds(xt, at).cpu().numpy()
+    assert G.relerr(y, ref + add) < 2e-6
+    assert np.array_equal(g.spmm_lds(xt).cpu().numpy(), g.spmm_lds(xt).cpu().numpy()), "must be bit-reproducible run to run"
+    assert G.relerr(g.spmm_lds(xt).cpu().numpy(), g.spmm(xt).cpu().numpy()) < 2e-6     # the two kernels agree
+    # all epilogues at once
+    L = _lib.lib()
+
+    def packed(t):
+        out = torch.empty_like(t)
+        _lib.check(L.rk_lds_pack(C.byref(info), _lib.ptr(t), _lib.ptr(out), 1, 0, _lib.stream_ptr()), "rk_lds_pack")
+        return out
+
+    def unpacked(t):
+        out = torch.empty_like(t)
+        _lib.check(L.rk_lds_unpack(C.byref(info), _lib.ptr(t), _lib.ptr(out), 1, 0, _lib.stream_ptr()), "rk_lds_unpack")
+        return out
+
+    assert torch.equal(unpacked(packed(xt)), xt)
+    s_in = rng.standard_normal((N, d), dtype=np.float32)
+    p0 = rng.standard_normal((N, d), dtype=np.float32)
+    m0 = (0.01 * rng.standard_normal((N, d))).astype(np.float32)
+    v0 = (0.001 * rng.random((N, d))).astype(np.float32)
+    xs, adds, sins = packed(xt), packed(at), packed(torch.from_numpy(s_in).to(gpu_device))
+    z1, z2 = torch.ones(N, d, device=gpu_device), torch.ones(N, d, device=gpu_device)
+    ys, sum_rm = torch.empty(N, d, device=gpu_device), torch.empty(N, d, device=gpu_device)
+    pt, mt, vt = (torch.from_numpy(a).to(gpu_device).clone() for a in (p0, m0, v0))
+    shadow = torch.empty(N, d, device=gpu_device)
+    coef = torch.zeros(2, device=gpu_device)
+    epi = _lib.LdsEpilogue(add=_lib.ptr(adds), y=_lib.ptr(ys), sum_in=_lib.ptr(sins), sum_out=_lib.ptr(sum_rm), sum_scale=0.25,
+                           y_row_major=0, sum_out_row_major=1, adam_t=3, zero1=_lib.ptr(z1), zero2=_lib.ptr(z2),
+                           adam_p=_lib.ptr(pt), adam_m=_lib.ptr(mt), adam_v=_lib.ptr(vt), adam_shadow=_lib.ptr(shadow),
+                           coef_scratch=_lib.ptr(coef), lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)
+    _lib.check(L.rk_spmm_lds(C.byref(info), _lib.ptr(plan), _lib.ptr(xs), C.byref(epi), _lib.stream_ptr()), "rk_spmm_lds")
+    v = y                                            # A.x + add from the first call
+    assert np.array_equal(unpacked(ys).cpu().numpy(), v)
+    assert G.relerr(sum_rm.cpu().numpy(), (s_in + v) * np.float32(0.25)) < 1e-6
+    assert float(z1.abs().max()) == 0.0 and float(z2.abs().max()) == 0.0
+    pr, mr, vr = p0.copy(), m0.copy(), v0.copy()
+    orc.adam(pr, v, mr, vr, 3)
+    assert G.relerr(pt.cpu().numpy(), pr) < 1e-6 and G.relerr(mt.cpu().numpy(), mr) < 1e-6 and G.relerr(vt.cpu().numpy(), vr) < 1e-6
+    assert np.array_equal(unpacked(shadow).cpu().numpy(), pt.cpu().numpy())
+
+
+def test_lightgcn_long_epoch_chunked_replay(gpu_device):
+    """An epoch longer than RK_MAX_GRAPH_STEPS: chunk graphs + a remainder graph + (70 = 8 * 8 + 6) against plain launches
+    and against one whole-call graph per 35-step half; ordered scatter, so the three must agree bit for bit."""
+    from recad_amd import model
+    g = G.load("lightgcn_game_d64_tg")
+    rng = np.random.default_rng(11)
+    U, I = int(g["n_users"]), int(g["n_items"])
+    B, steps = 256, 70
+    users = torch.from_numpy(rng.integers(0, U, B * steps - 17)).to(gpu_device)
+    pos = torch.from_numpy(rng.integers(0, I, B * steps - 17)).to(gpu_device)
+    neg = torch.from_numpy(rng.integers(0, I, B * steps - 17)).to(gpu_device)
+    outs = []
+    for mode in ("plain", "chunks", "halves"):
+        ds = ReplayDataset(g, LGN_KEYS, device=gpu_device, steps=[0])
+        m = model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=3, deterministic=True).I(dataset=ds)
+        u0, i0 = G.lightgcn_init(g)
+        m.embedding_user.weight.data.copy_(torch.from_numpy(u0))
+        m.embedding_item.weight.data.copy_(torch.from_numpy(i0))
+        m = m.to(gpu_device)
+        m.graph_steps = 0 if mode == "plain" else 8
+        if mode == "halves":
+            h = 35 * B
+            parts = [m._run_epoch(users[:h], pos[:h], neg[:h], B).clone(), m._run_epoch(users[h:], pos[h:], neg[h:], B).clone()]
+            part = torch.cat(parts)
+        else:
+            part = m._run_epoch(users, pos, neg, B).clone()
+        outs.append((part.sum(1).cpu().numpy(), m.embedding_user.weight.detach().cpu().numpy().copy(),
+                     m.embedding_item.weight.detach().cpu().numpy().copy(), int(m.optimizer.state[m.embedding_user.weight]["step"].item())))
+    for o in outs[1:]:
+        assert o[3] == outs[0][3] == steps
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+
+
 LGN = ["lightgcn_dev_d64", "lightgcn_dev_d128_l2_tg", "lightgcn_game_d64", "lightgcn_game_d64_tg"]
 
 
-def _make_lgn(g, device, steps=None):
+def _make_lgn(g, device, steps=None, lds=True):
+    """lds: the LDS-resident sliced propagation (csrc/spmm_lds.h; every golden graph qualifies) or the row-gather kernel."""
     from recad_amd import model
     ds = ReplayDataset(g, LGN_KEYS, device=device, steps=steps)
     m = model.from_config("victim", "lightgcn", latent_dim_rec=int(g["dim"]), lightGCN_n_layers=int(g["layers"])).I(dataset=ds)
+    m.use_lds = lds
     u, i = G.lightgcn_init(g)
     m.embedding_user.weight.data.copy_(torch.from_numpy(u))
     m.embedding_item.weight.data.copy_(torch.from_numpy(i))
     return m.to(device), ds
 
 
+def _took_lds(m):
+    return m._ws is not None and m._ws.get("lds") is not None
+
+
+@pytest.mark.parametrize("lds", [True, False])
 @pytest.mark.parametrize("name", LGN)
-def test_lightgcn_propagate_golden(gpu_device, name):
+def test_lightgcn_propagate_golden(gpu_device, name, lds):
     g = G.load(name)
-    m, _ = _make_lgn(g, gpu_device)
+    m, _ = _make_lgn(g, gpu_device, lds=lds)
     lu, li = m.computer()
+    assert _took_lds(m) == lds      # the reference's own graphs (dev, Amazon-game) qualify for the LDS plan
     light = torch.cat([lu, li]).cpu().numpy()
     assert G.relerr(light[:: int(g["row_stride"])], g["light0"]) < 1e-6
 
 
+@pytest.mark.parametrize("lds", [True, False])
 @pytest.mark.parametrize("graph_steps", [0, 4])
 @pytest.mark.parametrize("name", LGN)
-def test_lightgcn_train_golden(gpu_device, name, graph_steps):
-    """graph_steps: 0 = plain launches, 4 = hipGraph replay."""
+def test_lightgcn_train_golden(gpu_device, name, graph_steps, lds):
+    """graph_steps: 0 = plain launches, 4 = hipGraph replay; lds: both SpMM forms against the reference's goldens."""
     g = G.load(name)
     rs = int(g["row_stride"])
     # step-1 gradients (no update)
-    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    m, ds = _make_lgn(g, gpu_device, steps=[0], lds=lds)
     b = next(ds.generate_batch())
     part = m._run_epoch(b["users"], b["positive_items"], b["negative_items"], len(b["users"]), apply_update=False, want_grad=True)
     grad = m._ws["grad"].cpu().numpy()
@@ -83,8 +196,9 @@ def test_lightgcn_train_golden(gpu_device, name, graph_steps):
     assert G.relerr(grad[:U][::rs], g["grad1_user"]) < 1e-5
     assert G.relerr(grad[U:][::rs], g["grad1_item"]) < 1e-5
     assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
+    assert _took_lds(m) == lds
     # one step, then the rest, through the public train_step
-    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    m, ds = _make_lgn(g, gpu_device, steps=[0], lds=lds)
     m.graph_steps = graph_steps
     (l0,) = m.train_step(progress_bar=None)
     assert abs(l0 - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
