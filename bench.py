@@ -159,7 +159,7 @@ def cpu_baseline_port(d, graph, dim, layers, batch, triplets, n_steps_req, budge
         orc.lightgcn_step(csr, user, item, st, users[s * batch:(s + 1) * batch], pos[s * batch:(s + 1) * batch],
                           neg[s * batch:(s + 1) * batch], layers)
     el = time.perf_counter() - t0
-    return {"value": n * batch / el, "unit": "interactions/s", "cores": 1, "kind": "port",
+    return {"value": n * batch / el, "unit": "interactions/s", "cores": 1, "kind": "port", "impl": "c-oracle",
             "sample": f"{n} train steps of {batch} triplets on the same graph (oracle/recad_oracle.c, 1 thread, {el:.1f} s)"}
 
 
@@ -198,104 +198,22 @@ def mfma_gemm_probe(dev, nb=8192, n_items=34474, dim=256, reps=40):
 
 
 def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
-    """the reference's own op sequence (recad/model/victim/lightgcn.py:82-113,137-169) written
-    against ATen on the host cores -- torch.sparse.mm on the coalesced COO graph, index gathers, softplus,
-    autograd, torch.optim.Adam -- timed with k = all host threads.  Baseline only; never on the product path."""
-    import torch
+    """SURVEY.md 8d's CPU baseline: the reference's own op sequence (recad/model/victim/lightgcn.py:82-113,137-169 and
+    the per-user loop of recad/workflow/normal.py:57-93) on ATen with k host threads -- tests/tools/aten_ref.py, pinned
+    against the reference's goldens by tests/test_aten_ref.py.  Baseline only; never on the product path."""
+    from tests.tools import aten_ref
 
-    ncpu = os.cpu_count() or 1
-    prev = torch.get_num_threads()
-    try:
-        U, I = d["n_users"], d["n_items"]
-        ptr, idx = (np.asarray(a) for a in (d["train"] if graph == "train" else d["test"]))
-        deg_u = np.diff(ptr).astype(np.float64)
-        uu = np.repeat(np.arange(U, dtype=np.int64), np.diff(ptr))
-        ii = idx.astype(np.int64) + U
-        deg = np.zeros(U + I)
-        deg[:U] = deg_u
-        np.add.at(deg, ii, 1.0)
-        dinv = np.where(deg > 0, (deg + 1e-14) ** -0.5, 0.0)
-        rows = np.concatenate([uu, ii])
-        cols = np.concatenate([ii, uu])
-        vals = (dinv[rows] * dinv[cols]).astype(np.float32)
-        G = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (U + I, U + I)).coalesce()
-        g = torch.Generator().manual_seed(2023)
-        eu = torch.nn.Parameter(torch.randn(U, dim, generator=g) * 0.1)
-        ei = torch.nn.Parameter(torch.randn(I, dim, generator=g) * 0.1)
-        opt = torch.optim.Adam([eu, ei], lr=1e-3)
-        users, pos, neg = (torch.from_numpy(np.asarray(t)) for t in triplets)
-
-        def step(s):
-            sl = slice(s * batch, (s + 1) * batch)
-            u, p, n = users[sl], pos[sl], neg[sl]
-            all_emb = torch.cat([eu, ei])
-            embs = [all_emb]
-            for _ in range(layers):
-                all_emb = torch.sparse.mm(G, all_emb)
-                embs.append(all_emb)
-            light = torch.mean(torch.stack(embs, dim=1), dim=1)
-            lu, li = torch.split(light, [U, I])
-            ue, pe, ne = lu[u], li[p], li[n]
-            reg = 0.5 * (eu[u].norm(2).pow(2) + ei[p].norm(2).pow(2) + ei[n].norm(2).pow(2)) / float(len(u))
-            loss = torch.mean(torch.nn.functional.softplus((ue * ne).sum(1) - (ue * pe).sum(1))) + 1e-4 * reg
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            return float(loss.item())
-
-        # ATen's sparse kernels do not scale to hundreds of threads: time one step at a few thread counts and keep
-        # the fastest (k is reported)
-        avail = len(users) // batch
-        best = None
-        for k in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
-            torch.set_num_threads(k)
-            step(0)
-            t0 = time.perf_counter()
-            step(0)
-            one = time.perf_counter() - t0
-            if best is None or one < best[0]:
-                best = (one, k)
-            if one > 3.0:
-                break
-        one, k = best
-        torch.set_num_threads(k)
-        n = int(max(1, min(avail - 1, budget_s / max(one, 1e-3))))
-        t0 = time.perf_counter()
-        for s in range(1, n + 1):
-            last = step(s)
-        el = time.perf_counter() - t0
-        # the per-user evaluation loop of Normal.user_item_model_generate (normal.py:57-93): for EVERY user the reference calls
-        # model(users, items), i.e. computer() -- L sparse mm -- then the pair scores of the user's unseen items and a sort
-        tr_ptr, tr_idx = (np.asarray(a) for a in d["train"])
-        n_eval = 0
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            for u in range(0, U, max(1, U // 24)):
-                seen = np.zeros(I, dtype=bool)
-                seen[tr_idx[tr_ptr[u]:tr_ptr[u + 1]]] = True
-                items_t = torch.from_numpy(np.nonzero(~seen)[0])
-                all_emb = torch.cat([eu, ei])
-                embs = [all_emb]
-                for _ in range(layers):
-                    all_emb = torch.sparse.mm(G, all_emb)
-                    embs.append(all_emb)
-                light = torch.mean(torch.stack(embs, dim=1), dim=1)
-                lu, li = torch.split(light, [U, I])
-                scores = (lu[u].unsqueeze(0) * li[items_t]).sum(1)
-                order = torch.argsort(scores, descending=True)[:100]
-                _ = items_t[order]
-                n_eval += 1
-                if time.perf_counter() - t1 > 6.0:
-                    break
-        el_eval = time.perf_counter() - t1
-        return {"value": n * batch / el, "unit": "interactions/s", "cores": k, "kind": "port",
-                "sample": f"{n} train steps of {batch} triplets, the reference's ATen op sequence (torch.sparse.mm COO, "
-                          f"autograd, torch.optim.Adam) on {k} of {ncpu} host threads (fastest of 8/16/32/64), {el:.1f} s; last loss {last:.5f}",
-                "eval_users_per_s": n_eval / el_eval,
-                "eval_sample": f"{n_eval} users through the reference's per-user loop (computer() = {layers} sparse mm per user, "
-                               f"pair scores of the unseen items, sort, top-100), same {k} threads, {el_eval:.1f} s"}
-    finally:
-        torch.set_num_threads(prev)
+    ptr, idx = d["train"] if graph == "train" else d["test"]
+    r = aten_ref.time_baseline(d["n_users"], d["n_items"], ptr, idx, d["train"][0], d["train"][1], dim, layers, batch, triplets,
+                               budget_s=budget_s)
+    return {"value": r["interactions_per_s"], "unit": "interactions/s", "cores": r["threads"], "kind": "port", "impl": "aten",
+            "sample": f"{r['steps']} train steps of {batch} triplets through the reference's ATen op sequence (torch.sparse.mm on the "
+                      f"coalesced COO graph, autograd, torch.optim.Adam; tests/tools/aten_ref.py, validated against the reference's "
+                      f"goldens) on {r['threads']} of {r['host_threads']} host threads (fastest of 8/16/32/64), {r['seconds']:.1f} s; "
+                      f"last loss {r['last_loss']:.5f}",
+            "eval_users_per_s": r["eval_users_per_s"],
+            "eval_sample": f"{r['eval_users']} users through the reference's per-user loop (computer() = {layers} sparse mm per user, "
+                           f"pair scores of the unseen items, sort, top-100), same {r['threads']} threads, {r['eval_seconds']:.1f} s"}
 
 
 # ------------------------------------------------------------------------------------------------ worker
@@ -445,36 +363,55 @@ def worker(args):
         if n_ep:
             epoch_obj.update({"value": world * n_ep / te, "unit": "interactions/s", "triplets": n_ep})
 
-    # ---------------- dominant kernel: the CSR SpMM; per-launch time by HIP events on its stream
+    # ---------------- dominant kernel: the SpMM; per-launch time by HIP events on its stream
     roofline = None
     if sharded is None or rank == 0:
+        import ctypes as C
         stream = torch.cuda.current_stream()
         reps = 200 if nnz < 20_000_000 else 10
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         h = victim._ensure_handle()
+        lds = victim._ws.get("lds")
+        if lds is not None:
+            # the LDS-resident sliced kernel (csrc/spmm_lds.h), launched exactly as the first forward layer of a train step
+            ws = victim._ws
+            plan, info = lds
+            epi = _lib.LdsEpilogue(y=_lib.ptr(ws["buf_a"]), sum_in=_lib.ptr(ws["e0s"]), sum_out=_lib.ptr(ws["lsum"]), sum_scale=1.0)
+
+            def spmm_once():
+                _lib.check(_lib.lib().rk_spmm_lds(C.byref(info), _lib.ptr(plan), _lib.ptr(ws["e0s"]), C.byref(epi), _lib.stream_ptr()), "rk_spmm_lds")
+            per_call, kname = 1, f"spmm_lds_kernel<{info.lpa}, {info.lpb}>"
+        else:
+            def spmm_once():
+                _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+            per_call, kname = args.layers, f"spmm_csr_kernel<{args.dim}>"
         for _ in range(3):
-            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+            spmm_once()
         ev0.record(stream)
         for _ in range(reps):
-            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+            spmm_once()
         ev1.record(stream)
         torch.cuda.synchronize()
-        spmm_ms = ev0.elapsed_time(ev1) / (reps * args.layers)
+        spmm_ms = ev0.elapsed_time(ev1) / (reps * per_call)
         spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
         traffic = None
-        for tname in ("r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+        tkey = f"{args.workload}_{args.graph}_d{args.dim}" + ("_lds" if lds is not None else "")
+        for tname in ("r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.workload}_{args.graph}_d{args.dim}")
+                    traffic = json.load(open(tpath)).get(tkey)
                 except Exception:
                     traffic = None
-        roofline = {"bound": "hbm", "kernel": f"spmm_csr_kernel<{args.dim}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
                     "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
-                    "note": "per-launch time from HIP events around back-to-back propagate calls (includes the inter-kernel boundary)"}
+                    "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
+                            "inter-kernel boundary); algorithmic bytes = SURVEY 8d's 8 nnz + 4 (N+1) + 8 N d"}
+        if lds is not None:
+            roofline["on_chip_bytes_per_launch"] = 4 * nnz * args.dim   # what the LDS pipes deliver instead of the L2 -> L1 gather
 
     # ---------------- second half of the metric: full-catalog scoring + top-100 + HR@K
     topk = None
@@ -546,8 +483,8 @@ def worker(args):
                        "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
-            "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu,
-            "cpu_baseline_aten": cpu_aten, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
+            "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
+            "cpu_baseline_port": cpu, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
         if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
             same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]

@@ -189,7 +189,7 @@ typedef struct rk_lightgcn_desc {
     float *buf_a, *buf_b, *light, *gprop, *gego;
     float *grad;                              /* nullable: receives dLoss/dE0 [N*dim] */
     int32_t *state;                           /* device int32[16], 8-byte aligned, owned by the handle's user */
-    float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] */
+    float *coef;                              /* device float[2*RK_MAX_GRAPH_STEPS] (3*RK_MAX_GRAPH_STEPS with cnt) */
     int32_t *spmm_scratch;                    /* int32[scratch_words] of rk_csr_schedule_build, zero-filled, owned by this
                                                * handle's user (NULL when scratch_words == 0) */
     /* optional: device uint32[(N+31)/32] bitmap of the current minibatch's rows; when given (and
@@ -214,6 +214,10 @@ typedef struct rk_lightgcn_desc {
     const int32_t *lds_plan;
     rk_lds_info lds_info;
     float *lsum, *e0s, *ms, *vs;
+    int32_t *cnt;                             /* optional, int32[N]: per-node incidence counts of the minibatch; with it the L2-reg
+                                               * gradient is applied in closed form (lambda / nb * count * E0) and the BPR kernel
+                                               * scatters three rows per triplet instead of six; coef must then hold
+                                               * 3 * RK_MAX_GRAPH_STEPS floats */
 } rk_lightgcn_desc;
 #define RK_MAX_GRAPH_STEPS 64
 

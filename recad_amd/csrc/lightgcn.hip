@@ -68,6 +68,10 @@ struct BprArgs {
     // gprop / gego in the sliced layout of spmm_lds.h (the LDS-resident propagation gathers them by slice)
     int sliced;
     LdsDims sl;
+    // LDS path: the reg gradient is applied in closed form by the last backward launch (LdsEpi::cnt): only gprop is
+    // scattered, every node's incidences are counted, and the step's lambda / nb goes to creg_out
+    int *cnt;
+    float *creg_out;
 };
 
 // float offset of element (row, k) of a gradient buffer
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
     const float invB = nb > 0 ? 1.0f / (float)nb : 0.f;
     const float inv_layers = 1.0f / (float)(a.L + 1);
     const float creg = a.lam * invB;
+    if (a.creg_out && blockIdx.x == 0 && threadIdx.x == 0) a.creg_out[0] = creg;
     const int d = a.d;
     float sp_sum = 0.f, reg_sum = 0.f;
     const int wave_id = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
@@ -137,10 +142,13 @@ __global__ __launch_bounds__(256) void bpr_kernel(const BprArgs a)
             unsafeAtomicAdd(a.gprop + ou, du);
             unsafeAtomicAdd(a.gprop + op, dp);
             unsafeAtomicAdd(a.gprop + on, dn);
-            unsafeAtomicAdd(a.gego + ou, du + creg * a.emb[ou]);
-            unsafeAtomicAdd(a.gego + op, dp + creg * a.emb[op]);
-            unsafeAtomicAdd(a.gego + on, dn + creg * a.emb[on]);
+            if (!a.cnt) {
+                unsafeAtomicAdd(a.gego + ou, du + creg * a.emb[ou]);
+                unsafeAtomicAdd(a.gego + op, dp + creg * a.emb[op]);
+                unsafeAtomicAdd(a.gego + on, dn + creg * a.emb[on]);
+            }
         }
+        if (a.cnt && lane < 3) atomicAdd(a.cnt + (lane == 0 ? (int)u : a.U + (int)(lane == 1 ? p : n)), 1);
     }
     if (lane == 0) { red[0][w] = sp_sum; red[1][w] = reg_sum; }
     __syncthreads();
@@ -493,7 +501,7 @@ static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced,
     return RK_OK;
 }
 
-static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s)
+static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s, bool training)
 {
     const int L = d.n_layers;
     const LdsInfo li = lds_info(d);
@@ -508,12 +516,13 @@ static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s)
         a.e.sum_out = (l == L) ? d.light : d.lsum;
         a.e.sum_rm = (l == L) ? 1 : 0;
         a.e.sum_scale = (l == L) ? 1.0f / (float)(L + 1) : 1.0f;
+        if (training && l == 1) a.e.zero_cnt = d.cnt;   // (nullable) the incidence counts of the previous step
         RK_HIP(spmm_lds_launch(li, a, s));
     }
     return RK_OK;
 }
 
-static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s)
+static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s, bool counted)
 {
     const int N = d.n_users + d.n_items, L = d.n_layers;
     const LdsInfo li = lds_info(d);
@@ -524,11 +533,12 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
         a.plan = d.lds_plan;
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
         const bool last = (j == L);
-        a.e.add = last ? d.gego : d.gprop;
+        a.e.add = (last && !counted) ? d.gego : d.gprop;
         a.e.sum_scale = 1.0f;
         if (last) {
-            a.e.zero1 = d.gego;
+            a.e.zero1 = counted ? nullptr : d.gego;
             a.e.zero2 = (L >= 2) ? d.gprop : nullptr;
+            if (counted) { a.e.cnt = d.cnt; a.e.creg = d.coef + 2 * RK_MAX_GRAPH_STEPS + k; a.e.reg_p = d.e0s; }
             if (apply_update) {
                 a.e.adam = 1;
                 a.e.p = d.e0s; a.e.m = d.ms; a.e.v = d.vs;   // sliced working copies (lds_sync)
@@ -566,7 +576,7 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
 {
     const int L = d.n_layers;
     const float inv = 1.0f / (float)(L + 1);
-    if (use_lds(d) && drop == 0) return launch_forward_lds(d, s);
+    if (use_lds(d) && drop == 0) return launch_forward_lds(d, s, batch != nullptr);
     if (L == 0) {
         RK_HIP(hipMemcpyAsync(d.light, d.user_emb, sizeof(float) * (size_t)d.n_users * d.dim, hipMemcpyDeviceToDevice, s));
         RK_HIP(hipMemcpyAsync(d.light + (size_t)d.n_users * d.dim, d.item_emb, sizeof(float) * (size_t)d.n_items * d.dim,
@@ -595,10 +605,10 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
 }
 
 // backward + Adam for chunk step k; gprop/gego hold the BPR scatter
-static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s)
+static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s, bool ordered = false)
 {
     const int N = d.n_users + d.n_items, L = d.n_layers;
-    if (use_lds(d)) return launch_backward_lds(d, k, apply_update, bump, s);
+    if (use_lds(d)) return launch_backward_lds(d, k, apply_update, bump, s, d.cnt != nullptr && !ordered);
     float *bufs[2] = {d.buf_a, d.buf_b};
     auto fill_adam = [&](SpmmEpi &e) {
         if (apply_update) {
@@ -670,6 +680,7 @@ static int launch_step(const rk_lightgcn_desc &d, int k, int apply_update, int b
     b.keys = ord.keys;
     b.sliced = use_lds(d) ? 1 : 0;
     b.sl = LdsDims{d.n_users, d.n_items, d.dim, d.lds_info.lsu, d.lds_info.lsi};
+    if (use_lds(d) && d.cnt && !ord.keys) { b.cnt = d.cnt; b.creg_out = d.coef + 2 * RK_MAX_GRAPH_STEPS + k; }
     if (ord.keys) {
         if (d.dim <= 64) hipLaunchKernelGGL(bpr_rows_kernel<1>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
         else if (d.dim <= 128) hipLaunchKernelGGL(bpr_rows_kernel<2>, dim3(RK_LOSS_PARTIALS), dim3(kRowsWaves * 64), 0, s, b);
@@ -677,7 +688,7 @@ static int launch_step(const rk_lightgcn_desc &d, int k, int apply_update, int b
     }
     else hipLaunchKernelGGL(bpr_kernel, dim3(RK_LOSS_PARTIALS), dim3(256), 0, s, b);
     RK_CHECK_LAUNCH();
-    return launch_backward(d, k, apply_update, bump, s);
+    return launch_backward(d, k, apply_update, bump, s, ord.keys != nullptr);
 }
 
 static OrderedRef ordered_ref(const rk_lightgcn *h, int batch)
@@ -693,6 +704,7 @@ static int launch_prologue(const rk_lightgcn_desc &d, int apply_update, hipStrea
     RK_HIP(rk_zero_async(d.gprop, sizeof(float) * (size_t)N * d.dim, s));
     RK_HIP(rk_zero_async(d.gego, sizeof(float) * (size_t)N * d.dim, s));
     if (d.row_bits && !use_lds(d)) RK_HIP(rk_zero_async(d.row_bits, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
+    if (use_lds(d) && d.cnt) RK_HIP(rk_zero_async(d.cnt, sizeof(int32_t) * (size_t)N, s));
     if (use_lds(d)) return lds_sync(d, apply_update != 0, 1, s);
     return RK_OK;
 }

@@ -59,6 +59,11 @@ struct LdsEpi {
     int *state;
     int bump;
     unsigned long long *stamps;  // diagnostic, nullable: 4 wall-clock stamps per workgroup (start, staged, gathered, done)
+    // L2-regularisation gradient in closed form: v += creg[0] * cnt[node] * reg_p[r] (cnt = how often the node occurs in the
+    // minibatch, reg_p = E0 sliced) -- the BPR kernel then scatters three gradient rows per triplet instead of six
+    const int *cnt;
+    const float *creg, *reg_p;
+    int *zero_cnt;               // nullable: cnt is cleared here (a launch in which nobody reads it)
 };
 
 struct LdsArgs {
@@ -267,6 +272,12 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
         for (; p < o.p1; ++p) acc = f4_plus(acc, part[p * LP + j]);
         float4 v = f4_scale(acc, o.dr);
         if (e.add) v = f4_plus(v, o.addv);
+        if (e.cnt) {
+            const float c = e.creg[0] * (float)e.cnt[node0 + row0 + i / LP];
+            const float4 pr = e.adam && !e.adam_rm ? pw : *reinterpret_cast<const float4 *>(e.reg_p + o.so);
+            v.x += c * pr.x; v.y += c * pr.y; v.z += c * pr.z; v.w += c * pr.w;
+        }
+        if (e.zero_cnt && slice == 0 && j == 0) e.zero_cnt[node0 + row0 + i / LP] = 0;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e.zero1) *reinterpret_cast<float4 *>(e.zero1 + o.so) = z;
         if (e.zero2) *reinterpret_cast<float4 *>(e.zero2 + o.so) = z;

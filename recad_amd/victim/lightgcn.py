@@ -138,7 +138,7 @@ class LightGCN(BaseVictim):
         ws = {k: torch.zeros(N, d, device=dev, dtype=torch.float32) for k in ("buf_a", "buf_b", "light", "gprop", "gego")}
         ws["grad"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if want_grad else None
         ws["state"] = torch.zeros(16, device=dev, dtype=torch.int32)
-        ws["coef"] = torch.zeros(2 * _lib.RK_MAX_GRAPH_STEPS, device=dev, dtype=torch.float32)
+        ws["coef"] = torch.zeros(3 * _lib.RK_MAX_GRAPH_STEPS, device=dev, dtype=torch.float32)
         ws["row_bits"] = torch.zeros((N + 31) // 32, device=dev, dtype=torch.int32) if self.use_batch_sparsity else None
         if self.graph_dropout and self._drop_seed is None:
             self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -151,6 +151,7 @@ class LightGCN(BaseVictim):
             lds = g.lds_plan(d)
         ws["lds"] = lds
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
+        ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
         for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
             ws[k] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         desc = _lib.LightGCNDesc(
@@ -170,7 +171,7 @@ class LightGCN(BaseVictim):
             keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
             drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]),
             lds_plan=_lib.ptr(lds[0]) if lds else None, lds_info=lds[1] if lds else _lib.LdsInfo(),
-            lsum=_lib.ptr(ws["lsum"]), e0s=_lib.ptr(ws["e0s"]), ms=_lib.ptr(ws["ms"]), vs=_lib.ptr(ws["vs"]))
+            lsum=_lib.ptr(ws["lsum"]), e0s=_lib.ptr(ws["e0s"]), ms=_lib.ptr(ws["ms"]), vs=_lib.ptr(ws["vs"]), cnt=_lib.ptr(ws["cnt"]))
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         if self.deterministic:
