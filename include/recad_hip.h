@@ -162,7 +162,7 @@ int rk_bpr_rows(int32_t dim, int32_t n_layers, float lambda, const float *light,
 
 /* The same minibatch with the ordered scatter of rk_lightgcn_set_deterministic (no atomics: plain stores, one wave per
  * touched row; gprop / gego must be zero on the minibatch's rows): light is always the compact [3*nb, dim] block, and
- * keys = device uint64[3*nb], the batch's incidences (row << 20) | (3*b + role), role 0/1/2 = user/positive/negative,
+ * keys = device uint64[3*nb], the batch's incidences (row << 20) | (3*b + role) with row < 2^24, role 0/1/2 = user/positive/negative,
  * SORTED ascending -- the caller's sort (the row-sharded trainer sorts a whole epoch with one batched torch.sort).
  * Every rank that runs it on the same triplets gets bit-identical gradient rows. */
 int rk_bpr_rows_ordered(int32_t dim, int32_t n_layers, float lambda, const float *light, const float *emb, float *gprop,

@@ -397,7 +397,9 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
     hipStream_t s = (hipStream_t)stream;
-    if (use_fused(n_items, dim, K, n_targets) && (reinterpret_cast<uintptr_t>(scratch) & 7) == 0) {
+    if (use_fused(n_items, dim, K, n_targets)) {
+        // (no silent fall-through to the GEMM path: the caller sized `scratch` for THIS path, 1025 floats per user)
+        if (reinterpret_cast<uintptr_t>(scratch) & 7) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 8-byte aligned (fused sweep)");
         SelArgs a;
         memset(&a, 0, sizeof(a));
         a.nb = nb; a.n_items = n_items; a.d = dim; a.K = K;

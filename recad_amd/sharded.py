@@ -135,6 +135,10 @@ class HipOps:
     def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None):
         if slab["col"].numel() == 0 and slab["n_rows"] == 0:
             return
+        if slab["col"].numel() == 0:
+            # a chunk made of padding rows only (n_rows > 0, no nonzeros -- a user-chosen chunk count on a small slab):
+            # the launch needs col / val pointers, so give it one unused zero entry
+            slab = dict(slab, col=torch.zeros(1, dtype=torch.int32, device=x.device), val=torch.zeros(1, dtype=torch.float32, device=x.device))
         e = _lib.SpmmEpilogue(add=_lib.ptr(add), y=_lib.ptr(y), sum_in=_lib.ptr(sum_in), sum_out=_lib.ptr(sum_out),
                               sum_scale=float(sum_scale))
         if adam is not None:
@@ -347,6 +351,9 @@ class ShardedLightGCN:
             n_steps = (n + batch - 1) // batch
             if 3 * batch >= (1 << 20):
                 raise ValueError("deterministic scatter: batches of < 349525 triplets")
+            if self.world * lay.M >= (1 << 24):
+                # the kernel (rk_bpr_rows_ordered, plan_row) keeps 24 bits of the gathered row in a key
+                raise ValueError("deterministic scatter: fewer than 2^24 gathered rows (world * rows per rank)")
             b_in = torch.arange(n, device=dev) % batch
             keys = (posn << 20) | (3 * b_in.unsqueeze(0) + torch.arange(3, device=dev).unsqueeze(1))          # [3, n]
             padded = torch.full((3, n_steps * batch), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)

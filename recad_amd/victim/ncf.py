@@ -77,6 +77,7 @@ class NCF(BaseVictim):
         self.drop_p = float(dropout)
         self._drop_seed = None   # drawn from torch's global RNG on first use (nn.Dropout draws its masks from it)
         self._drop_calls = 0
+        self._mask_steps = 0   # minibatches trained so far (numbers the dropout masks of gradient-only calls)
         self.max_batch = 16384  # forward chunk of the full-catalog evaluation: large enough for the 128x128-tile GEMM
 
     # ------------------------------------------------------------------ C-ABI descriptor
@@ -155,6 +156,12 @@ class NCF(BaseVictim):
             raise _lib.HipCallError("fused update requested with a non-default optimizer (internal error)")
         st0 = self.optimizer.state.get(self._tensors()[0], {})
         t0 = int(st0["step"]) if "step" in st0 else 0
+        if not apply_update:
+            # gradient-only calls (a foreign optimizer applies the update): the library numbers the train-time dropout masks
+            # by adam_t0 + step, and optimizers such as SGD keep no 'step' -- count the minibatches here so that every one
+            # draws a fresh mask like nn.Dropout does (ncf.py:44)
+            t0 = self._mask_steps
+        self._mask_steps += n_steps
         _lib.check(_lib.lib().rk_ncf_train_epoch(C.byref(d), _lib.ptr(users), _lib.ptr(items), _lib.ptr(labels), n, batch,
                                                  t0, _lib.ptr(lp), 1 if apply_update else 0, _lib.stream_ptr()),
                    "rk_ncf_train_epoch")

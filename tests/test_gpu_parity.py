@@ -1569,11 +1569,12 @@ def _spmm_rows_host(rp, c, v, x, rows):
     return out
 
 
-@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused")])
+@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("config4", 64, "default")])
 def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
-    """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128) and
+    """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128),
     config 4 / 4 (250 K x 125 K, 25 M edges, d=64: rows of > 100 K nonzeros, i.e. hundreds of cross-workgroup
-    pieces, 32-bit gather offsets at 96 MB tables).  The oracle cannot replay these sizes in seconds, so:
+    pieces, 32-bit gather offsets at 96 MB tables) and config 4 itself (1 M x 500 K x 100 M edges: 200 M nonzeros,
+    384 MB tables, a 500 K-item catalogue scored through the fused sweep).  The oracle cannot replay these sizes in seconds, so:
     size-independent properties (linearity, symmetry, spectral bound of the normalised adjacency, determinism),
     float64 host restatements of SAMPLED rows (the longest rows included), a train step that moves the loss, and
     bit-exact top-K lists / target ranks against the oracle on sampled users."""
@@ -1581,7 +1582,7 @@ def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     from recad_amd.evaluate import eligible_users_device, full_catalog_topk
     if mode == "fused":
         request.getfixturevalue("fused_scoring")
-    if shape == "c4s":
+    if shape in ("c4s", "config4"):
         dd = synth.make_device(shape, gpu_device)
         d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
         del dd
@@ -1781,6 +1782,30 @@ def test_ncf_neumf_pre_initialisation(gpu_device):
     assert torch.allclose(pre(u, i), want, rtol=1e-5, atol=1e-6)
     with pytest.raises(Exception):
         model.from_config("victim", "ncf", model="NeuMF-pre").I(dataset=ds)
+
+
+def test_ncf_dropout_masks_advance_with_a_stepless_optimizer(gpu_device):
+    """optim='SGD' keeps no 'step' in its state: the gradient-only path must still draw a fresh dropout mask for every
+    minibatch (nn.Dropout, ncf.py:44), numbered by the module's own minibatch counter."""
+    from recad_amd import model
+    g = G.load("ncf_dev_f8_l3")
+    ds = ReplayDataset(g, PW_KEYS, device=gpu_device, with_graph=False, steps=[0])
+    torch.manual_seed(9)
+    m = model.from_config("victim", "ncf", factor_num=8, num_layers=3, dropout=0.3, optim="SGD", lr=0.0).I(dataset=ds).to(gpu_device)
+    m._drop_seed = 1234
+    n = int(g["batch_len"][0])
+    cols = [torch.from_numpy(g["batches"][0, k, :n].astype(np.int64)).to(gpu_device) for k in range(3)]
+    m.train()
+    p1, g1 = m._grad_step(cols)
+    p2, g2 = m._grad_step(cols)     # same minibatch, same weights (lr = 0): only the mask can differ
+    w = m._tensors()[4]
+    assert not torch.equal(g1[w], g2[w]) and float(p1.sum()) != float(p2.sum())
+    m._mask_steps = 0               # the same counter value reproduces the same mask
+    p3, g3 = m._grad_step(cols)
+    assert torch.allclose(g3[w], g1[w], rtol=1e-4, atol=1e-7) and abs(float(p3.sum()) - float(p1.sum())) <= 1e-6 * abs(float(p1.sum()))
+    (l1,) = m.train_step()
+    (l2,) = m.train_step()
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
 
 
 def test_ncf_and_mf_dropout(gpu_device):
