@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--force-collectives", action="store_true",
                     help="N=1 with --parallel rows: keep every collective of the sharded trainer (one-rank RCCL group): "
                          "exercises the real all-gather / all-reduce calls, async handles and stream ordering on a 1-GPU box")
+    ap.add_argument("--workflow", action="store_true",
+                    help="labelled extra mode (SURVEY 8d config 3): time train(clean) + inject 50 fake users + train(poisoned) + 2 x "
+                         "evaluation through workflow.execute(), with the graph / schedule rebuild of the retrain loop itemised")
+    ap.add_argument("--rec-epoch", type=int, default=2, help="--workflow: training epochs per (re)train")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
     a = ap.parse_args(argv)
@@ -494,9 +498,82 @@ def worker(args):
         dist.destroy_process_group()
 
 
+def workflow_bench(args):
+    """SURVEY 8d config 3's timed quantity: Normal.execute (recad/workflow/normal.py:193-225) = train(clean) + attacker +
+    inject (recad/dataset/implicit.py:482-494) + fresh victim on the poisoned graph + train(poisoned) + the two evaluations,
+    with the host-side costs of the perturb-retrain loop itemised: dataset / graph rebuild, SpMM schedule or LDS plan build
+    (first handle of the new victim), hipGraph capture."""
+    import torch
+    from recad_amd import dataset, model, synth, workflow
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+
+    def sync_time():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    t = sync_time()
+    big = args.workload in ("c4s", "config4")
+    if big:
+        dd = synth.make_device(args.workload, dev)
+        d = {k: (tuple(x.cpu().numpy() for x in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+        del dd
+    else:
+        d = synth.make(args.workload)
+    t_synth = sync_time() - t
+    t = sync_time()
+    ds = dataset.from_config("implicit", args.workload, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                             need_graph=True, device=dev, graph_source=args.graph, pairwise_batch_size=args.batch, seed=1234)
+    g = ds.graph_csr()
+    t_dataset = sync_time() - t
+    torch.manual_seed(2023)
+    victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers)
+    wf = workflow.from_config("no defense", victim_data=ds, attack_data=None, victim=victim,
+                              attacker=workflow.RandomAttack(ds.n_items, attack_num=50, filler_num=36, seed=2),
+                              rec_epoch=args.rec_epoch, attack_epoch=0, device=dev, target_id_list=[0])
+    items = {}
+
+    def staged(name, fn):
+        t0 = sync_time()
+        out = fn()
+        items[name] = sync_time() - t0
+        return out
+
+    t_all = sync_time()
+    wf.victim = wf.victim.to(dev)
+    staged("clean_handle_schedule_build_s", lambda: wf.victim._ensure_handle())
+    staged("train_clean_s", lambda: wf.normal_train(wf.victim, args.rec_epoch))
+    fake = staged("attacker_generate_fake_s", lambda: wf.attacker.generate_fake(**wf.info_describe()))
+    fake_ds = staged("inject_dataset_rebuild_s", lambda: ds.inject_data("explicit", fake, filter_num=wf.c["filter_num"]))
+    staged("inject_graph_rebuild_s", lambda: fake_ds.graph_csr())
+    fake_victim = staged("reset_instantiate_s", lambda: wf.victim.reset().I(dataset=fake_ds).to(dev))
+    staged("poisoned_handle_schedule_build_s", lambda: fake_victim._ensure_handle())
+    staged("train_poisoned_s", lambda: wf.normal_train(fake_victim, args.rec_epoch))
+    res = staged("evaluate_2x_s", lambda: wf.normal_evaluate(wf.victim, fake_victim, ds, [0], wf.c["topks"]))
+    total = sync_time() - t_all
+    retrain = items["inject_dataset_rebuild_s"] + items["inject_graph_rebuild_s"] + items["reset_instantiate_s"] + \
+        items["poisoned_handle_schedule_build_s"] + items["train_poisoned_s"]
+    host = items["inject_dataset_rebuild_s"] + items["inject_graph_rebuild_s"] + items["poisoned_handle_schedule_build_s"]
+    n_ep = int(len(ds.generate_epoch()["users"]))
+    out = {"metric": "config-3 workflow: train(clean) + inject 50 users + train(poisoned) + 2 x evaluation, seconds",
+           "value": total, "unit": "s", "higher_is_better": False, "n_gpus": 1, "data": "synthetic", "dtype": "f32",
+           "config": {"workload": f"LightGCN victim, {args.workload}-shaped synthetic {ds.n_users}x{ds.n_items}, {ds.traindataSize} train edges, "
+                                  f"graph={args.graph} (nnz {g.nnz}), dim={args.dim}, layers={args.layers}, batch={args.batch}, "
+                                  f"rec_epoch={args.rec_epoch}, random attacker 50 x 36, device sampler included",
+                      "spmm": "lds" if wf.victim._ws.get("lds") is not None else "csr"},
+           "items_s": items, "synth_s": t_synth, "dataset_and_graph_build_s": t_dataset,
+           "retrain_s": retrain, "retrain_host_rebuild_s": host, "retrain_host_share": host / retrain,
+           "triplets_per_epoch": n_ep, "train_interactions_per_s": 2 * args.rec_epoch * n_ep / (items["train_clean_s"] + items["train_poisoned_s"]),
+           "results": {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in res.items()}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    if args.workflow:
+        return workflow_bench(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_workers(args, argv))
     worker(args)

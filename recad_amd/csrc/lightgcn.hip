@@ -402,8 +402,10 @@ static int check_desc(const rk_lightgcn_desc &d)
 {
     if (d.n_users <= 0 || d.n_items <= 0 || d.dim <= 0 || d.n_layers < 0) RK_FAIL(RK_EINVAL, "lightgcn: bad sizes");
     if (d.dim > 256) RK_FAIL(RK_EINVAL, "lightgcn: dim %d > 256 unsupported (long-row scratch slots are 256 floats)", d.dim);
-    if (!d.rowptr || !d.col || !d.val || !d.wave_desc || d.n_blocks <= 0) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
-    if ((d.n_blocks & kSchedLongFlag) && !d.spmm_scratch) RK_FAIL(RK_EINVAL, "lightgcn: the schedule has long rows: desc.spmm_scratch is required");
+    const bool lds_only = d.lds_plan && d.n_layers >= 1 && !(d.keep_prob > 0.f);   // every SpMM of the handle takes the LDS kernel
+    if (!d.rowptr || !d.col || !d.val) RK_FAIL(RK_EINVAL, "lightgcn: graph pointers missing");
+    if (!lds_only && (!d.wave_desc || d.n_blocks <= 0)) RK_FAIL(RK_EINVAL, "lightgcn: the SpMM schedule (wave_desc, n_blocks) is missing");
+    if (!lds_only && (d.n_blocks & kSchedLongFlag) && !d.spmm_scratch) RK_FAIL(RK_EINVAL, "lightgcn: the schedule has long rows: desc.spmm_scratch is required");
     if (!d.user_emb || !d.item_emb || !d.m_user || !d.v_user || !d.m_item || !d.v_item)
         RK_FAIL(RK_EINVAL, "lightgcn: parameter/moment pointers missing");
     if (!d.buf_a || !d.buf_b || !d.light || !d.gprop || !d.gego || !d.state || !d.coef)
@@ -633,6 +635,8 @@ static int launch_backward(const rk_lightgcn_desc &d, int k, int apply_update, i
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
         const bool last = (j == L);
         if (d.row_bits && L >= 2) {
+            // the bitmap of the minibatch's rows (set by the first forward layer) is still up: gprop is zero elsewhere
+            if (j == 1) a.src_filter = d.row_bits;
             if (last) { a.clear_bits = d.row_bits; a.n_words = (N + 31) / 32; }
         }
         if (d.keep_prob > 0.f) set_dropout(a, d, 2, k, d.drop_seed, true);

@@ -53,6 +53,12 @@ struct SpmmArgs {
     // the gathers of all-zero gradient rows in the first backward layer was measured too: the
     // predicated loads cost more than they save, 26.0 vs 18.1 us.)
     const unsigned *row_filter;  // skip rows whose bit is clear (outputs not written)
+    // Frontier-sparse gather operand (first backward layer of a train step: x = dL/dlight is non-zero only on the
+    // minibatch's <= 3B rows): bit c clear => x[c] is all zeros and entry (r, c) is skipped.  Every 64-entry chunk of
+    // the column stream is tested against the bitmap and the hits are compacted (ds_permute) before the row gathers,
+    // so the launch moves sum_{s in batch} deg(s) rows instead of nnz; the surviving terms keep their order, i.e.
+    // the sums are bit-identical to the unfiltered launch.
+    const unsigned *src_filter;
     unsigned *mark_bits;         // set the bits of the current minibatch (first forward layer)
     unsigned *clear_bits;        // zero the bitmap (last backward layer)
     int n_words, mark_U, mark_k;
@@ -171,9 +177,10 @@ __device__ __forceinline__ float4 gather_round(float4 acc, int c, float a, int n
 
 // Partial sum of row segment [eb, ee) for the D/4 lanes that share `sub`; after the
 // cross-group reduction every lane holds the total for its float4 slot.
-template <int D, int UNMAX, bool DROP>
+template <int D, int UNMAX, bool DROP, bool FILT = false>
 __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, const float *__restrict__ val, int eb, int ee,
-                                               const float *__restrict__ x, int lane, const DropCtx &dc)
+                                               const float *__restrict__ x, int lane, const DropCtx &dc,
+                                               const unsigned *__restrict__ filt = nullptr)
 {
     constexpr int G = D / 4, NG = 64 / G;
     const int grp = lane / G, sub = lane % G;
@@ -182,11 +189,22 @@ __device__ __forceinline__ float4 spmm_segment(const int *__restrict__ col, cons
     float a_next = 0.f;
     if (eb + lane < ee) { c_next = ld_col(col + eb + lane); a_next = DROP ? drop_val(dc, eb + lane, val[eb + lane]) : ld_val(val + eb + lane); }
     for (int base = eb; base < ee; base += 64) {
-        const int n = min(64, ee - base);
-        const int c = c_next;
-        const float a = a_next;
+        int n = min(64, ee - base);
+        int c = c_next;
+        float a = a_next;
         c_next = 0; a_next = 0.f;
         if (base + 64 + lane < ee) { c_next = ld_col(col + base + 64 + lane); a_next = DROP ? drop_val(dc, base + 64 + lane, val[base + 64 + lane]) : ld_val(val + base + 64 + lane); }
+        if (FILT) {
+            // keep the entries whose source row is in the frontier, compacted to the low lanes in their original order
+            const bool hit = lane < n && ((filt[(unsigned)c >> 5] >> (c & 31)) & 1u);
+            const unsigned long long mask = __ballot(hit);
+            n = __popcll(mask);
+            if (n == 0) continue;
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            const int dst = hit ? rank : 63;   // lanes that miss park on the last lane: only read when all 64 hit, and then nobody misses
+            c = __builtin_amdgcn_ds_permute(dst << 2, c);
+            a = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(a)));
+        }
         const int iters = (n + NG - 1) / NG;
         int t = 0;
         for (; t + UNMAX <= iters; t += UNMAX) acc = gather_round<D, UNMAX>(acc, c, a, n, t, x, grp, sub);
@@ -296,7 +314,7 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
 
 // DROP: graph dropout compiled in (a separate instantiation: carrying the mask state through the default
 // kernel cost 7 % of a train step even with dropout switched off at run time)
-template <int D, int UNMAX, int WAVES, int MINW, bool PACKED = false, bool DROP = false>
+template <int D, int UNMAX, int WAVES, int MINW, bool PACKED = false, bool DROP = false, bool FILT = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmArgs a)
 {
     constexpr int G = D / 4;
@@ -354,7 +372,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
                 const int t = t0 + j;
                 int cc = __shfl(c, (grp * G + t) & 63, 64);
                 float aa = __shfl(av, (grp * G + t) & 63, 64);
-                const bool ok = t < n;
+                bool ok = t < n;
+                if (FILT) ok = ok && ((a.src_filter[(unsigned)cc >> 5] >> (cc & 31)) & 1u);
                 cc = ok ? cc : 0;
                 aw[j] = ok ? aa : 0.f;
                 xv[j] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(cc * D + sub * 4));
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         return;
     }
     if (ds.z > ds.y && !(a.dbg & 1)) {
-        acc = spmm_segment<D, UNMAX, DROP>(a.col, a.val, ds.y, ds.z, a.x, lane, dc);
+        acc = spmm_segment<D, UNMAX, DROP, FILT>(a.col, a.val, ds.y, ds.z, a.x, lane, dc, a.src_filter);
     }
     if (lane < G) part[w][lane] = acc;
     __syncthreads();
@@ -477,9 +496,15 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     static const int variant = getenv("RK_SPMM_VARIANT") ? atoi(getenv("RK_SPMM_VARIANT")) : 0;
     static const int dbg = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
     a.dbg = dbg;
+    static const int no_filt = getenv("RK_SPMM_NO_FRONTIER") ? atoi(getenv("RK_SPMM_NO_FRONTIER")) : 0;   // A/B only
+    if (no_filt || a.drop_thresh24 || !(a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) a.src_filter = nullptr;
+    const bool filt = a.src_filter != nullptr;
 #define RK_SPMM_CASE(D, UN, WV, MW)                                                              \
     do {                                                                                         \
-        if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true>), grid, block, 0, s, a); \
+        if (filt) {                                                                              \
+            if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true, false, true>), grid, block, 0, s, a);  \
+            else hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, false, false, true>), grid, block, 0, s, a);        \
+        } else if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, false>), grid, block, 0, s, a);  \
     } while (0)
 #define RK_SPMM_DROP(D)                                                                                \

@@ -78,6 +78,7 @@ __device__ __forceinline__ float4 f4_plus(float4 a, float4 b) { return make_floa
 // epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
 // the row's sum is ready
 // LDS (address space 3) pointer to a float4: lets an absolute LDS byte address be dereferenced without a base add
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // (host pass only: LDS pointers are 32-bit on the device)
 typedef float lds_f4n __attribute__((ext_vector_type(4)));
 typedef const lds_f4n __attribute__((address_space(3))) *lds_f4_ptr;
 

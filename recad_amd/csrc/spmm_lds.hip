@@ -1,6 +1,8 @@
 // Plan builder and entry points of the LDS-resident sliced SpMM (spmm_lds.h).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "spmm_lds.h"
@@ -63,17 +65,35 @@ static int colour_group(const std::vector<std::vector<int>> &cls, int K, std::ve
     if (delta == 0) return 0;
     struct Edge { int u, v, i, c; };
     std::vector<Edge> es;
-    const size_t D = (size_t)delta;
+    const size_t D = (size_t)delta, W = (D + 63) / 64;
     std::vector<int> atL((size_t)n * D, -1), atR((size_t)K * D, -1);
+    // used-colour bitmaps per node (bits >= delta preset): the first free colour is one ctz away
+    std::vector<unsigned long long> useL((size_t)n * W, 0ULL), useR((size_t)K * W, 0ULL);
+    auto preset = [&](std::vector<unsigned long long> &m, size_t nodes) {
+        for (size_t q = 0; q < nodes; ++q)
+            for (size_t c = D; c < W * 64; ++c) m[q * W + c / 64] |= 1ULL << (c % 64);
+    };
+    preset(useL, (size_t)n); preset(useR, (size_t)K);
+    auto first_free = [&](const unsigned long long *a, const unsigned long long *b) {   // first colour free in a (and b)
+        for (size_t q = 0; q < W; ++q) {
+            const unsigned long long m = ~(a[q] | (b ? b[q] : 0ULL));
+            if (m) return (int)(q * 64 + (size_t)__builtin_ctzll(m));
+        }
+        return -1;
+    };
+    auto set_bit = [&](std::vector<unsigned long long> &m, size_t node, int c, bool on) {
+        if (on) m[node * W + (size_t)c / 64] |= 1ULL << (c % 64); else m[node * W + (size_t)c / 64] &= ~(1ULL << (c % 64));
+    };
     std::vector<int> path;
     for (int j = 0; j < n; ++j) {
         pos[(size_t)j].assign(cls[(size_t)j].size(), -1);
         for (int i = 0; i < (int)cls[(size_t)j].size(); ++i) {
             const int u = j, v = cls[(size_t)j][(size_t)i];
-            int a = 0, b = 0;
-            while (atL[(size_t)u * D + (size_t)a] >= 0) ++a;
-            while (atR[(size_t)v * D + (size_t)b] >= 0) ++b;
-            if (atR[(size_t)v * D + (size_t)a] >= 0) {   // a is taken at v: flip the a/b alternating path that starts there
+            int a = first_free(&useL[(size_t)u * W], &useR[(size_t)v * W]);   // free at both ends: no flip needed
+            if (a < 0) {
+                a = first_free(&useL[(size_t)u * W], nullptr);
+                const int b = first_free(&useR[(size_t)v * W], nullptr);
+                // a is taken at v: flip the a/b alternating path that starts there (it cannot reach u, which has no a edge)
                 path.clear();
                 int node = v, c = a, o = b;
                 bool right = true;
@@ -87,20 +107,20 @@ static int colour_group(const std::vector<std::vector<int>> &cls, int K, std::ve
                 }
                 for (int eid : path) {
                     Edge &e = es[(size_t)eid];
-                    atL[(size_t)e.u * D + (size_t)e.c] = -1;
-                    atR[(size_t)e.v * D + (size_t)e.c] = -1;
+                    atL[(size_t)e.u * D + (size_t)e.c] = -1; set_bit(useL, (size_t)e.u, e.c, false);
+                    atR[(size_t)e.v * D + (size_t)e.c] = -1; set_bit(useR, (size_t)e.v, e.c, false);
                 }
                 for (int eid : path) {
                     Edge &e = es[(size_t)eid];
                     e.c = (e.c == a) ? b : a;
-                    atL[(size_t)e.u * D + (size_t)e.c] = eid;
-                    atR[(size_t)e.v * D + (size_t)e.c] = eid;
+                    atL[(size_t)e.u * D + (size_t)e.c] = eid; set_bit(useL, (size_t)e.u, e.c, true);
+                    atR[(size_t)e.v * D + (size_t)e.c] = eid; set_bit(useR, (size_t)e.v, e.c, true);
                 }
             }
             const int eid = (int)es.size();
             es.push_back({u, v, i, a});
-            atL[(size_t)u * D + (size_t)a] = eid;
-            atR[(size_t)v * D + (size_t)a] = eid;
+            atL[(size_t)u * D + (size_t)a] = eid; set_bit(useL, (size_t)u, a, true);
+            atR[(size_t)v * D + (size_t)a] = eid; set_bit(useR, (size_t)v, a, true);
         }
     }
     for (const Edge &e : es) pos[(size_t)e.u][(size_t)e.i] = e.c;
@@ -240,103 +260,130 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
     w[LP_BLK_OFS] = (int32_t)w.size();
     const size_t n_blocks_total = (size_t)hp[0].n_blk + (size_t)hp[1].n_blk;
     w.resize(w.size() + n_blocks_total * LB_WORDS, 0);
-    std::vector<uint16_t> stream;   // all blocks' column streams, 16-byte units
-    std::vector<size_t> stream_ofs16(n_blocks_total, 0);
-    for (int h = 0; h < 2; ++h) {
+    // ---- per (half, row block): chunks, tasks, conflict-free column stream.  Blocks are independent: built by a few host
+    // threads (the plan sits on the perturb-retrain loop: one per injected graph), merged in block order afterwards.
+    struct BlockOut {
+        int32_t row0 = 0, n_rows = 0, n_part = 0, n_tasks = 0;
+        std::vector<int32_t> tasks, dst, pp;
+        std::vector<uint16_t> stream;
+    };
+    std::vector<BlockOut> blocks(n_blocks_total);
+    static const int no_colour = getenv("RK_LDS_NOCOLOUR") ? atoi(getenv("RK_LDS_NOCOLOUR")) : 0;   // tuning: CSR order
+    auto build_block = [&](size_t bi) {
+        const int h = bi < (size_t)hp[0].n_blk ? 0 : 1;
+        const int rb = (int)(bi - (h ? (size_t)hp[0].n_blk : 0));
         const int SL = 64 / hp[h].lp, C = hp[h].chunk;
         const int cls0 = h ? U : 0;           // node id of the first output row of this class
         const int src0 = h ? 0 : U;           // node id of the first source row
         const int n_src = h ? U : I;
-        for (int rb = 0; rb < hp[h].n_blk; ++rb) {
-            const int r_lo = hp[h].bounds[(size_t)rb], r_hi = hp[h].bounds[(size_t)rb + 1];
-            const int n_rows = r_hi - r_lo;
-            std::vector<int32_t> pp((size_t)n_rows + 1, 0);
-            std::vector<Chunk> chunks;
-            for (int r = r_lo; r < r_hi; ++r) {
-                const int b = rp[r], n = rp[r + 1] - b;
-                int ci = 0;
-                for (int o = 0; o < n; o += C, ++ci) {
-                    const int len = std::min(C, n - o);
-                    chunks.push_back({(len + 7) & ~7, len, b + o, pp[(size_t)(r - r_lo)] + ci});
-                }
-                pp[(size_t)(r - r_lo) + 1] = pp[(size_t)(r - r_lo)] + ci;
+        const int r_lo = hp[h].bounds[(size_t)rb], r_hi = hp[h].bounds[(size_t)rb + 1];
+        const int n_rows = r_hi - r_lo;
+        BlockOut &o = blocks[bi];
+        std::vector<int32_t> &pp = o.pp;
+        pp.assign((size_t)n_rows + 1, 0);
+        std::vector<Chunk> chunks;
+        for (int r = r_lo; r < r_hi; ++r) {
+            const int b = rp[r], n = rp[r + 1] - b;
+            int ci = 0;
+            for (int k = 0; k < n; k += C, ++ci) {
+                const int len = std::min(C, n - k);
+                chunks.push_back({(len + 7) & ~7, len, b + k, pp[(size_t)(r - r_lo)] + ci});
             }
-            std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &x, const Chunk &y) { return x.padded > y.padded; });
-            const int n_tasks = (int)((chunks.size() + (size_t)SL - 1) / (size_t)SL);
-            const size_t bi = (size_t)(h ? hp[0].n_blk : 0) + (size_t)rb;
-            int32_t *bd = &w[(size_t)w[LP_BLK_OFS] + bi * LB_WORDS];
-            bd[LB_ROW0] = r_lo - cls0; bd[LB_NROWS] = n_rows; bd[LB_NPART] = pp[(size_t)n_rows]; bd[LB_NTASKS] = n_tasks;
-            // tasks {first stream unit, n blocks}: the int2 array must be 8-byte aligned
-            if (w.size() & 1) w.push_back(0);
-            const size_t task_ofs = w.size();
-            w.resize(w.size() + (size_t)n_tasks * 2, 0);
-            const size_t dst_ofs = w.size();
-            w.resize(w.size() + (size_t)n_tasks * SL, -1);
-            const size_t pp_ofs = w.size();
-            w.insert(w.end(), pp.begin(), pp.end());
-            bd = &w[(size_t)w[LP_BLK_OFS] + bi * LB_WORDS];  // (w may have been reallocated)
-            bd[LB_TASK_OFS] = (int32_t)task_ofs; bd[LB_DST_OFS] = (int32_t)dst_ofs; bd[LB_PP_OFS] = (int32_t)pp_ofs;
-            stream_ofs16[bi] = stream.size() / 8;
-            size_t unit = 0;   // 16-byte units since the block's stream began
-            static const int no_colour = getenv("RK_LDS_NOCOLOUR") ? atoi(getenv("RK_LDS_NOCOLOUR")) : 0;   // tuning: CSR order
-            const int LPh = hp[h].lp, K = 16 / LPh;   // lanes per entry, bank classes (= chunks per 16-lane group)
-            auto zero_row = [&](int klass) { return n_src + ((klass - n_src % K) % K + K) % K; };
-            for (int t = 0; t < n_tasks; ++t) {
-                const size_t c0 = (size_t)t * SL, c1 = std::min(chunks.size(), c0 + (size_t)SL);
-                for (size_t c = c0; c < c1; ++c) w[dst_ofs + (size_t)t * SL + (c - c0)] = chunks[c].pidx;
-                // per 16-lane group: its K slots' entries, ordered so that every wave-instruction reads K different classes
-                std::vector<std::vector<int>> slot_pos((size_t)SL);
-                int longest = 0;
-                std::vector<int> gslots[4];
-                for (int gi = 0; gi < 4; ++gi) {
-                    for (int l = 0; l < 16; ++l) {
-                        const int sl = kB128Group[gi][l] / LPh;
-                        if (gslots[gi].empty() || gslots[gi].back() != sl) gslots[gi].push_back(sl);
-                    }
-                    std::vector<std::vector<int>> cls((size_t)K), pos;
-                    for (int j = 0; j < K; ++j) {
-                        const size_t c = c0 + (size_t)gslots[gi][(size_t)j];
-                        if (c >= c1) continue;
-                        const Chunk &ck = chunks[c];
-                        cls[(size_t)j].resize((size_t)ck.len);
-                        for (int k = 0; k < ck.len; ++k) cls[(size_t)j][(size_t)k] = (col[ck.e_begin + k] - src0) % K;
-                    }
-                    if (no_colour) {
-                        pos.assign((size_t)K, std::vector<int>());
-                        for (int j = 0; j < K; ++j) { pos[(size_t)j].resize(cls[(size_t)j].size()); for (size_t k = 0; k < cls[(size_t)j].size(); ++k) pos[(size_t)j][k] = (int)k; }
-                        for (int j = 0; j < K; ++j) longest = std::max(longest, (int)cls[(size_t)j].size());
-                    } else {
-                        longest = std::max(longest, colour_group(cls, K, pos));
-                    }
-                    for (int j = 0; j < K; ++j) slot_pos[(size_t)gslots[gi][(size_t)j]] = pos[(size_t)j];
-                }
-                const int nb = std::max(1, (longest + 7) / 8);
-                w[task_ofs + (size_t)t * 2] = (int32_t)unit;
-                w[task_ofs + (size_t)t * 2 + 1] = nb;
-                const size_t sbase = stream.size();
-                stream.resize(sbase + (size_t)nb * SL * 8, (uint16_t)0xffff);
-                auto at = [&](int slot, int p) -> uint16_t & { return stream[sbase + ((size_t)(p / 8) * SL + (size_t)slot) * 8 + (size_t)(p % 8)]; };
-                for (size_t c = c0; c < c1; ++c) {
-                    const Chunk &ck = chunks[c];
-                    const int slot = (int)(c - c0);
-                    for (int k = 0; k < ck.len; ++k) at(slot, slot_pos[(size_t)slot][(size_t)k]) = (uint16_t)(col[ck.e_begin + k] - src0);
-                }
-                // padding: the zero row of a class nobody else in the lane group reads at that position
-                for (int gi = 0; gi < 4; ++gi)
-                    for (int p = 0; p < nb * 8; ++p) {
-                        unsigned used = 0;
-                        for (int sl : gslots[gi]) if (at(sl, p) != 0xffff) used |= 1u << (at(sl, p) % K);
-                        for (int sl : gslots[gi]) {
-                            if (at(sl, p) != 0xffff) continue;
-                            int k = 0;
-                            while (k < K - 1 && (used & (1u << k))) ++k;
-                            used |= 1u << k;
-                            at(sl, p) = (uint16_t)zero_row(k);
-                        }
-                    }
-                unit += (size_t)nb * SL;
-            }
+            pp[(size_t)(r - r_lo) + 1] = pp[(size_t)(r - r_lo)] + ci;
         }
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &x, const Chunk &y) { return x.padded > y.padded; });
+        const int n_tasks = (int)((chunks.size() + (size_t)SL - 1) / (size_t)SL);
+        o.row0 = r_lo - cls0; o.n_rows = n_rows; o.n_part = pp[(size_t)n_rows]; o.n_tasks = n_tasks;
+        o.tasks.assign((size_t)n_tasks * 2, 0);
+        o.dst.assign((size_t)n_tasks * SL, -1);
+        std::vector<uint16_t> &stream = o.stream;
+        size_t unit = 0;   // 16-byte units since the block's stream began
+        const int LPh = hp[h].lp, K = 16 / LPh;   // lanes per entry, bank classes (= chunks per 16-lane group)
+        auto zero_row = [&](int klass) { return n_src + ((klass - n_src % K) % K + K) % K; };
+        std::vector<int> gslots[4];
+        for (int gi = 0; gi < 4; ++gi)
+            for (int l = 0; l < 16; ++l) {
+                const int sl = kB128Group[gi][l] / LPh;
+                if (gslots[gi].empty() || gslots[gi].back() != sl) gslots[gi].push_back(sl);
+            }
+        for (int t = 0; t < n_tasks; ++t) {
+            const size_t c0 = (size_t)t * SL, c1 = std::min(chunks.size(), c0 + (size_t)SL);
+            for (size_t c = c0; c < c1; ++c) o.dst[(size_t)t * SL + (c - c0)] = chunks[c].pidx;
+            // per 16-lane group: its K slots' entries, ordered so that every wave-instruction reads K different classes
+            std::vector<std::vector<int>> slot_pos((size_t)SL);
+            int longest = 0;
+            for (int gi = 0; gi < 4; ++gi) {
+                std::vector<std::vector<int>> cls((size_t)K), pos;
+                for (int j = 0; j < K; ++j) {
+                    const size_t c = c0 + (size_t)gslots[gi][(size_t)j];
+                    if (c >= c1) continue;
+                    const Chunk &ck = chunks[c];
+                    cls[(size_t)j].resize((size_t)ck.len);
+                    for (int k = 0; k < ck.len; ++k) cls[(size_t)j][(size_t)k] = (col[ck.e_begin + k] - src0) % K;
+                }
+                if (no_colour) {
+                    pos.assign((size_t)K, std::vector<int>());
+                    for (int j = 0; j < K; ++j) { pos[(size_t)j].resize(cls[(size_t)j].size()); for (size_t k = 0; k < cls[(size_t)j].size(); ++k) pos[(size_t)j][k] = (int)k; }
+                    for (int j = 0; j < K; ++j) longest = std::max(longest, (int)cls[(size_t)j].size());
+                } else {
+                    longest = std::max(longest, colour_group(cls, K, pos));
+                }
+                for (int j = 0; j < K; ++j) slot_pos[(size_t)gslots[gi][(size_t)j]] = pos[(size_t)j];
+            }
+            const int nb = std::max(1, (longest + 7) / 8);
+            o.tasks[(size_t)t * 2] = (int32_t)unit;
+            o.tasks[(size_t)t * 2 + 1] = nb;
+            const size_t sbase = stream.size();
+            stream.resize(sbase + (size_t)nb * SL * 8, (uint16_t)0xffff);
+            auto at = [&](int slot, int p) -> uint16_t & { return stream[sbase + ((size_t)(p / 8) * SL + (size_t)slot) * 8 + (size_t)(p % 8)]; };
+            for (size_t c = c0; c < c1; ++c) {
+                const Chunk &ck = chunks[c];
+                const int slot = (int)(c - c0);
+                for (int k = 0; k < ck.len; ++k) at(slot, slot_pos[(size_t)slot][(size_t)k]) = (uint16_t)(col[ck.e_begin + k] - src0);
+            }
+            // padding: the zero row of a class nobody else in the lane group reads at that position
+            for (int gi = 0; gi < 4; ++gi)
+                for (int p = 0; p < nb * 8; ++p) {
+                    unsigned used = 0;
+                    for (int sl : gslots[gi]) if (at(sl, p) != 0xffff) used |= 1u << (at(sl, p) % K);
+                    for (int sl : gslots[gi]) {
+                        if (at(sl, p) != 0xffff) continue;
+                        int k = 0;
+                        while (k < K - 1 && (used & (1u << k))) ++k;
+                        used |= 1u << k;
+                        at(sl, p) = (uint16_t)zero_row(k);
+                    }
+                }
+            unit += (size_t)nb * SL;
+        }
+    };
+    {
+        static const int env_threads = getenv("RK_LDS_PLAN_THREADS") ? atoi(getenv("RK_LDS_PLAN_THREADS")) : 0;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t n_threads = std::min<size_t>(n_blocks_total, env_threads > 0 ? (size_t)env_threads : std::min<unsigned>(hw, 16u));
+        std::atomic<size_t> next(0);
+        auto worker = [&]() { for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi); };
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    std::vector<uint16_t> stream;   // all blocks' column streams, 16-byte units
+    std::vector<size_t> stream_ofs16(n_blocks_total, 0);
+    for (size_t bi = 0; bi < n_blocks_total; ++bi) {
+        const BlockOut &o = blocks[bi];
+        if (w.size() & 1) w.push_back(0);   // the int2 task array must be 8-byte aligned
+        const size_t task_ofs = w.size();
+        w.insert(w.end(), o.tasks.begin(), o.tasks.end());
+        const size_t dst_ofs = w.size();
+        w.insert(w.end(), o.dst.begin(), o.dst.end());
+        const size_t pp_ofs = w.size();
+        w.insert(w.end(), o.pp.begin(), o.pp.end());
+        int32_t *bd = &w[(size_t)w[LP_BLK_OFS] + bi * LB_WORDS];
+        bd[LB_ROW0] = o.row0; bd[LB_NROWS] = o.n_rows; bd[LB_NPART] = o.n_part; bd[LB_NTASKS] = o.n_tasks;
+        bd[LB_TASK_OFS] = (int32_t)task_ofs; bd[LB_DST_OFS] = (int32_t)dst_ofs; bd[LB_PP_OFS] = (int32_t)pp_ofs;
+        stream_ofs16[bi] = stream.size() / 8;
+        stream.insert(stream.end(), o.stream.begin(), o.stream.end());
     }
     w[LP_DINV_OFS] = (int32_t)w.size();
     w.resize(w.size() + (size_t)N);

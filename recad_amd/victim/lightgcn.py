@@ -134,7 +134,6 @@ class LightGCN(BaseVictim):
         self._drop_handle()
         g = self._csr(dev)
         N, d = self.num_users + self.num_items, self.latent_dim
-        wave_desc, n_blocks = g.schedule(d)
         ws = {k: torch.zeros(N, d, device=dev, dtype=torch.float32) for k in ("buf_a", "buf_b", "light", "gprop", "gego")}
         ws["grad"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if want_grad else None
         ws["state"] = torch.zeros(16, device=dev, dtype=torch.int32)
@@ -143,13 +142,15 @@ class LightGCN(BaseVictim):
         if self.graph_dropout and self._drop_seed is None:
             self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ws["tpos"] = g.transpose_index() if self.graph_dropout else None
-        ws["spmm_scratch"] = g.new_scratch(d)  # this handle's own long-row counters / partial slots
         # LDS-resident sliced propagation (csrc/spmm_lds.h) when the graph qualifies: bipartite normalised binary adjacency
         # whose class tables fit a CU's LDS (ml1m / Amazon-game size); RK_LDS_OFF=1 keeps the row-gather kernel (A/B)
         lds = None
         if self.use_lds and self.n_layers >= 1 and not self.graph_dropout and not os.environ.get("RK_LDS_OFF"):
             lds = g.lds_plan(d)
         ws["lds"] = lds
+        # the row-gather kernel's schedule (host-built) only when this handle will launch it
+        wave_desc, n_blocks = (None, 0) if lds else g.schedule(d)
+        ws["spmm_scratch"] = None if lds else g.new_scratch(d)  # this handle's own long-row counters / partial slots
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
         for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
