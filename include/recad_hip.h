@@ -98,6 +98,10 @@ typedef struct rk_spmm_epilogue {
     float *zero1, *zero2;
     float *adam_p, *adam_m, *adam_v, *coef_scratch;
     float lr, beta1, beta2, eps;
+    /* optional frontier of the gather operand: device uint32 bitmap over x's rows, bit c clear => x[c] is all zeros and
+     * the entries (r, c) are skipped (first backward layer of a train step: x = dL/dlight is non-zero on the minibatch's
+     * rows only).  Same sums, bit for bit; NULL = gather everything.  rk_rows_mark_bits sets / clears the bits. */
+    const uint32_t *src_filter;
 } rk_spmm_epilogue;
 int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
                    const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
@@ -148,6 +152,14 @@ typedef struct rk_lds_epilogue {
     uint64_t *stamps;   /* diagnostic, nullable: device uint64[4 * n_wg], wall-clock stamps (start, staged, gathered, done) per workgroup */
 } rk_lds_epilogue;
 int rk_spmm_lds(const rk_lds_info *info, const int32_t *plan, const float *x, const rk_lds_epilogue *epi, void *stream);
+
+/* The row-sharded trainer's per-step index work (the reference's getEmbedding gathers, lightgcn.py:122-130, split over ranks):
+ * out[i, :] = mask[i] * src[idx[i], :] (mask NULL = 1; a zero mask entry gives exact zeros), and a[idx[i], :] = b[idx[i], :] = 0
+ * (b nullable).  idx: device int64[n]. */
+int rk_rows_gather_masked(int32_t dim, const float *src, const int64_t *idx, const float *mask, int64_t n, float *out, void *stream);
+int rk_rows_zero(int32_t dim, float *a, float *b, const int64_t *idx, int64_t n, void *stream);
+/* bits[idx[i] >> 5] |= 1 << (idx[i] & 31) (set != 0), or the words holding those bits = 0 (set == 0) */
+int rk_rows_mark_bits(uint32_t *bits, const int64_t *idx, int64_t n, int32_t set, void *stream);
 
 /* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
  * index emb/gprop/gego directly (item rows already offset), and light too unless light_compact != 0:

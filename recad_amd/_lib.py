@@ -76,6 +76,7 @@ class SpmmEpilogue(C.Structure):
         ("sum_scale", C.c_float), ("adam_t", C.c_int32), ("zero1", C.c_void_p), ("zero2", C.c_void_p),
         ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("coef_scratch", C.c_void_p),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("src_filter", C.c_void_p),
     ]
 
 
@@ -118,6 +119,9 @@ _SIGNATURES = {
     "rk_lds_pack": [C.POINTER(LdsInfo), _P, _P, _I32, _I64, _P],
     "rk_lds_unpack": [C.POINTER(LdsInfo), _P, _P, _I32, _I64, _P],
     "rk_spmm_lds": [C.POINTER(LdsInfo), _P, _P, C.POINTER(LdsEpilogue), _P],
+    "rk_rows_gather_masked": [_I32, _P, _P, _P, _I64, _P, _P],
+    "rk_rows_zero": [_I32, _P, _P, _P, _I64, _P],
+    "rk_rows_mark_bits": [_P, _P, _I64, _I32, _P],
     "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_bpr_rows_ordered": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],

@@ -921,6 +921,7 @@ RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_
     a.scratch = scratch;
     a.e.add = epi->add; a.e.y = epi->y; a.e.sum_in = epi->sum_in; a.e.sum_out = epi->sum_out; a.e.sum_scale = epi->sum_scale;
     a.e.zero1 = epi->zero1; a.e.zero2 = epi->zero2;
+    a.src_filter = epi->src_filter;
     if (epi->sum_out && !epi->sum_in) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: sum_out needs sum_in");
     if (epi->adam_t > 0) {
         if (!epi->adam_p || !epi->adam_m || !epi->adam_v || !epi->coef_scratch) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: Adam pointers missing");

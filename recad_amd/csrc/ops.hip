@@ -410,6 +410,67 @@ RK_EXPORT int rk_pair_scores(int32_t dim, const float *utab, const float *itab, 
     return RK_OK;
 }
 
+// ---- row gather / row zero (the row-sharded trainer's per-step index work)
+__global__ void rows_gather_masked_kernel(int d, const float *__restrict__ src, const int64_t *__restrict__ idx,
+                                          const float *__restrict__ mask, long long n, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long i = wave; i < n; i += n_waves) {
+        const float m = mask ? mask[i] : 1.f;
+        const float *row = src + (size_t)idx[i] * d;
+        for (int k = lane; k < d; k += 64) out[(size_t)i * d + k] = m != 0.f ? row[k] * m : 0.f;
+    }
+}
+
+__global__ void rows_zero_kernel(int d, float *__restrict__ a, float *__restrict__ b, const int64_t *__restrict__ idx, long long n)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long i = wave; i < n; i += n_waves) {
+        const size_t o = (size_t)idx[i] * d;
+        for (int k = lane; k < d; k += 64) { a[o + k] = 0.f; if (b) b[o + k] = 0.f; }
+    }
+}
+
+__global__ void rows_mark_bits_kernel(unsigned *bits, const int64_t *__restrict__ idx, long long n, int set)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx[i];
+        if (set) atomicOr(&bits[r >> 5], 1u << (r & 31)); else bits[r >> 5] = 0u;
+    }
+}
+
+RK_EXPORT int rk_rows_mark_bits(uint32_t *bits, const int64_t *idx, int64_t n, int32_t set, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (!bits || !idx) RK_FAIL(RK_EINVAL, "rk_rows_mark_bits: bad arguments");
+    hipLaunchKernelGGL(rows_mark_bits_kernel, dim3((int)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, bits, idx,
+                       (long long)n, (int)set);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+RK_EXPORT int rk_rows_gather_masked(int32_t dim, const float *src, const int64_t *idx, const float *mask, int64_t n, float *out, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (dim <= 0 || !src || !idx || !out) RK_FAIL(RK_EINVAL, "rk_rows_gather_masked: bad arguments");
+    const int grid = (int)std::min<long long>((n + 3) / 4, 4096);
+    hipLaunchKernelGGL(rows_gather_masked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dim, src, idx, mask, (long long)n, out);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+RK_EXPORT int rk_rows_zero(int32_t dim, float *a, float *b, const int64_t *idx, int64_t n, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (dim <= 0 || !a || !idx) RK_FAIL(RK_EINVAL, "rk_rows_zero: bad arguments");
+    const int grid = (int)std::min<long long>((n + 3) / 4, 4096);
+    hipLaunchKernelGGL(rows_zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dim, a, b, idx, (long long)n);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
 RK_EXPORT int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,
                           const int32_t *wave_desc, int32_t n_blocks, int32_t *scratch, int32_t dim, const float *x,
                           const float *add, float *y, void *stream)

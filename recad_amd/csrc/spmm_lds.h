@@ -34,7 +34,7 @@ __host__ __device__ __forceinline__ size_t sl_off(const LdsDims &g, int r, int k
 // plan buffer (device int32 words), header words
 enum {
     LP_MAGIC = 0, LP_NWG, LP_U, LP_I, LP_D, LP_LSU, LP_LSI, LP_NBLK0, LP_NBLK1, LP_WG_OFS, LP_BLK_OFS, LP_DINV_OFS,
-    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_HDR_WORDS = 32
+    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_HDR_WORDS = 32
 };
 static constexpr int kLdsMagic = 0x4c445331;  // "LDS1"
 // block descriptor words (one per (half, row block), shared by all slices)
@@ -103,6 +103,9 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
     // the source class's slice table: n_src * S contiguous floats
     const float4 *s4 = reinterpret_cast<const float4 *>(a.x + (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S);
     const int n4 = n_src * LP;
+    // LDS row of source row c: sources sorted by degree are dealt round-robin over the 16 / LP bank classes, so the hot
+    // columns (an item half the users rated) do not pile up in one class of every lane group
+    const int *perm = plan + plan[half ? LP_PERM1 : LP_PERM0];
     const int n_tasks = bd[LB_NTASKS];
     const int2 *tasks = reinterpret_cast<const int2 *>(plan + bd[LB_TASK_OFS]);
     const int *dstv = plan + bd[LB_DST_OFS];
@@ -144,15 +147,16 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
     for (int i0 = tid; i0 < n4; i0 += kLdsThreads * UN) {
         float4 v[UN];
         float s[UN];
+        int pr[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * kLdsThreads;
-            if (i < n4) { v[u] = s4[i]; s[u] = dsrc[i / LP]; }
+            if (i < n4) { v[u] = s4[i]; s[u] = dsrc[i / LP]; pr[u] = perm[i / LP]; }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * kLdsThreads;
-            if (i < n4) tab[i] = f4_scale(v[u], s[u]);
+            if (i < n4) tab[pr[u] * LP + i % LP] = f4_scale(v[u], s[u]);
         }
     }
     if (tid < 16) tab[n4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding entries' rows

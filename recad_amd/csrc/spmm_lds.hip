@@ -163,7 +163,9 @@ static bool choose_half(const int32_t *rp, int row_lo, int row_hi, int n_src, in
         if (table >= limit) continue;
         for (int C : kC) {
             if (force_c && C != force_c) continue;
-            const int mp = std::max(1, max_partials(rp, bounds, C));
+            // every chunk gets one partial slot per piece of its group
+            static const int sub2 = getenv("RK_LDS_SUB") ? atoi(getenv("RK_LDS_SUB")) : 0;
+            const int mp = std::max(1, max_partials(rp, bounds, C)) * (sub2 == 2 ? 2 : 1);
             const int SL = 256 / S;                                        // chunks per task
             const long long task_bytes = (((mp + SL - 1) / SL + 1) / 2 + 1) * 16;   // descriptors staged in front of the table
             const long long need = task_bytes + table + (long long)mp * S * 4;
@@ -257,6 +259,42 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
             ++taken[x];
         }
     }
+    // ---- LDS row of every source row.  Identity, except that the kHot highest-degree sources are dealt round-robin over
+    // the 16 / LP bank classes (each swaps rows with a cold source that sits in the wanted class): an item that half the
+    // users rated would otherwise load its class in every lane group.  Cold rows keep their natural order, so the staging
+    // writes of consecutive rows stay conflict-free.
+    std::vector<int32_t> perm[2];
+    static const int no_perm = getenv("RK_LDS_NOPERM") ? atoi(getenv("RK_LDS_NOPERM")) : 0;   // tuning: identity
+    static const int hot_env = getenv("RK_LDS_HOT") ? atoi(getenv("RK_LDS_HOT")) : 0;
+    for (int h = 0; h < 2; ++h) {
+        const int n_src = h ? U : I, src0 = h ? 0 : U, K = 16 / hp[h].lp;
+        perm[h].resize((size_t)n_src);
+        for (int c = 0; c < n_src; ++c) perm[h][(size_t)c] = c;
+        const int kHot = no_perm ? 0 : std::min(n_src / 2, hot_env > 0 ? hot_env : 512);
+        if (kHot > 0) {
+            std::vector<int32_t> order((size_t)n_src);
+            for (int c = 0; c < n_src; ++c) order[(size_t)c] = c;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rp[src0 + x + 1] - rp[src0 + x] > rp[src0 + y + 1] - rp[src0 + y]; });
+            std::vector<char> hot((size_t)n_src, 0);
+            for (int k = 0; k < kHot; ++k) hot[(size_t)order[(size_t)k]] = 1;
+            std::vector<int32_t> owner((size_t)n_src);   // source currently stored in LDS row q
+            for (int c = 0; c < n_src; ++c) owner[(size_t)c] = c;
+            std::vector<int> cursor((size_t)K, 0);        // next candidate row of each class (rows q = class, class + K, ...)
+            for (int k = 0; k < kHot; ++k) {
+                const int c = order[(size_t)k], want = k % K;
+                if (perm[h][(size_t)c] % K == want) continue;
+                int q = want + cursor[(size_t)want] * K;
+                while (q < n_src && hot[(size_t)owner[(size_t)q]]) { ++cursor[(size_t)want]; q = want + cursor[(size_t)want] * K; }
+                if (q >= n_src) continue;
+                ++cursor[(size_t)want];
+                const int other = owner[(size_t)q], mine = perm[h][(size_t)c];
+                perm[h][(size_t)c] = q; owner[(size_t)q] = c;
+                perm[h][(size_t)other] = mine; owner[(size_t)mine] = other;
+            }
+        }
+        w[h ? LP_PERM1 : LP_PERM0] = (int32_t)w.size();
+        w.insert(w.end(), perm[h].begin(), perm[h].end());
+    }
     w[LP_BLK_OFS] = (int32_t)w.size();
     const size_t n_blocks_total = (size_t)hp[0].n_blk + (size_t)hp[1].n_blk;
     w.resize(w.size() + n_blocks_total * LB_WORDS, 0);
@@ -284,18 +322,26 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
         std::vector<Chunk> chunks;
         for (int r = r_lo; r < r_hi; ++r) {
             const int b = rp[r], n = rp[r + 1] - b;
+            // ceil(n / C) chunks of (almost) equal length: fewer short leftovers than full chunks + a remainder
+            static const int even_env = getenv("RK_LDS_EVEN") ? atoi(getenv("RK_LDS_EVEN")) : 1;
+            const int n_ch = (n + C - 1) / C;
             int ci = 0;
-            for (int k = 0; k < n; k += C, ++ci) {
-                const int len = std::min(C, n - k);
+            for (int k = 0; ci < n_ch; ++ci) {
+                const int len = even_env ? (int)(((long long)n * (ci + 1)) / n_ch - ((long long)n * ci) / n_ch) : std::min(C, n - k);
                 chunks.push_back({(len + 7) & ~7, len, b + k, pp[(size_t)(r - r_lo)] + ci});
+                k += len;
             }
             pp[(size_t)(r - r_lo) + 1] = pp[(size_t)(r - r_lo)] + ci;
         }
         std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &x, const Chunk &y) { return x.padded > y.padded; });
-        const int n_tasks = (int)((chunks.size() + (size_t)SL - 1) / (size_t)SL);
-        o.row0 = r_lo - cls0; o.n_rows = n_rows; o.n_part = pp[(size_t)n_rows]; o.n_tasks = n_tasks;
-        o.tasks.assign((size_t)n_tasks * 2, 0);
-        o.dst.assign((size_t)n_tasks * SL, -1);
+        // A "group" = SL chunks walked together (one per lane slot) and coloured jointly; it is executed as pieces of at
+        // most half its 8-entry blocks -- the tasks the waves pop -- each with its own partial-sum slot per chunk, so that the
+        // sixteen waves of the workgroup finish within a few blocks of each other (whole groups as tasks left a quarter
+        // of the waves idle behind the last long ones).
+        static const int sub_env = getenv("RK_LDS_SUB") ? atoi(getenv("RK_LDS_SUB")) : 0;   // tuning: 2 = split groups in two
+        const int kMaxPieces = sub_env == 2 ? 2 : 1;   // (measured: pieces cost the row phase more than the balance gains -- off)
+        const int n_groups = (int)((chunks.size() + (size_t)SL - 1) / (size_t)SL);
+        o.row0 = r_lo - cls0; o.n_rows = n_rows;
         std::vector<uint16_t> &stream = o.stream;
         size_t unit = 0;   // 16-byte units since the block's stream began
         const int LPh = hp[h].lp, K = 16 / LPh;   // lanes per entry, bank classes (= chunks per 16-lane group)
@@ -306,9 +352,37 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
                 const int sl = kB128Group[gi][l] / LPh;
                 if (gslots[gi].empty() || gslots[gi].back() != sl) gslots[gi].push_back(sl);
             }
-        for (int t = 0; t < n_tasks; ++t) {
+        struct Piece { int32_t unit, nb, group, part; };
+        std::vector<Piece> pieces;
+        std::vector<int> group_parts((size_t)n_groups, 0);
+        for (int t = 0; t < n_groups; ++t) {
             const size_t c0 = (size_t)t * SL, c1 = std::min(chunks.size(), c0 + (size_t)SL);
-            for (size_t c = c0; c < c1; ++c) o.dst[(size_t)t * SL + (c - c0)] = chunks[c].pidx;
+            // Which of the group's chunks share a 16-lane group is free: deal them greedily so that no bank class of a lane
+            // group collects many more entries than the chunks are long (the colouring needs max(longest chunk, fullest
+            // class) positions).  The chunks are swapped inside [c0, c1): slot = position in the sorted list.
+            if (!no_colour && c1 - c0 == (size_t)SL) {
+                int hist[64 * 16], load[4 * 16], n_mem[4] = {0, 0, 0, 0};
+                size_t members[4][16];
+                memset(hist, 0, sizeof(hist));
+                memset(load, 0, sizeof(load));
+                for (size_t c = c0; c < c1; ++c)
+                    for (int k = 0; k < chunks[c].len; ++k) ++hist[(c - c0) * 16 + (size_t)(perm[h][(size_t)(col[chunks[c].e_begin + k] - src0)] % K)];
+                for (size_t c = c0; c < c1; ++c) {
+                    int best = -1, best_cost = 0;
+                    for (int gi = 0; gi < 4; ++gi) {
+                        if (n_mem[gi] >= K) continue;
+                        int cost = 0;
+                        for (int k = 0; k < K; ++k) cost = std::max(cost, load[gi * 16 + k] + hist[(c - c0) * 16 + (size_t)k]);
+                        if (best < 0 || cost < best_cost) { best = gi; best_cost = cost; }
+                    }
+                    members[best][n_mem[best]++] = c;
+                    for (int k = 0; k < K; ++k) load[best * 16 + k] += hist[(c - c0) * 16 + (size_t)k];
+                }
+                std::vector<Chunk> placed(c1 - c0);
+                for (int gi = 0; gi < 4; ++gi)
+                    for (int j = 0; j < K; ++j) placed[(size_t)gslots[gi][(size_t)j]] = chunks[members[gi][j]];
+                std::copy(placed.begin(), placed.end(), chunks.begin() + (long)c0);
+            }
             // per 16-lane group: its K slots' entries, ordered so that every wave-instruction reads K different classes
             std::vector<std::vector<int>> slot_pos((size_t)SL);
             int longest = 0;
@@ -319,7 +393,7 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
                     if (c >= c1) continue;
                     const Chunk &ck = chunks[c];
                     cls[(size_t)j].resize((size_t)ck.len);
-                    for (int k = 0; k < ck.len; ++k) cls[(size_t)j][(size_t)k] = (col[ck.e_begin + k] - src0) % K;
+                    for (int k = 0; k < ck.len; ++k) cls[(size_t)j][(size_t)k] = perm[h][(size_t)(col[ck.e_begin + k] - src0)] % K;
                 }
                 if (no_colour) {
                     pos.assign((size_t)K, std::vector<int>());
@@ -331,15 +405,13 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
                 for (int j = 0; j < K; ++j) slot_pos[(size_t)gslots[gi][(size_t)j]] = pos[(size_t)j];
             }
             const int nb = std::max(1, (longest + 7) / 8);
-            o.tasks[(size_t)t * 2] = (int32_t)unit;
-            o.tasks[(size_t)t * 2 + 1] = nb;
             const size_t sbase = stream.size();
             stream.resize(sbase + (size_t)nb * SL * 8, (uint16_t)0xffff);
             auto at = [&](int slot, int p) -> uint16_t & { return stream[sbase + ((size_t)(p / 8) * SL + (size_t)slot) * 8 + (size_t)(p % 8)]; };
             for (size_t c = c0; c < c1; ++c) {
                 const Chunk &ck = chunks[c];
                 const int slot = (int)(c - c0);
-                for (int k = 0; k < ck.len; ++k) at(slot, slot_pos[(size_t)slot][(size_t)k]) = (uint16_t)(col[ck.e_begin + k] - src0);
+                for (int k = 0; k < ck.len; ++k) at(slot, slot_pos[(size_t)slot][(size_t)k]) = (uint16_t)perm[h][(size_t)(col[ck.e_begin + k] - src0)];
             }
             // padding: the zero row of a class nobody else in the lane group reads at that position
             for (int gi = 0; gi < 4; ++gi)
@@ -354,7 +426,45 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
                         at(sl, p) = (uint16_t)zero_row(k);
                     }
                 }
+            // two pieces of about equal length once a group is at least four blocks long
+            const int np = (nb >= 4) ? kMaxPieces : 1;
+            group_parts[(size_t)t] = np;
+            for (int q = 0; q < np; ++q) {
+                const int b0 = (int)((long long)nb * q / np), b1 = (int)((long long)nb * (q + 1) / np);
+                pieces.push_back({(int32_t)(unit + (size_t)b0 * SL), b1 - b0, t, q});
+            }
             unit += (size_t)nb * SL;
+        }
+        // partial-sum slots: row by row, chunk by chunk (CSR order), piece by piece -- the order phase 3 adds them in
+        std::vector<int32_t> chunk_first(chunks.size(), 0);   // first slot of chunk (sorted index)
+        {
+            std::vector<int32_t> by_pidx(chunks.size(), 0);    // sorted index of the chunk with row-order index pidx
+            for (size_t c = 0; c < chunks.size(); ++c) by_pidx[(size_t)chunks[c].pidx] = (int32_t)c;
+            int32_t next = 0;
+            size_t ci = 0;
+            for (int lr = 0; lr < n_rows; ++lr) {
+                const int32_t n_ch = pp[(size_t)lr + 1] - pp[(size_t)lr];
+                pp[(size_t)lr] = next;
+                for (int32_t k = 0; k < n_ch; ++k, ++ci) {
+                    const size_t c = (size_t)by_pidx[ci];
+                    chunk_first[c] = next;
+                    next += group_parts[c / (size_t)SL];
+                }
+            }
+            pp[(size_t)n_rows] = next;
+            o.n_part = next;
+        }
+        std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.nb > y.nb; });   // longest first
+        const int n_tasks = (int)pieces.size();
+        o.n_tasks = n_tasks;
+        o.tasks.assign((size_t)n_tasks * 2, 0);
+        o.dst.assign((size_t)n_tasks * SL, -1);
+        for (int t = 0; t < n_tasks; ++t) {
+            const Piece &pc = pieces[(size_t)t];
+            o.tasks[(size_t)t * 2] = pc.unit;
+            o.tasks[(size_t)t * 2 + 1] = pc.nb;
+            const size_t c0 = (size_t)pc.group * SL, c1 = std::min(chunks.size(), c0 + (size_t)SL);
+            for (size_t c = c0; c < c1; ++c) o.dst[(size_t)t * SL + (c - c0)] = chunk_first[c] + pc.part;
         }
     };
     {

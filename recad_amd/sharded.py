@@ -75,11 +75,13 @@ class RowLayout:
         return lo, lo + self.Mc
 
 
-def build_slab_chunks(rowptr, col, val, rank, layout):
+def build_slab_chunks(rowptr, col, val, rank, layout, tiled=False):
     """CSR slabs (one per chunk) of the rows owned by `rank`, columns in the gathered layout, entry order
     inside a row unchanged.  Inputs: host arrays or torch tensors (any device); the work is vectorised
     (repeat / cumsum / gather), on the inputs' device.  Returns a list of (rowptr int32[Mc+1], col int32,
-    val float32) torch tensors."""
+    val float32) torch tensors -- or, tiled, a list of lists: entry [c][k] holds the entries of row chunk c
+    whose columns lie in gathered chunk k (positions [k W Mc, (k+1) W Mc)), entry order inside a tile row
+    unchanged, so that y_c = sum_k tile[c][k] . x can start on the column blocks that have arrived."""
     rp = torch.as_tensor(rowptr).long()
     cl = torch.as_tensor(col)
     vl = torch.as_tensor(val)
@@ -102,7 +104,24 @@ def build_slab_chunks(rowptr, col, val, rank, layout):
     out = []
     for c in range(L.C):
         a, b = int(lp[c * L.Mc].item()), int(lp[(c + 1) * L.Mc].item())
-        out.append(((lp[c * L.Mc:(c + 1) * L.Mc + 1] - a).to(torch.int32).contiguous(), c_new[a:b].contiguous(), v_new[a:b].contiguous()))
+        if not tiled:
+            out.append(((lp[c * L.Mc:(c + 1) * L.Mc + 1] - a).to(torch.int32).contiguous(), c_new[a:b].contiguous(), v_new[a:b].contiguous()))
+            continue
+        cc, vv = c_new[a:b], v_new[a:b]
+        rows_c = (row_of[a:b] - c * L.Mc)
+        blk = cc.long() // (L.W * L.Mc)                                  # source chunk of every entry
+        order = torch.argsort(blk * L.Mc + rows_c, stable=True)          # by (block, row), entry order kept inside
+        cnt = torch.bincount(blk * L.Mc + rows_c, minlength=L.C * L.Mc).view(L.C, L.Mc)
+        cs, vs = cc[order], vv[order]
+        start = 0
+        tiles = []
+        for k in range(L.C):
+            rp_k = torch.zeros(L.Mc + 1, dtype=torch.long, device=dev)
+            rp_k[1:] = torch.cumsum(cnt[k], 0)
+            nk = int(rp_k[-1].item())
+            tiles.append((rp_k.to(torch.int32).contiguous(), cs[start:start + nk].contiguous(), vs[start:start + nk].contiguous()))
+            start += nk
+        out.append(tiles)
     return out
 
 
@@ -132,23 +151,50 @@ class HipOps:
             slab["sched"][dim] = (desc, int(n_blocks.value), scratch)   # the slab is this trainer's own: one stream
         return slab["sched"][dim]
 
-    def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None):
+    def spmm(self, slab, x, add=None, y=None, sum_in=None, sum_out=None, sum_scale=1.0, adam=None, src_filter=None):
         if slab["col"].numel() == 0 and slab["n_rows"] == 0:
             return
-        if slab["col"].numel() == 0:
-            # a chunk made of padding rows only (n_rows > 0, no nonzeros -- a user-chosen chunk count on a small slab):
-            # the launch needs col / val pointers, so give it one unused zero entry
-            slab = dict(slab, col=torch.zeros(1, dtype=torch.int32, device=x.device), val=torch.zeros(1, dtype=torch.float32, device=x.device))
-        e = _lib.SpmmEpilogue(add=_lib.ptr(add), y=_lib.ptr(y), sum_in=_lib.ptr(sum_in), sum_out=_lib.ptr(sum_out),
-                              sum_scale=float(sum_scale))
+        # A step repeats the same launches on the same persistent buffers: the marshalled argument list of every distinct
+        # (slab, operands) combination is built once and replayed (the step is host-bound on small graphs: 2 L C^2 launches)
+        dp = lambda t: 0 if t is None else t.data_ptr()
+        key = (id(slab), dp(x), dp(add), dp(y), dp(sum_in), dp(sum_out), float(sum_scale), dp(src_filter),
+               None if adam is None else (dp(adam["p"]), dp(adam["m"]), dp(adam["v"])))
+        memo = self.__dict__.setdefault("_calls", {})
+        call = memo.get(key)
+        if call is None:
+            if slab["col"].numel() == 0:
+                # a chunk / tile without nonzeros (n_rows > 0): the launch needs col / val pointers, so give it one unused zero entry
+                slab = dict(slab, col=torch.zeros(1, dtype=torch.int32, device=x.device), val=torch.zeros(1, dtype=torch.float32, device=x.device))
+            e = _lib.SpmmEpilogue(add=_lib.ptr(add), y=_lib.ptr(y), sum_in=_lib.ptr(sum_in), sum_out=_lib.ptr(sum_out),
+                                  sum_scale=float(sum_scale), src_filter=_lib.ptr(src_filter))
+            if adam is not None:
+                e.adam_p, e.adam_m, e.adam_v = _lib.ptr(adam["p"]), _lib.ptr(adam["m"]), _lib.ptr(adam["v"])
+                e.coef_scratch = _lib.ptr(slab["coef"])
+                e.lr, e.beta1, e.beta2, e.eps = adam["lr"], adam["b1"], adam["b2"], adam["eps"]
+            desc, n_blocks, scratch = self._sched(slab, x.shape[1])
+            args = (slab["n_rows"], _lib.ptr(slab["rowptr"]), _lib.ptr(slab["col"]), _lib.ptr(slab["val"]), _lib.ptr(desc), n_blocks,
+                    _lib.ptr(scratch), x.shape[1], _lib.ptr(x), x.shape[0], C.byref(e))
+            call = memo[key] = (args, e, (slab, desc, scratch, x, add, y, sum_in, sum_out, adam, src_filter))   # (keeps the tensors alive)
+        args, e, _ = call
         if adam is not None:
-            e.adam_t, e.adam_p, e.adam_m, e.adam_v = adam["t"], _lib.ptr(adam["p"]), _lib.ptr(adam["m"]), _lib.ptr(adam["v"])
-            e.coef_scratch = _lib.ptr(slab["coef"])
+            e.adam_t = adam["t"]
             e.lr, e.beta1, e.beta2, e.eps = adam["lr"], adam["b1"], adam["b2"], adam["eps"]
-        desc, n_blocks, scratch = self._sched(slab, x.shape[1])
-        _lib.check(_lib.lib().rk_spmm_csr_ex(slab["n_rows"], _lib.ptr(slab["rowptr"]), _lib.ptr(slab["col"]), _lib.ptr(slab["val"]),
-                                             _lib.ptr(desc), n_blocks, _lib.ptr(scratch), x.shape[1], _lib.ptr(x), x.shape[0],
-                                             C.byref(e), _lib.stream_ptr()), "rk_spmm_csr_ex")
+        _lib.check(_lib.lib().rk_spmm_csr_ex(*args, _lib.stream_ptr()), "rk_spmm_csr_ex")
+
+    def gather_rows(self, src, idx, mask, out):
+        """out[i] = mask[i] * src[idx[i]] (mask None = 1): the minibatch's light rows this rank owns, zeros elsewhere."""
+        _lib.check(_lib.lib().rk_rows_gather_masked(src.shape[1], _lib.ptr(src), _lib.ptr(idx), _lib.ptr(mask), idx.numel(), _lib.ptr(out),
+                                                    _lib.stream_ptr()), "rk_rows_gather_masked")
+
+    def zero_rows(self, a, b, idx):
+        _lib.check(_lib.lib().rk_rows_zero(a.shape[1], _lib.ptr(a), _lib.ptr(b), _lib.ptr(idx), idx.numel(), _lib.stream_ptr()), "rk_rows_zero")
+
+    def new_row_bits(self, n_rows, device):
+        return torch.zeros((n_rows + 31) // 32, dtype=torch.int32, device=device)
+
+    def mark_rows(self, bits, idx, on):
+        """frontier bitmap of the first backward layer: set the bits of the minibatch's gathered rows / clear their words"""
+        _lib.check(_lib.lib().rk_rows_mark_bits(_lib.ptr(bits), _lib.ptr(idx), idx.numel(), 1 if on else 0, _lib.stream_ptr()), "rk_rows_mark_bits")
 
     def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials, keys=None):
         """light_rows: compact [3*nb, d] (users, positives, negatives of the minibatch, in that order);
@@ -186,7 +232,7 @@ class ShardedLightGCN:
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective", force_collectives=False,
-                 deterministic=False):
+                 deterministic=False, overlap=None):
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -216,23 +262,45 @@ class ShardedLightGCN:
             rowptr, col, val = csr.rowptr, csr.col, csr.val
         else:
             rowptr, col, val = csr
-        self.slabs = [self.ops.make_slab(rp, c, v, self.device) for rp, c, v in build_slab_chunks(rowptr, col, val, self.rank, self.layout)]
+        # Consumer-side overlap (SURVEY 8e "SpMM on already-arrived column blocks"): every row chunk's slab is tiled by source
+        # chunk and a layer runs source chunk by source chunk, chaining the partial sums through the SpMM's `add` epilogue, so
+        # layer l+1 starts on the column blocks whose all-gather has completed while the last chunk of layer l is still in
+        # flight.  Off for one chunk, and in deterministic mode (the tiled sum is not in CSR order, so the tables would stop
+        # being bit-identical across world sizes).
+        if overlap is None:
+            overlap = "consumer" if (self.layout.C > 1 and not deterministic) else "producer"
+        if overlap not in ("consumer", "producer"):
+            raise ValueError("overlap must be 'consumer' or 'producer'")
+        self.tiled = overlap == "consumer" and self.layout.C > 1
+        built = build_slab_chunks(rowptr, col, val, self.rank, self.layout, tiled=self.tiled)
+        if self.tiled:
+            self.tiles = [[self.ops.make_slab(rp, c, v, self.device) for rp, c, v in row] for row in built]
+            self.slabs = None
+        else:
+            self.slabs = [self.ops.make_slab(rp, c, v, self.device) for rp, c, v in built]
+            self.tiles = [[sl] for sl in self.slabs]
         dev, M, W, d = self.device, self.layout.M, self.world, self.d
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.e0, self.m, self.v = z(M, d), z(M, d), z(M, d)
         self.xfull = [z(W * M, d) for _ in range(2)]      # gathered X_l / t_j (ping-pong)
         self.e0_full = z(W * M, d)
         self.y, self.s = z(M, d), z(M, d)
+        self.ybuf = [self.y, z(M, d)] if self.tiled else [self.y, self.y]   # tiled: a layer's output is still being gathered while the next one accumulates
+        self._ysel = 0
         self.gprop, self.gego = z(W * M, d), z(W * M, d)  # replicated, zero outside a step
         self.t = 0
         self._plan = None
+        self._src_filter = None
+        # frontier bitmap over the gathered rows (first backward layer); ops without it (the CPU stand-in) gather everything
+        self.row_bits = self.ops.new_row_bits(W * M, dev) if hasattr(self.ops, "new_row_bits") else None
         self.load_tables(user_emb, item_emb)
 
     def describe(self):
         L = self.layout
         return (f"node rows sharded round-robin over {self.world} GPUs ({L.M} rows/rank in {L.C} chunk(s)); per step "
                 f"{2 * self.L - 1} all-gathers of {L.M * self.d * 4 / 1e6:.1f} MB/rank ({self.gather_mode}) overlapped chunk-wise "
-                f"with the local SpMM + one [3B,d] all-reduce; BPR replicated, no reduce-scatter")
+                f"with the local SpMM ({'consumer-side: tiles by source chunk' if self.tiled else 'producer-side'}) + one [3B,d] "
+                f"all-reduce; BPR replicated, no reduce-scatter")
 
     # ------------------------------------------------------------------ table movement
     def load_tables(self, user_emb, item_emb):
@@ -305,23 +373,59 @@ class ShardedLightGCN:
         return full[: self.U].contiguous(), full[self.U:].contiguous()
 
     # ------------------------------------------------------------------ propagation (shared by train / eval)
+    def _layer(self, x, ready, first_add, final_kw, gather_into):
+        """One propagation layer on the owned rows: y_c = sum_k tile[c][k] . x (+ first_add_c), the partial sums chained through
+        the SpMM's `add` epilogue in self.y.  Source chunk k is the OUTER loop: its tiles only need gathered chunk k of x
+        (`ready[k]`: the pending all-gather works of that chunk, or None), so they run while the later chunks are still in
+        flight; row chunk c is complete after its last tile, and -- gather_into given -- its own all-gather starts at once.
+        first_add(c) -> addend of row chunk c or None; final_kw(c) -> epilogue of its last tile (sum_in/sum_out/sum_scale/adam;
+        `y` is filled in here).  Returns the pending works of the produced chunks (or None)."""
+        ops, lay = self.ops, self.layout
+        K = len(self.tiles[0])
+        pending = [None] * lay.C
+        self._ysel ^= 1
+        ybuf = self.ybuf[self._ysel]   # (not the buffer whose chunks the previous layer's all-gathers may still be reading)
+        for k in range(K):
+            if ready is not None and ready[k]:
+                self._wait([ready[k]])   # gathered chunk k of x has landed (the later chunks may still be in flight)
+            for c in range(lay.C):
+                rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
+                first, final = k == 0, k == K - 1
+                add = first_add(c) if first else ybuf[rs]
+                kw = dict(final_kw(c)) if final else {}
+                want_y = kw.pop("want_y", True)
+                if getattr(self, "_src_filter", None) is not None:
+                    kw["src_filter"] = self._src_filter
+                ops.spmm(self.tiles[c][k], x, add=add, y=ybuf[rs] if (not final or want_y) else None, **kw)
+                if final and gather_into is not None:
+                    pending[c] = self._all_gather_chunk(ybuf[rs], gather_into, c, True)
+        return pending if gather_into is not None else None
+
+    def _ready_all(self, ready):
+        """Wait for every chunk (the untiled layer needs all of x)."""
+        if ready is None:
+            return None
+        self._wait([w for w in ready if w])
+        return None
+
     def _forward(self):
-        """L chunked SpMM layers with the all-gathers of layers < L in flight under the next chunk;
-        leaves light rows (owned) in self.s."""
-        ops, L, lay = self.ops, self.L, self.layout
+        """L propagation layers with the all-gathers of layers < L in flight under the local SpMMs (tiled: also under the
+        NEXT layer's tiles of the chunks that have arrived); leaves light rows (owned) in self.s."""
+        L, lay = self.L, self.layout
         inv = 1.0 / (L + 1)
         x = self._gather_full(self.e0, self.e0_full)
+        ready = None
         for l in range(1, L + 1):
             last = l == L
             nxt = self.xfull[l & 1]
-            pending = []
-            for c in range(lay.C):
+            if not self.tiled:
+                ready = self._ready_all(ready)
+
+            def final_kw(c, l=l, last=last):
                 rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
-                ops.spmm(self.slabs[c], x, y=None if last else self.y[rs], sum_in=(self.e0 if l == 1 else self.s)[rs],
-                         sum_out=self.s[rs], sum_scale=inv if last else 1.0)
-                if not last:
-                    pending.append(self._all_gather_chunk(self.y[rs], nxt, c, True))
-            self._wait(pending)
+                return {"sum_in": (self.e0 if l == 1 else self.s)[rs], "sum_out": self.s[rs], "sum_scale": inv if last else 1.0,
+                        "want_y": not last}
+            ready = self._layer(x, ready, lambda c: None, final_kw, None if last else nxt)
             x = nxt
 
     # ------------------------------------------------------------------ training
@@ -344,6 +448,20 @@ class ShardedLightGCN:
         own_f = ((nodes % self.world) == self.rank).to(torch.float32)
         local = (nodes // self.world)
         ep = {"pos": posn, "own_f": own_f, "local": local}
+        # per step: the 3*nb (role-major) indices as ONE contiguous row each, for the row kernels
+        n_all = posn.shape[1]
+        n_st = (n_all + batch - 1) // batch
+
+        def per_step(t, fill):
+            pad = torch.full((3, n_st * batch), fill, dtype=t.dtype, device=dev)
+            pad[:, :n_all] = t
+            full = pad.view(3, n_st, batch).permute(1, 0, 2).contiguous()           # [step, role, b]
+            out = full.reshape(n_st, 3 * batch).clone()
+            last = n_all - (n_st - 1) * batch
+            if last < batch:   # ragged last step: its 3*nb entries must be contiguous at the front
+                out[n_st - 1, : 3 * last] = full[n_st - 1, :, :last].reshape(-1)
+            return out
+        ep["local3"], ep["pos3"], ep["own3"] = per_step(local, 0), per_step(posn, 0), per_step(own_f, 0.0)
         if self.deterministic:
             # ordered scatter: every step's 3*nb incidences (gathered row << 20 | 3*b + role) sorted once per epoch, the ragged
             # last step padded with keys that sort behind everything (the kernel reads the first 3*nb of a step)
@@ -368,10 +486,10 @@ class ShardedLightGCN:
         self._forward()
         # light rows of the minibatch: own rows in place, zeros elsewhere, summed over the ranks (x + 0 is exact)
         rows = plan["rows"][: 3 * nb]
-        loc = ep["local"][:, s0:s0 + nb].reshape(-1)
-        torch.index_select(self.s, 0, loc, out=rows)       # r // W is a valid local row for every node
-        if self.world > 1 or self.force_collectives:
-            rows.mul_(ep["own_f"][:, s0:s0 + nb].reshape(-1, 1))   # x*1 = x, x*0 = 0: exact, no host sync
+        collective = self.world > 1 or self.force_collectives
+        # r // W is a valid local row for every node; rows this rank does not own come out as exact zeros
+        ops.gather_rows(self.s, ep["local3"][k][: 3 * nb], ep["own3"][k][: 3 * nb] if collective else None, rows)
+        if collective:
             self._all_reduce(rows)
         ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
         lp = plan["loss"][k]
@@ -381,23 +499,31 @@ class ShardedLightGCN:
         self.t += 1
         adam = {"t": self.t, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}
         x = self.gprop
+        ready = None
+        frontier = getattr(self, "row_bits", None)
+        if frontier is not None:
+            ops.mark_rows(frontier, ep["pos3"][k][: 3 * nb], True)   # gprop is zero outside these rows: the first layer skips the rest
         for j in range(1, L + 1):
             last = j == L
             nxt = self.xfull[j & 1]
-            pending = []
-            for c in range(lay.C):
-                rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
+            self._src_filter = frontier if j == 1 else None
+            if not self.tiled:
+                ready = self._ready_all(ready)
+
+            def first_add(c, last=last):
                 lo, hi = lay.chunk_range(r, c)
-                a = dict(adam, p=self.e0[rs], m=self.m[rs], v=self.v[rs]) if last else None
-                ops.spmm(self.slabs[c], x, add=(self.gego if last else self.gprop)[lo:hi], y=None if last else self.y[rs], adam=a)
-                if not last:
-                    pending.append(self._all_gather_chunk(self.y[rs], nxt, c, True))
-            self._wait(pending)
+                return (self.gego if last else self.gprop)[lo:hi]
+
+            def final_kw(c, last=last):
+                rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
+                return {"adam": dict(adam, p=self.e0[rs], m=self.m[rs], v=self.v[rs]), "want_y": False} if last else {}
+            ready = self._layer(x, ready, first_add, final_kw, None if last else nxt)
             x = nxt
+        self._src_filter = None
         # only the minibatch's rows of the replicated gradient buffers are non-zero
-        touched = ep["pos"][:, s0:s0 + nb].reshape(-1)
-        self.gprop.index_fill_(0, touched, 0.0)
-        self.gego.index_fill_(0, touched, 0.0)
+        ops.zero_rows(self.gprop, self.gego, ep["pos3"][k][: 3 * nb])
+        if frontier is not None:
+            ops.mark_rows(frontier, ep["pos3"][k][: 3 * nb], False)
         return lp
 
     def train_epoch(self, users, pos, neg, batch):

@@ -2,7 +2,9 @@
 (recad_amd/sharded.py: RowLayout + build_slab_chunks + HipOps.spmm), W = 1, 2, 4, 8.  What a rank computes per layer
 (its chunked local SpMMs over the full gathered table) is timed with no collective at all -- the compute side of the
 strong-scaling curve that the driver's multi-GPU run would complete with the all-gather side.
-    python3 scripts/shard_probe.py [workload=config4] [dim=64] [reps=10] [chunks=2]"""
+    python3 scripts/shard_probe.py [workload=config4] [dim=64] [reps=10] [chunks=2]
+Also timed (W > 1): the same layer as C x C tiles chained through the `add` epilogue, source chunk outermost -- the
+consumer-side-overlap order of ShardedLightGCN._layer -- i.e. the compute price of starting on arrived column blocks."""
 import json
 import sys
 
@@ -47,10 +49,27 @@ for W in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     nnz_local = sum(int(s["col"].numel()) for s in slabs)
-    out["per_layer_ms"][str(W)] = {"ms": ms, "local_rows": lay.M, "local_nnz": nnz_local, "chunks": len(slabs),
+    ms_tiled = None
+    if W > 1 and lay.C > 1:
+        tiles = [[ops.make_slab(rp, cl, vl, dev) for rp, cl, vl in row] for row in build_slab_chunks(g.rowptr, g.col, g.val, 0, lay, tiled=True)]
+
+        def tiled_layer():
+            for k in range(lay.C):
+                for c in range(lay.C):
+                    ops.spmm(tiles[c][k], x, add=None if k == 0 else ys[c], y=ys[c])
+        tiled_layer()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            tiled_layer()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_tiled = e0.elapsed_time(e1) / reps
+        del tiles
+    out["per_layer_ms"][str(W)] = {"ms": ms, "ms_tiled": ms_tiled, "local_rows": lay.M, "local_nnz": nnz_local, "chunks": len(slabs),
                                    "allgather_bytes_per_rank_out": lay.M * dim * 4, "allgather_bytes_per_rank_in": (W - 1) * lay.M * dim * 4}
-    print(f"W={W}: rank-0 local SpMM per layer {ms:.3f} ms  ({nnz_local} nnz, {lay.M} rows, {len(slabs)} chunk(s)); "
-          f"all-gather receives {(W - 1) * lay.M * dim * 4 / 1e6:.1f} MB per layer", flush=True)
+    print(f"W={W}: rank-0 local SpMM per layer {ms:.3f} ms" + (f" (tiled {lay.C} x {lay.C}: {ms_tiled:.3f} ms)" if ms_tiled else "") +
+          f"  ({nnz_local} nnz, {lay.M} rows, {len(slabs)} chunk(s)); all-gather receives {(W - 1) * lay.M * dim * 4 / 1e6:.1f} MB per layer", flush=True)
     del slabs, x, ys
     torch.cuda.empty_cache()
 base = out["per_layer_ms"]["1"]["ms"]

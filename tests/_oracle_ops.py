@@ -36,6 +36,15 @@ class OracleOps:
             for k, arr in (("p", p), ("m", m), ("v", vv)):
                 adam[k].copy_(torch.from_numpy(arr))
 
+    def gather_rows(self, src, idx, mask, out):
+        rows = src[idx]
+        out.copy_(rows if mask is None else rows * mask.view(-1, 1))
+
+    def zero_rows(self, a, b, idx):
+        a[idx] = 0.0
+        if b is not None:
+            b[idx] = 0.0
+
     def bpr(self, dim, n_layers, lam, light_rows, emb, gprop, gego, ru, rp, rn, loss_partials, keys=None):   # keys: the HIP ops' ordered plan; this loop is ordered anyway
         """light_rows: compact [3B, d] (users, positives, negatives); emb/gprop/gego indexed by ru/rp/rn."""
         R = light_rows.numpy()

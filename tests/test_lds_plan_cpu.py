@@ -10,7 +10,7 @@ import pytest
 from recad_amd import _lib, synth
 
 H = dict(MAGIC=0, NWG=1, U=2, I=3, D=4, LSU=5, LSI=6, NBLK0=7, NBLK1=8, WG_OFS=9, BLK_OFS=10, DINV_OFS=11, LDS_BYTES=12,
-         CHUNK=13, NWORDS=14)
+         CHUNK=13, NWORDS=14, PERM0=15, PERM1=16)
 LB = dict(ROW0=0, NROWS=1, NPART=2, NTASKS=3, TASK_OFS=4, DST_OFS=5, PP_OFS=6, STREAM_OFS=7, WORDS=8)
 
 
@@ -76,7 +76,9 @@ def emulate(words, x, check_banks=True):
         cols = slice(sl * Sh, (sl + 1) * Sh)
         K = 16 // LPn
         table = np.zeros((n_src + K, Sh), dtype=np.float32)
-        table[:n_src] = x[src0: src0 + n_src, cols] * dinv[src0: src0 + n_src, None]
+        perm = words[int(words[H["PERM1" if half else "PERM0"]]):][:n_src]
+        assert np.array_equal(np.sort(perm), np.arange(n_src))
+        table[perm] = x[src0: src0 + n_src, cols] * dinv[src0: src0 + n_src, None]
         part = np.zeros((max(int(bd[LB["NPART"]]), 1), Sh), dtype=np.float32)
         written = np.zeros(part.shape[0], dtype=np.int32)
         for t in range(int(bd[LB["NTASKS"]])):
