@@ -62,8 +62,10 @@ class LightGCN(BaseVictim):
         self.graph_steps = 32  # steps per hipGraph replay of a long epoch (<= 64-step epochs are one replay); 0/1 = plain launches
         # last forward layer only on the minibatch's rows (-4 us of 18 on ml1m)
         self.use_batch_sparsity = True
-        # LDS-resident sliced SpMM on graphs that qualify (csrc/spmm_lds.h)
-        self.use_lds = True
+        # LDS-resident sliced SpMM (csrc/spmm_lds.h) on graphs that qualify: True / False force it on / off, "auto" takes it
+        # when it is the faster kernel -- staging the slice tables costs ~2 us per launch whatever the graph holds, so sparse
+        # graphs (the reference's as-is test-edge graphs: 10 nonzeros per row, 7.3 vs 6.6 us per launch) stay on the row gather
+        self.use_lds = "auto"
         # ordered (bit-reproducible) gradient scatter instead of float atomics: one more launch per step and a sort of
         # the epoch's triplets (rk_lightgcn_set_deterministic); not a reference option (its CUDA path is atomic too)
         self.deterministic = bool(config.get("deterministic", False))
@@ -128,7 +130,7 @@ class LightGCN(BaseVictim):
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
-               bool(self.deterministic), bool(self.use_lds))
+               bool(self.deterministic), str(self.use_lds))
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -145,7 +147,8 @@ class LightGCN(BaseVictim):
         # LDS-resident sliced propagation (csrc/spmm_lds.h) when the graph qualifies: bipartite normalised binary adjacency
         # whose class tables fit a CU's LDS (ml1m / Amazon-game size); RK_LDS_OFF=1 keeps the row-gather kernel (A/B)
         lds = None
-        if self.use_lds and self.n_layers >= 1 and not self.graph_dropout and not os.environ.get("RK_LDS_OFF"):
+        want_lds = self.use_lds if self.use_lds != "auto" else g.nnz >= 24 * N
+        if want_lds and self.n_layers >= 1 and not self.graph_dropout and not os.environ.get("RK_LDS_OFF"):
             lds = g.lds_plan(d)
         ws["lds"] = lds
         # the row-gather kernel's schedule (host-built) only when this handle will launch it
