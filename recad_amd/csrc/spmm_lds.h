@@ -357,7 +357,12 @@ inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStre
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>),                      \
+            /* the gather addresses table rows by ABSOLUTE LDS address (table at 0): the kernel must own no static LDS */  \
+            hipFuncAttributes fa_;                                                                                          \
+            hipError_t e_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>));            \
+            if (e_ != hipSuccess) return e_;                                                                                \
+            if (fa_.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;                                              \
+            e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>),                      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes - 64);             \
             if (e_ != hipSuccess) return e_;                                                                                \
             attr_set = true;                                                                                                \

@@ -830,23 +830,30 @@ def test_state_dict_roundtrip_and_device_moves(gpu_device):
     assert G.relerr(out.cpu().numpy(), m2(users, items).cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("d,L,graph_source", [(32, 1, "train"), (128, 4, "train"), (256, 3, "reference"), (100, 2, "train"),
-                                              (48, 3, "reference"), (64, 2, "reference"), (32, 3, "reference")])
-def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source):
-    """Every SpMM instantiation (vector D in {32,64,128,256}, generic D, packed short rows, long-row
-    pieces) and layer count, 3 epochs on a small synthetic graph: step losses and final tables
-    against the CPU oracle on the same triplets."""
+@pytest.mark.parametrize("d,L,graph_source,lds", [(32, 1, "train", False), (128, 4, "train", False), (256, 3, "reference", False),
+                                                  (100, 2, "train", False), (48, 3, "reference", False), (64, 2, "reference", False),
+                                                  (32, 3, "reference", False),
+                                                  (32, 1, "train", True), (128, 4, "train", True), (256, 3, "reference", True),
+                                                  (100, 2, "train", True), (48, 3, "reference", True), (64, 2, "train", True)])
+def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source, lds):
+    """Every SpMM instantiation (row gather: vector D in {32,64,128,256}, generic D, packed short rows, long-row
+    pieces; lds: the LDS-resident sliced kernel forced onto the small graph, d = 32 ... 256 incl. widths that are
+    no power of two, one layer = the extra zeroing launch) and layer count, 3 epochs on a small synthetic graph:
+    step losses and final tables against the CPU oracle on the same triplets."""
     from recad_amd import dataset, model, synth
     dd = synth.make("tiny")
     ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"],
                              device=gpu_device, graph_source=graph_source, seed=d + L, pairwise_batch_size=512)
     torch.manual_seed(d * 10 + L)
     m = model.from_config("victim", "lightgcn", latent_dim_rec=d, lightGCN_n_layers=L).I(dataset=ds).to(gpu_device)
+    m.use_lds = lds
     u0 = m.embedding_user.weight.detach().cpu().numpy().copy()
     i0 = m.embedding_item.weight.detach().cpu().numpy().copy()
     g = ds.graph_csr()
     csr = (g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy())
     st = orc.AdamState(u0.shape, i0.shape)
+    m._ensure_handle()
+    assert _took_lds(m) == lds
     for ep in range(3):
         e = ds.generate_epoch()
         users, pos, neg = (e[k] for k in LGN_KEYS)
@@ -868,8 +875,9 @@ def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source):
     assert np.allclose(out, ref, rtol=2e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("d,L,graph_steps", [(64, 3, 8), (32, 1, 0), (256, 2, 8), (100, 2, 8), (50, 2, 4)])
-def test_lightgcn_deterministic_scatter(gpu_device, d, L, graph_steps):
+@pytest.mark.parametrize("d,L,graph_steps,lds", [(64, 3, 8, False), (32, 1, 0, False), (256, 2, 8, False), (100, 2, 8, False), (50, 2, 4, False),
+                                                 (64, 3, 8, True), (32, 1, 0, True), (128, 2, 8, True)])
+def test_lightgcn_deterministic_scatter(gpu_device, d, L, graph_steps, lds):
     """rk_lightgcn_set_deterministic: ordered gradient scatter.  Two independent runs of three epochs (hipGraph chunks and
     plain launches, a ragged last step, heavy row collisions: 512-triplet batches on 300 users / 200 items) end in
     bit-identical tables and losses; step-0 gradients, per-step losses and the trained tables agree with the oracle like
@@ -883,6 +891,7 @@ def test_lightgcn_deterministic_scatter(gpu_device, d, L, graph_steps):
         torch.manual_seed(d * 10 + L)
         m = model.from_config("victim", "lightgcn", latent_dim_rec=d, lightGCN_n_layers=L, deterministic=True).I(dataset=ds).to(gpu_device)
         m.graph_steps = graph_steps
+        m.use_lds = lds      # (lds: the ordered scatter writes the SLICED gradient buffers of the LDS-resident propagation)
         assert m.deterministic
         u0 = m.embedding_user.weight.detach().cpu().numpy().copy()
         i0 = m.embedding_item.weight.detach().cpu().numpy().copy()
