@@ -22,6 +22,9 @@
 // Nothing but the K results per row, the target scores / ranks and the (L2-resident) candidate lists
 // touches memory: 22 M scores of the ml1m evaluation were 88 MB written and re-read before.
 #pragma once
+#include <algorithm>
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float sel_f32x4 __attribute__((ext_vector_type(4)));
@@ -49,6 +52,7 @@ static constexpr int kSelKC = 32;     // k per LDS chunk
 static constexpr int kSelLdB = 36;    // padded chunk row: operand reads hit every bank exactly twice, rows 16-byte aligned
 static constexpr int kSelMaxT = 4;    // targets ranked in the sweep
 static constexpr int kSelMaxK = 256;
+static constexpr int kSelMaxSplits = 8;
 
 struct SelArgs {
     int nb, n_items, d, K;
@@ -64,8 +68,10 @@ struct SelArgs {
     float *top_scores;
     float *target_score;
     int *target_rank;
-    unsigned long long *cand;     // [nb][kSelC] scratch
-    int *cand_cnt;                // [nb] scratch
+    unsigned long long *cand;     // [nb][n_splits][kSelC] scratch
+    int *cand_cnt;                // [nb][n_splits] scratch
+    int *rank_part;               // [nb][n_splits][n_targets] scratch: per-split target rank counts, summed by the finalize kernel
+    int n_splits;                 // the catalogue is swept in n_splits contiguous tile ranges, one workgroup per (row block, range)
     int id_bits;                  // item ids < 2^id_bits
     unsigned long long *stamps;   // diagnostic build (RK_SEL_STAMPS) only: [grid][8] cycle sums of wave 0
 };
@@ -159,15 +165,27 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
     float *sA = smem;                                   // prologue only: [RB][SA] user rows, then the target rows
     const int row0 = blockIdx.x * RB;
     const int n_in = a.n_targets;                       // <= kSelMaxT (host-checked)
-    const int n_tiles = (a.n_items + kSelTN - 1) / kSelTN;
+    const int n_tiles_all = (a.n_items + kSelTN - 1) / kSelTN;
+    // item-range split (blockIdx.y): with few row blocks (ml1m: 93 of 64 rows) one workgroup per row block leaves most CUs idle
+    // behind a serial chain of 29 tiles; the ranges keep their own exact top-K lists, merged by sel_finalize_kernel
+    const int split = blockIdx.y, n_splits = gridDim.y;
+    const int tile_begin = (int)((long long)n_tiles_all * split / n_splits), n_tiles = (int)((long long)n_tiles_all * (split + 1) / n_splits);
 
     // ---- prologue: row metadata, user rows -> LDS (zero-padded), target scores
     for (int r = tid; r < RB; r += NT) {
         const int g = row0 + r;
         const int u = g < a.nb ? a.user_ids[g] : -1;
         sUid[r] = u;
-        sCur[r] = u >= 0 ? a.seen_ptr[u] : 0;
-        sEnd[r] = u >= 0 ? a.seen_ptr[u + 1] : 0;
+        int cur = u >= 0 ? a.seen_ptr[u] : 0;
+        const int endp = u >= 0 ? a.seen_ptr[u + 1] : 0;
+        if (tile_begin > 0) {   // first seen id of this range (the list is sorted)
+            int lo = cur, hi = endp;
+            const int first = tile_begin * kSelTN;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.seen_idx[mid] < first) lo = mid + 1; else hi = mid; }
+            cur = lo;
+        }
+        sCur[r] = cur;
+        sEnd[r] = endp;
         sCnt[r] = 0;
         sTau[r] = 0u;
 #pragma unroll
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
             float s = 0.f;
             for (int k = 0; k < a.d; ++k) s = fmaf(av[k], iv[k], s);
             if (a.ubias) s = ((s + a.ubias[sUid[r]]) + a.ibias[tg]) + a.mean;
-            a.target_score[(size_t)(row0 + r) * a.n_targets + t] = s;
+            if (split == 0) a.target_score[(size_t)(row0 + r) * a.n_targets + t] = s;
             key = score_key(s);
         }
         sTkey[r][t] = key;
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = sel_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_b(0, 0);
+    load_b(tile_begin, 0);
     store_b(0);
     __syncthreads();
 #ifdef RK_SEL_STAMPS
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
 #define RK_STAMP(k)
 #endif
     int buf = 0;
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = tile_begin; tile < n_tiles; ++tile) {
         const int n0 = tile * kSelTN;
         // seen ids of this tile: loads issued before the MFMAs, consumed after them
         int seen_id = 0x7fffffff;
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
                     int base = 0;
                     if (l16 == 0 && tot) base = atomicAdd(&sCnt[rl], tot);
                     base = __shfl(base, lq * 16, 64);
-                    unsigned long long *dst = a.cand + (size_t)(row0 + rl) * kSelC + base;
+                    unsigned long long *dst = a.cand + ((size_t)(row0 + rl) * n_splits + split) * kSelC + base;
                     const unsigned below = (1u << l16) - 1u;
                     if (app[0]) dst[__popc(g0 & below)] = ((unsigned long long)key[0] << 32) | (unsigned)(~(unsigned)(n0 + wn * 32 + l16));
                     if (app[1]) dst[n0g + __popc(g1 & below)] = ((unsigned long long)key[1] << 32) | (unsigned)(~(unsigned)(n0 + wn * 32 + 16 + l16));
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
                 const int n = sCnt[r];
                 if (n > kSelC - kSelTN) {   // wave-uniform
                     unsigned tau;
-                    const int m = wave_compact_row(a.cand + (size_t)(row0 + r) * kSelC, n, a.K, a.id_bits, lane, &tau);
+                    const int m = wave_compact_row(a.cand + ((size_t)(row0 + r) * n_splits + split) * kSelC, n, a.K, a.id_bits, lane, &tau);
                     if (lane == 0) { sCnt[r] = m; sTau[r] = tau; }
                 }
             }
@@ -416,11 +434,11 @@ __global__ __launch_bounds__(WAVES_M * 256) void score_select_kernel(const SelAr
     __syncthreads();
     for (int i = tid; i < RB * n_in; i += NT) {
         const int r = i / n_in, t = i % n_in;
-        if (sUid[r] >= 0) a.target_rank[(size_t)(row0 + r) * a.n_targets + t] = sRank[r][t];
+        if (sUid[r] >= 0) a.rank_part[((size_t)(row0 + r) * n_splits + split) * a.n_targets + t] = sRank[r][t];
     }
-    // ---- the candidate lists (at most kSelC entries, at least min(K, #unseen)) go to sel_finalize_kernel
+    // ---- the candidate lists (at most kSelC entries per range, at least min(K, #unseen of the range)) go to sel_finalize_kernel
     for (int r = tid; r < RB; r += NT)
-        if (row0 + r < a.nb) a.cand_cnt[row0 + r] = sCnt[r];
+        if (row0 + r < a.nb) a.cand_cnt[(size_t)(row0 + r) * n_splits + split] = sCnt[r];
 }
 
 // One radix digit of a 256-bin histogram, scanned by wave 0 alone (4 bins per lane, shuffles only).  Finds the bin
@@ -454,16 +472,30 @@ __device__ __forceinline__ void sel_find_bin(const int *hist, int need, int tid,
 // 8-bit radix rounds over the composite (most significant byte first) narrow the set; then every thread
 // rank-sorts one survivor by counting the composites above it -- (score desc, id asc) exactly like the oracle.
 __global__ __launch_bounds__(256) void sel_finalize_kernel(const unsigned long long *__restrict__ cand, const int *__restrict__ cand_cnt,
-                                                           int K, int *__restrict__ top_ids, float *__restrict__ top_scores)
+                                                           int K, int *__restrict__ top_ids, float *__restrict__ top_scores, int n_splits,
+                                                           const int *__restrict__ rank_part, int n_targets, int *__restrict__ target_rank)
 {
-    __shared__ unsigned long long ent[kSelC];
+    __shared__ unsigned long long ent[kSelC * kSelMaxSplits];
     __shared__ unsigned long long sel[256];
     __shared__ __attribute__((aligned(16))) int hist[256];
-    __shared__ int sh[4];
+    __shared__ int sh[4], sOff[kSelMaxSplits + 1];
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int n = min(cand_cnt[b], kSelC);
-    for (int i = tid; i < n; i += 256) ent[i] = cand[(size_t)b * kSelC + i];
-    if (tid == 0) { sh[3] = 0; }
+    // the ranges' lists (each its range's exact top candidates) back to back; the target ranks are the sums of the ranges' counts
+    if (tid == 0) {
+        int o = 0;
+        for (int q = 0; q < n_splits; ++q) { sOff[q] = o; o += min(cand_cnt[(size_t)b * n_splits + q], kSelC); }
+        sOff[n_splits] = o;
+        sh[3] = 0;
+    }
+    if (tid < n_targets) {
+        int r = 0;
+        for (int q = 0; q < n_splits; ++q) r += rank_part[((size_t)b * n_splits + q) * n_targets + tid];
+        target_rank[(size_t)b * n_targets + tid] = r;
+    }
+    __syncthreads();
+    const int n = sOff[n_splits];
+    for (int q = 0; q < n_splits; ++q)
+        for (int i = tid; i < sOff[q + 1] - sOff[q]; i += 256) ent[sOff[q] + i] = cand[((size_t)b * n_splits + q) * kSelC + i];
     __syncthreads();
     unsigned long long lower = 0ULL;   // survivors: composites >= lower
     int n_sel = n;
@@ -523,6 +555,27 @@ inline size_t sel_lds_bytes(int rb, int d)
     return sizeof(float) * (tile > pro ? tile : pro);
 }
 
+// Item ranges per row block (blockIdx.y): a function of the call's (nb, n_items) only, so that the scratch sizing and the
+// launch agree.  ONE by default: measured on ml1m (5893 x 3702 x 64, round 3) the ranges do not pay -- 64-row workgroups with
+// 1 / 2 / 3 / 8 ranges 330 / 238 / 266 / 281 us against 198 us for the 16-row form and 97 us for GEMM + selection: the sweep is
+// bound by its per-tile epilogue and barriers, not by the number of workgroups.  RK_SEL_SPLITS=n (with RK_SEL_CONFIG=2) for tuning.
+inline int sel_splits(int nb, int n_items)
+{
+    const char *es = getenv("RK_SEL_SPLITS");   // read per call (tests switch it)
+    const int env = es ? atoi(es) : 0;
+    const int n_tiles = (n_items + kSelTN - 1) / kSelTN;
+    (void)nb;
+    long long sp = env > 0 ? env : 1;
+    sp = std::min<long long>(sp, std::max(1, n_tiles / 4));
+    return (int)std::max<long long>(1, std::min<long long>(sp, kSelMaxSplits));
+}
+// floats of scratch per call: candidate slots (8 bytes each) + counts + per-range target rank counts
+inline long long sel_scratch_floats(int nb, int n_items, int n_targets)
+{
+    const long long sp = sel_splits(nb, n_items);
+    return (long long)nb * sp * (kSelC * 2 + 1 + std::max(n_targets, 1)) + 2;
+}
+
 // whether the fused path applies to a request (dim <= 128: the A operands of the whole sweep live in registers)
 inline bool sel_supported(int n_items, int d, int K, int n_targets)
 {
@@ -549,17 +602,19 @@ inline hipError_t score_select_launch(SelArgs a, hipStream_t s)
     // small user blocks: 16 rows per workgroup so that the chip is filled; large ones: 64 rows (4x less item traffic per flop)
     const bool small = force ? force == 1 : ((long long)(a.nb + 63) / 64 < 512);
     const bool one = a.n_targets <= 1;
+    if (a.n_splits < 1 || a.n_splits > kSelMaxSplits) return hipErrorInvalidValue;
     if (small) {
-        const dim3 grid((a.nb + 15) / 16), block(256);
+        const dim3 grid((a.nb + 15) / 16, a.n_splits), block(256);
         if (one) sel_launch_nch<16, 1, 1>(a, grid, block, sel_lds_bytes(16, a.d), s);
         else sel_launch_nch<16, 1, kSelMaxT>(a, grid, block, sel_lds_bytes(16, a.d), s);
     } else {
-        const dim3 grid((a.nb + 63) / 64), block(512);
+        const dim3 grid((a.nb + 63) / 64, a.n_splits), block(512);
         if (one) sel_launch_nch<32, 2, 1>(a, grid, block, sel_lds_bytes(64, a.d), s);
         else sel_launch_nch<32, 2, kSelMaxT>(a, grid, block, sel_lds_bytes(64, a.d), s);
     }
     hipError_t e0 = hipGetLastError();
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(sel_finalize_kernel, dim3(a.nb), dim3(256), 0, s, a.cand, a.cand_cnt, a.K, a.top_ids, a.top_scores);
+    hipLaunchKernelGGL(sel_finalize_kernel, dim3(a.nb), dim3(256), 0, s, a.cand, a.cand_cnt, a.K, a.top_ids, a.top_scores, a.n_splits,
+                       a.rank_part, a.n_targets, a.target_rank);
     return hipGetLastError();
 }

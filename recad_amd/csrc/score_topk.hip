@@ -379,7 +379,7 @@ static bool use_fused(int n_items, int dim, int K, int n_targets)
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
 {
     if (nb <= 0 || n_items <= 0) return 0;
-    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)nb * kSelC * 2 + nb;   // candidate slots + counts
+    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)sel_scratch_floats(nb, n_items, n_targets);   // candidate slots + counts (per item range)
     return (int64_t)nb * n_items;
 }
 
@@ -406,11 +406,13 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
         a.utab = utab; a.user_ids = user_ids; a.itab = itab; a.ubias = ubias; a.ibias = ibias; a.mean = mean;
         a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
         a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
+        a.n_splits = sel_splits(nb, n_items);
         a.cand = reinterpret_cast<unsigned long long *>(scratch);
-        a.cand_cnt = reinterpret_cast<int *>(scratch + (size_t)nb * kSelC * 2);
+        a.cand_cnt = reinterpret_cast<int *>(scratch + (size_t)nb * a.n_splits * kSelC * 2);
+        a.rank_part = a.cand_cnt + (size_t)nb * a.n_splits;
 #ifdef RK_SEL_STAMPS
         // diagnostic build: the stamps go behind the candidate scratch (the caller over-allocates it by 64 KiB)
-        a.stamps = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + (size_t)nb * kSelC * 2 + nb) + 63) & ~(uintptr_t)63);
+        a.stamps = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + sel_scratch_floats(nb, n_items, n_targets)) + 63) & ~(uintptr_t)63);
 #endif
         RK_HIP(score_select_launch(a, s));
         return RK_OK;

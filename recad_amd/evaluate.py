@@ -51,11 +51,11 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     trank = torch.empty(n, max(T, 1), dtype=torch.int32, device=dev)
     chunk = max(1, min(chunk, n))
     if dot:
-        # fused sweep (K <= 256, <= 4 targets): candidate slots only, so the whole user list goes in ONE call
-        per_user = int(_lib.lib().rk_score_topk_scratch_floats(1, n_items, d, K, T))
-        if per_user < n_items:
+        # fused sweep (K <= 256, <= 4 targets): candidate slots only, so the whole user list goes in ONE call.  The scratch is
+        # sized for the block size actually passed (the library splits the catalogue into item ranges by that size)
+        if int(_lib.lib().rk_score_topk_scratch_floats(n, n_items, d, K, T)) < n * n_items:
             chunk = n
-        scratch = torch.empty(chunk * per_user, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(_lib.lib().rk_score_topk_scratch_floats(chunk, n_items, d, K, T)), dtype=torch.float32, device=dev)
     else:
         scratch = torch.empty(chunk * n_items, dtype=torch.float32, device=dev)
     for s in range(0, n, chunk):

@@ -33,7 +33,7 @@ for mode in ("fused", "unfused"):
     if mode == "unfused":
         os.environ["RK_SEL_OFF"] = "1"
     chunk = nu if mode == "fused" else max(256, min(8192, (1 << 31) // I))
-    need = int(_lib.lib().rk_score_topk_scratch_floats(min(chunk, nu), I, d, K, 1))
+    need = int(_lib.lib().rk_score_topk_scratch_floats(min(chunk, nu), I, d, K, 1)) + 16384
     scratch = torch.empty(need, device=dev)
 
     def once():
