@@ -487,7 +487,7 @@ static LdsInfo lds_info(const rk_lightgcn_desc &d)
 // Sliced working copies.  During a train_epoch call E0 and the Adam moments LIVE in e0s / ms / vs (the fused Adam's
 // 32-byte pieces of row-major rows cost the last backward launch 7 of 17.6 us); the row-major tensors the caller owns
 // are read once at the start of the call (with_moments) and written back once at its end.  A propagate call only needs e0s.
-static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced, hipStream_t s)
+static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced, hipStream_t s, bool clear_scatter = false, bool clear_gego = true)
 {
     const LdsInfo li = lds_info(d);
     const LdsDims g{li.U, li.I, li.d, li.lsu, li.lsi};
@@ -498,6 +498,11 @@ static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced,
     job.rm[0] = d.user_emb; job.sl[0] = d.e0s;
     job.rm[1] = d.m_user; job.sl[1] = d.ms;
     job.rm[2] = d.v_user; job.sl[2] = d.vs;
+    if (clear_scatter) {   // a train call's prologue: the scatter targets start (and, by the self-cleaning epilogues, stay) zero
+        job.zero[0] = d.gprop;
+        job.zero[1] = clear_gego ? d.gego : nullptr;   // (only the ordered scatter writes gego on this path)
+        job.zero_i = d.cnt;
+    }
     hipLaunchKernelGGL(lds_pack_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, g, job, to_sliced);
     RK_CHECK_LAUNCH();
     return RK_OK;
@@ -702,14 +707,13 @@ static OrderedRef ordered_ref(const rk_lightgcn *h, int batch)
 
 // what every train_epoch call does before its first step: scatter targets start (and, by the self-cleaning epilogues, stay)
 // zero; LDS path: sliced working copies of E0 / m / v.  Kernels, not memset nodes (see common.h rk_zero_async).
-static int launch_prologue(const rk_lightgcn_desc &d, int apply_update, hipStream_t s)
+static int launch_prologue(const rk_lightgcn_desc &d, int apply_update, hipStream_t s, bool ordered)
 {
     const int N = d.n_users + d.n_items;
+    if (use_lds(d)) return lds_sync(d, apply_update != 0, 1, s, true, ordered || !d.cnt);   // ONE launch: layout conversions + clears
     RK_HIP(rk_zero_async(d.gprop, sizeof(float) * (size_t)N * d.dim, s));
     RK_HIP(rk_zero_async(d.gego, sizeof(float) * (size_t)N * d.dim, s));
-    if (d.row_bits && !use_lds(d)) RK_HIP(rk_zero_async(d.row_bits, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
-    if (use_lds(d) && d.cnt) RK_HIP(rk_zero_async(d.cnt, sizeof(int32_t) * (size_t)N, s));
-    if (use_lds(d)) return lds_sync(d, apply_update != 0, 1, s);
+    if (d.row_bits) RK_HIP(rk_zero_async(d.row_bits, sizeof(uint32_t) * (size_t)((N + 31) / 32), s));
     return RK_OK;
 }
 
@@ -744,7 +748,7 @@ static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update,
     hipGraph_t g = nullptr;
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = RK_OK;
-    if (whole) rc = launch_prologue(d, apply_update, h->cap_stream);
+    if (whole) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
     for (int k = 0; k < n_steps && rc == RK_OK; ++k)
         rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, ord);
     if (whole && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
@@ -870,7 +874,7 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
         RK_HIP(hipGraphLaunch(ex, s));
         return RK_OK;
     }
-    int rc = launch_prologue(d, apply_update, s);
+    int rc = launch_prologue(d, apply_update, s, h->deterministic != 0);
     if (rc) return rc;
     int done = 0;
     if (graph_steps > 1) {

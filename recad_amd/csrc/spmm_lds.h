@@ -75,13 +75,13 @@ struct LdsArgs {
 __device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_plus(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
-// the row's sum is ready
 // LDS (address space 3) pointer to a float4: lets an absolute LDS byte address be dereferenced without a base add
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // (host pass only: LDS pointers are 32-bit on the device)
 typedef float lds_f4n __attribute__((ext_vector_type(4)));
 typedef const lds_f4n __attribute__((address_space(3))) *lds_f4_ptr;
 
+// epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
+// the row's sum is ready
 struct LdsRowOps {
     int p0, p1;
     float dr;
@@ -328,6 +328,8 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_kernel(const LdsArgs a)
 struct LdsPackJob {
     float *rm[3], *sl[3];   // up to three (row-major, sliced) pairs converted by one launch
     int n;
+    float *zero[2];         // nullable: [N, d] buffers cleared by the same launch (a train call's scatter targets)
+    int *zero_i;            // nullable: int32[N] cleared too (incidence counts)
 };
 static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
 {
@@ -336,6 +338,9 @@ static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / d4), k = (int)(i % d4) * 4;
         const size_t so = sl_off(g, r, k), ro = (size_t)r * g.d + k;
+        if (job.zero[0]) *reinterpret_cast<float4 *>(job.zero[0] + ro) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (job.zero[1]) *reinterpret_cast<float4 *>(job.zero[1] + ro) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (job.zero_i && k == 0) job.zero_i[r] = 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             if (q >= job.n) break;
