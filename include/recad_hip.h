@@ -87,7 +87,9 @@ int rk_spmm_csr(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const
  * themselves (the row-sharded multi-GPU trainer runs collectives between the launches).  Row r of
  * the CSR slab addresses row r of add/y/sum_in/sum_out/zero1/zero2/adam_*; x has x_rows rows.
  *   v = A.x (+ add);  y = v;  sum_out = (sum_in + v) * sum_scale;  zero1 = zero2 = 0;
- *   adam_t > 0: torch.optim.Adam step t on adam_p/m/v with gradient v (coef_scratch: device float[2]). */
+ *   adam_t > 0: torch.optim.Adam step t on adam_p/m/v with gradient v (coef_scratch: device float[2]);
+ *   adam_t < 0: the same with the coefficients already in coef_scratch (rk_adam_coef_advance: a device-resident step
+ *   counter, for callers that replay a captured step). */
 typedef struct rk_spmm_epilogue {
     const float *add;
     float *y;
@@ -160,6 +162,9 @@ int rk_rows_gather_masked(int32_t dim, const float *src, const int64_t *idx, con
 int rk_rows_zero(int32_t dim, float *a, float *b, const int64_t *idx, int64_t n, void *stream);
 /* bits[idx[i] >> 5] |= 1 << (idx[i] & 31) (set != 0), or the words holding those bits = 0 (set == 0) */
 int rk_rows_mark_bits(uint32_t *bits, const int64_t *idx, int64_t n, int32_t set, void *stream);
+
+/* counter[0] += 1; coef = {lr / (1 - beta1^t), sqrt(1 - beta2^t)} for t = the new counter value (device int32 / float[2]). */
+int rk_adam_coef_advance(float *coef, int32_t *counter, float lr, float beta1, float beta2, void *stream);
 
 /* BPR forward+backward of ONE minibatch on explicit node rows (lightgcn.py:122-165): rows_u/p/n
  * index emb/gprop/gego directly (item rows already offset), and light too unless light_compact != 0:

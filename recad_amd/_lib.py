@@ -122,6 +122,7 @@ _SIGNATURES = {
     "rk_rows_gather_masked": [_I32, _P, _P, _P, _I64, _P, _P],
     "rk_rows_zero": [_I32, _P, _P, _P, _I64, _P],
     "rk_rows_mark_bits": [_P, _P, _I64, _I32, _P],
+    "rk_adam_coef_advance": [_P, _P, _F, _F, _F, _P],
     "rk_bpr_rows": [_I32, _I32, _F, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "rk_bpr_rows_ordered": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],

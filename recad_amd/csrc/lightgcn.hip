@@ -927,15 +927,36 @@ RK_EXPORT int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_
     a.e.zero1 = epi->zero1; a.e.zero2 = epi->zero2;
     a.src_filter = epi->src_filter;
     if (epi->sum_out && !epi->sum_in) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: sum_out needs sum_in");
-    if (epi->adam_t > 0) {
+    if (epi->adam_t != 0) {
         if (!epi->adam_p || !epi->adam_m || !epi->adam_v || !epi->coef_scratch) RK_FAIL(RK_EINVAL, "rk_spmm_csr_ex: Adam pointers missing");
-        const AdamCoef c = adam_coef(epi->adam_t, epi->lr, epi->beta1, epi->beta2);
-        hipLaunchKernelGGL(set_coef_kernel, dim3(1), dim3(1), 0, s, epi->coef_scratch, c.step_size, c.bc2s);
-        RK_CHECK_LAUNCH();
+        if (epi->adam_t > 0) {   // (adam_t < 0: coef_scratch already holds this step's coefficients -- rk_adam_coef_advance)
+            const AdamCoef c = adam_coef(epi->adam_t, epi->lr, epi->beta1, epi->beta2);
+            hipLaunchKernelGGL(set_coef_kernel, dim3(1), dim3(1), 0, s, epi->coef_scratch, c.step_size, c.bc2s);
+            RK_CHECK_LAUNCH();
+        }
         a.e.adam = 1; a.e.p = epi->adam_p; a.e.m = epi->adam_m; a.e.v = epi->adam_v; a.e.coef = epi->coef_scratch;
         a.e.b1 = epi->beta1; a.e.b2 = epi->beta2; a.e.eps = epi->eps;
     }
     RK_HIP(spmm_launch(a, s));
+    return RK_OK;
+}
+
+// Adam coefficients of the NEXT step from a device-resident step counter (a captured step graph cannot take the step number
+// from the host): counter += 1; coef = {lr / (1 - b1^t), sqrt(1 - b2^t)}.
+__global__ void adam_coef_advance_kernel(float *coef, int *counter, float lr, float b1, float b2)
+{
+    const int t = counter[0] + 1;
+    counter[0] = t;
+    const AdamCoef c = adam_coef(t, lr, b1, b2);
+    coef[0] = c.step_size;
+    coef[1] = c.bc2s;
+}
+
+RK_EXPORT int rk_adam_coef_advance(float *coef, int32_t *counter, float lr, float beta1, float beta2, void *stream)
+{
+    if (!coef || !counter) RK_FAIL(RK_EINVAL, "rk_adam_coef_advance: bad arguments");
+    hipLaunchKernelGGL(adam_coef_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, coef, counter, lr, beta1, beta2);
+    RK_CHECK_LAUNCH();
     return RK_OK;
 }
 

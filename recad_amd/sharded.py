@@ -158,7 +158,7 @@ class HipOps:
         # (slab, operands) combination is built once and replayed (the step is host-bound on small graphs: 2 L C^2 launches)
         dp = lambda t: 0 if t is None else t.data_ptr()
         key = (id(slab), dp(x), dp(add), dp(y), dp(sum_in), dp(sum_out), float(sum_scale), dp(src_filter),
-               None if adam is None else (dp(adam["p"]), dp(adam["m"]), dp(adam["v"])))
+               None if adam is None else (dp(adam["p"]), dp(adam["m"]), dp(adam["v"]), dp(adam.get("coef"))))
         memo = self.__dict__.setdefault("_calls", {})
         call = memo.get(key)
         if call is None:
@@ -169,12 +169,12 @@ class HipOps:
                                   sum_scale=float(sum_scale), src_filter=_lib.ptr(src_filter))
             if adam is not None:
                 e.adam_p, e.adam_m, e.adam_v = _lib.ptr(adam["p"]), _lib.ptr(adam["m"]), _lib.ptr(adam["v"])
-                e.coef_scratch = _lib.ptr(slab["coef"])
+                e.coef_scratch = _lib.ptr(adam.get("coef", slab["coef"]))
                 e.lr, e.beta1, e.beta2, e.eps = adam["lr"], adam["b1"], adam["b2"], adam["eps"]
             desc, n_blocks, scratch = self._sched(slab, x.shape[1])
             args = (slab["n_rows"], _lib.ptr(slab["rowptr"]), _lib.ptr(slab["col"]), _lib.ptr(slab["val"]), _lib.ptr(desc), n_blocks,
                     _lib.ptr(scratch), x.shape[1], _lib.ptr(x), x.shape[0], C.byref(e))
-            call = memo[key] = (args, e, (slab, desc, scratch, x, add, y, sum_in, sum_out, adam, src_filter))   # (keeps the tensors alive)
+            call = memo[key] = (args, e, (slab, desc, scratch, x, add, y, sum_in, sum_out, dict(adam) if adam else None, src_filter))   # (keeps the tensors alive)
         args, e, _ = call
         if adam is not None:
             e.adam_t = adam["t"]
@@ -188,6 +188,11 @@ class HipOps:
 
     def zero_rows(self, a, b, idx):
         _lib.check(_lib.lib().rk_rows_zero(a.shape[1], _lib.ptr(a), _lib.ptr(b), _lib.ptr(idx), idx.numel(), _lib.stream_ptr()), "rk_rows_zero")
+
+    def adam_advance(self, coef, counter, lr, b1, b2):
+        """counter += 1 and this step's Adam coefficients into coef, on the device (a captured step cannot take t from the host)"""
+        _lib.check(_lib.lib().rk_adam_coef_advance(_lib.ptr(coef), _lib.ptr(counter), float(lr), float(b1), float(b2), _lib.stream_ptr()),
+                   "rk_adam_coef_advance")
 
     def new_row_bits(self, n_rows, device):
         return torch.zeros((n_rows + 31) // 32, dtype=torch.int32, device=device)
@@ -232,7 +237,7 @@ class ShardedLightGCN:
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, group=None, ops=None, device=None, chunks=None, gather="collective", force_collectives=False,
-                 deterministic=False, overlap=None):
+                 deterministic=False, overlap=None, capture=None):
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -291,6 +296,14 @@ class ShardedLightGCN:
         self.t = 0
         self._plan = None
         self._src_filter = None
+        # Step capture: one full-batch train step -- its ~2 L C^2 + 6 kernel launches AND its collectives -- recorded once into a
+        # graph (torch.cuda.CUDAGraph on the launch stream: the C-ABI launches go to torch's current stream, so they are
+        # captured with the RCCL calls) and replayed per step; the step's indices are copied into fixed staging buffers first
+        # and Adam's step number lives on the device (rk_adam_coef_advance).  None = try it wherever it can work (HIP ops,
+        # device tensors, RCCL or no collective at all) and fall back to the eager step if the capture fails.
+        self.capture = capture
+        self._graph = None
+        self._graph_failed = False
         # frontier bitmap over the gathered rows (first backward layer); ops without it (the CPU stand-in) gather everything
         self.row_bits = self.ops.new_row_bits(W * M, dev) if hasattr(self.ops, "new_row_bits") else None
         self.load_tables(user_emb, item_emb)
@@ -480,29 +493,26 @@ class ShardedLightGCN:
             ep["keys"] = torch.sort(per_step, dim=1).values.contiguous()
         return ep
 
-    def step(self, plan, ep, s0, nb, k):
-        """One train step on triplets [s0, s0+nb) of the epoch plan; writes its loss partials to plan['loss'][k]."""
+    def _step_core(self, nb, idx_local3, idx_own3, idx_pos3, lp, keys, adam):
+        """One train step given the minibatch's 3*nb role-major index rows (gathered positions idx_pos3, local rows idx_local3,
+        ownership mask idx_own3) -- slices of the epoch plan (eager) or the fixed staging buffers (captured)."""
         ops, L, lay, r = self.ops, self.L, self.layout, self.rank
         self._forward()
         # light rows of the minibatch: own rows in place, zeros elsewhere, summed over the ranks (x + 0 is exact)
-        rows = plan["rows"][: 3 * nb]
+        rows = self._plan["rows"][: 3 * nb]
         collective = self.world > 1 or self.force_collectives
         # r // W is a valid local row for every node; rows this rank does not own come out as exact zeros
-        ops.gather_rows(self.s, ep["local3"][k][: 3 * nb], ep["own3"][k][: 3 * nb] if collective else None, rows)
+        ops.gather_rows(self.s, idx_local3, idx_own3 if collective else None, rows)
         if collective:
             self._all_reduce(rows)
-        ru, rp, rn = (ep["pos"][i, s0:s0 + nb] for i in range(3))
-        lp = plan["loss"][k]
-        ops.bpr(self.d, L, self.lam, rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp,
-                keys=ep["keys"][k] if self.deterministic else None)
+        ru, rp, rn = idx_pos3[:nb], idx_pos3[nb:2 * nb], idx_pos3[2 * nb:3 * nb]
+        ops.bpr(self.d, L, self.lam, rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp, keys=keys)
         # backward + Adam on the owned rows
-        self.t += 1
-        adam = {"t": self.t, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}
         x = self.gprop
         ready = None
         frontier = getattr(self, "row_bits", None)
         if frontier is not None:
-            ops.mark_rows(frontier, ep["pos3"][k][: 3 * nb], True)   # gprop is zero outside these rows: the first layer skips the rest
+            ops.mark_rows(frontier, idx_pos3, True)   # gprop is zero outside these rows: the first layer skips the rest
         for j in range(1, L + 1):
             last = j == L
             nxt = self.xfull[j & 1]
@@ -521,10 +531,73 @@ class ShardedLightGCN:
             x = nxt
         self._src_filter = None
         # only the minibatch's rows of the replicated gradient buffers are non-zero
-        ops.zero_rows(self.gprop, self.gego, ep["pos3"][k][: 3 * nb])
+        ops.zero_rows(self.gprop, self.gego, idx_pos3)
         if frontier is not None:
-            ops.mark_rows(frontier, ep["pos3"][k][: 3 * nb], False)
+            ops.mark_rows(frontier, idx_pos3, False)
+
+    def step(self, plan, ep, s0, nb, k):
+        """One train step on triplets [s0, s0+nb) of the epoch plan; writes its loss partials to plan['loss'][k]."""
+        lp = plan["loss"][k]
+        self.t += 1
+        if nb == plan["batch"] and self._capture_ok():
+            if self._replay(plan, ep, k, lp):
+                return lp
+        adam = {"t": self.t, "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}
+        self._step_core(nb, ep["local3"][k][: 3 * nb], ep["own3"][k][: 3 * nb], ep["pos3"][k][: 3 * nb], lp,
+                        ep["keys"][k] if self.deterministic else None, adam)
         return lp
+
+    # ------------------------------------------------------------------ captured step
+    def _capture_ok(self):
+        if self.capture is False or self._graph_failed or self.device.type != "cuda" or not hasattr(self.ops, "adam_advance"):
+            return False
+        if self._host_staged():
+            return False
+        return True
+
+    def _replay(self, plan, ep, k, lp):
+        """Replay (after capturing it on first use) the full-batch step graph for step k of the epoch; False = not available."""
+        B = plan["batch"]
+        if self._graph is None or self._graph["batch"] != B:
+            if self.t <= 1:
+                return False      # the first step of a trainer runs eagerly: it builds the schedules and the memoised launches
+            st = {"local3": torch.zeros(3 * B, dtype=torch.int64, device=self.device),
+                  "pos3": torch.zeros(3 * B, dtype=torch.int64, device=self.device),
+                  "own3": torch.zeros(3 * B, dtype=torch.float32, device=self.device),
+                  "keys": torch.zeros(3 * B, dtype=torch.int64, device=self.device) if self.deterministic else None,
+                  "loss": torch.zeros(_lib.RK_LOSS_PARTIALS, dtype=torch.float32, device=self.device),
+                  "coef": torch.zeros(2, dtype=torch.float32, device=self.device),
+                  "t_dev": torch.zeros(1, dtype=torch.int32, device=self.device), "t_host": -1, "batch": B}
+            adam = {"t": -1, "coef": st["coef"], "lr": self.lr, "b1": self.betas[0], "b2": self.betas[1], "eps": self.eps}
+            ysel = self._ysel
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self.ops.adam_advance(st["coef"], st["t_dev"], self.lr, self.betas[0], self.betas[1])
+                    self._step_core(B, st["local3"], st["own3"], st["pos3"], st["loss"], st["keys"], adam)
+            except Exception as exc:    # RCCL / runtime without capture support: keep the eager step
+                self._graph_failed = True
+                self._ysel = ysel
+                import warnings
+                warnings.warn(f"ShardedLightGCN: step capture unavailable ({type(exc).__name__}: {exc}); running eagerly")
+                return False
+            if (self._ysel ^ ysel) & 1:
+                raise RuntimeError("internal: a step must flip the partial-sum buffer an even number of times")
+            st["graph"] = g
+            self._graph = st
+        st = self._graph
+        st["local3"].copy_(ep["local3"][k], non_blocking=True)
+        st["pos3"].copy_(ep["pos3"][k], non_blocking=True)
+        st["own3"].copy_(ep["own3"][k], non_blocking=True)
+        if self.deterministic:
+            st["keys"].copy_(ep["keys"][k], non_blocking=True)
+        if st["t_host"] != self.t - 1:
+            st["t_dev"].fill_(self.t - 1)     # eager steps ran in between: the device counter follows the host's
+        st["graph"].replay()
+        st["t_host"] = self.t
+        lp.copy_(st["loss"], non_blocking=True)
+        return True
 
     def train_epoch(self, users, pos, neg, batch):
         """All ranks pass the SAME triplets.  Returns the per-step losses (float64 tensor, host)."""

@@ -596,6 +596,33 @@ def test_sharded_trainer_single_rank_hip(gpu_device, name, chunks):
                         users.cpu().numpy(), items.cpu().numpy())
 
 
+def test_sharded_step_capture_matches_eager(gpu_device):
+    """The captured step graph (kernels + collectives recorded once, replayed per step with staged indices and a
+    device-resident Adam step number) against the eager step: ordered scatter, so losses and tables must agree bit for bit;
+    a ragged last step and a second epoch (eager steps in between re-synchronise the device counter)."""
+    from recad_amd.sharded import ShardedLightGCN
+    g = G.load("lightgcn_game_d64_tg")
+    U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    rng = np.random.default_rng(4)
+    B, n = 256, 256 * 9 + 77
+    users, pos, neg = (torch.from_numpy(rng.integers(0, hi, n)).to(gpu_device) for hi in (U, I, I))
+    outs = []
+    for capture in (False, None):
+        tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device), chunks=2,
+                             deterministic=True, capture=capture)
+        l1 = tr.train_epoch(users, pos, neg, B).numpy().copy()
+        l2 = tr.train_epoch(users[: 5 * B], pos[: 5 * B], neg[: 5 * B], B).numpy().copy()
+        assert (tr._graph is not None) == (capture is None), "the default must have captured its step"
+        tu, ti = tr.tables()
+        outs.append((l1, l2, tu.cpu().numpy(), ti.cpu().numpy(), tr.t))
+    a, b = outs
+    assert a[4] == b[4] == 10 + 5
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
 def _check_sharded_eval(ev, g, csr, users, items):
     U, I, L = int(g["n_users"]), int(g["n_items"]), int(g["layers"])
     topks = (10, 20, 50, 100)
