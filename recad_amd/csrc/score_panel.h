@@ -1,0 +1,681 @@
+// Full-catalog scoring + selection with the scores held in REGISTERS (gfx950), for Normal.user_item_model_generate
+// (recad/workflow/normal.py:57-93).  No score matrix, no per-tile bookkeeping.
+//
+// One workgroup (8 waves, 128 VGPRs each, two workgroups per CU) owns 16 user rows and walks the catalogue in PANELS of
+// 128 * NTW items.  Inside a panel wave w owns the 16-item tiles w, w + 8, ...; a tile's 16 x 16 scores are one
+// accumulator block of v_mfma_f32_16x16x4_f32 taken as (items, users), so a lane holds, for ONE user row (lane & 15),
+// the scores of four consecutive items per tile -- 4 * NTW scores per lane, the whole 16 x (128 NTW) panel in the
+// register file.  The MFMA is the exact-fp32 k-ordered fmaf chain, so a score has the bits of the oracle's scalar loop.
+//   * operands: the item rows come straight from global memory as 16-byte loads of a K-PERMUTED copy of the item table
+//     (position 16c + 4g + s holds k = 16c + 4s + g: the four floats a lane group g feeds into the MFMAs s = 0..3 of a
+//     16-chunk are contiguous; rk_score_topk makes the copy, one pass over the table); the 16 user rows are permuted the
+//     same way into registers (dim <= 128) or LDS (dim <= 256).  No LDS traffic and no barrier inside a panel's MFMAs.
+//   * a panel's epilogue runs on the registers: seen items (a per-row LDS bitmap filled from the sorted train lists) become
+//     -inf; target ranks are per-lane counters (#(s > s_t) + #(s == s_t, id < t)); the candidates are the scores at or
+//     above a per-row bound tau and go to a 384-slot list per row in LDS as (key << 32 | ~id) composites.
+//   * tau: in the first panel the K-th largest of 256 group maxima per row (each maximum is a distinct item, so it is a
+//     lower bound of the K-th largest score; with groups of 8 scores about 1.25 K scores lie above it); afterwards the
+//     (coarse) K-th largest key of the row's list.  Later panels hold larger item ids, so "s >= tau" keeps a superset of
+//     the final top K whatever the ties.
+//   * a row whose list would overflow (tie-heavy or constant rows, K near 256) sends the workgroup through the SAFE
+//     form of the panel: one tile per wave and round (128 consecutive ids), every row cut back to its exact top K
+//     composites after each round -- exact by construction, slow, and only taken by degenerate rows.
+//   * at the end a wave per row cuts the list to <= 256 entries, sorts them (bitonic, 4 per lane) and writes the K
+//     results: (score desc, id asc) exactly like the oracle's scan.
+#pragma once
+#include <float.h>
+
+#include "score_select.h"
+
+static constexpr int kPanRows = 16;
+static constexpr int kPanWaves = 8;
+static constexpr int kPanNT = kPanWaves * 64;
+static constexpr int kPanCap = 384;          // candidate slots per row: K (<= 256) + one safe round (128)
+static constexpr int kPanMaxT = 4;
+static constexpr int kPanDefaultMaxItems = 0;   // rk_score_topk takes this form by default up to this catalogue size (RK_PAN_FORCE=1: always)
+
+struct PanArgs {
+    int nb, n_items, d, K;
+    const float *utab;
+    const int *user_ids;
+    const float *itab;            // natural layout (target rows)
+    const float *itabp;           // k-permuted copy, rows of 16 * DC floats
+    const float *ubias, *ibias;   // both or neither: s = ((dot + ubias[u]) + ibias[i]) + mean
+    float mean;
+    const int *seen_ptr, *seen_idx;
+    const int *targets;
+    int n_targets;
+    int *top_ids;
+    float *top_scores;
+    float *target_score;
+    int *target_rank;
+    int id_bits;
+    int force_safe;               // tests: every panel through the safe form
+    unsigned long long *stamps;   // diagnostic, nullable (RK_PAN_STAMPS=1): [grid][36] wall-clock stamps of thread 0
+};
+
+// out[item][16c + 4g + s] = in[item][16c + 4s + g]  (zero beyond d): one thread per float4 of the copy
+__global__ __launch_bounds__(256) void pan_permute_kernel(const float *__restrict__ in, int n_items, int d, int dc, float *__restrict__ out)
+{
+    const long long n4 = (long long)n_items * dc * 4;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long long)gridDim.x * 256) {
+        const long long item = t / (dc * 4);
+        const int q = (int)(t % (dc * 4)), c = q >> 2, g = q & 3;
+        const float *src = in + item * d + 16 * c + g;
+        float4 v;
+        v.x = 16 * c + g < d ? src[0] : 0.f;
+        v.y = 16 * c + 4 + g < d ? src[4] : 0.f;
+        v.z = 16 * c + 8 + g < d ? src[8] : 0.f;
+        v.w = 16 * c + 12 + g < d ? src[12] : 0.f;
+        reinterpret_cast<float4 *>(out)[t] = v;
+    }
+}
+
+// The candidate lists hold RAW entries (score bits << 32 | ~id): the panels' epilogues append without the key transform;
+// the wave-level consumers below turn an entry into its (key << 32 | ~id) composite when they load it.
+__device__ __forceinline__ unsigned long long pan_raw(float s, unsigned id) { return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(~id); }
+__device__ __forceinline__ unsigned long long pan_comp(unsigned long long raw)
+{
+    return ((unsigned long long)score_key(__uint_as_float((unsigned)(raw >> 32))) << 32) | (raw & 0xffffffffULL);
+}
+
+__device__ __forceinline__ float pan_bound(unsigned T)
+{
+    // the smallest float whose key is >= T (T: a key prefix with zero low bits); keys below those of finite floats: everything
+    return T < 0x00800000u ? -FLT_MAX : key_score(T);
+}
+
+// Two sets of 256 composites, 4 per lane each (element 4 * lane + q), sorted DESCENDING across the wave; the two sets are
+// independent, so their lane exchanges overlap
+__device__ __forceinline__ void pan_sort256x2(unsigned long long (&c0)[4], unsigned long long (&c1)[4], int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long o0 = __shfl_xor(c0[q], j >> 2, 64), o1 = __shfl_xor(c1[q], j >> 2, 64);
+                    const int e = lane * 4 + q;
+                    const bool take_max = ((e & j) == 0) == ((e & k) == 0);
+                    c0[q] = ((c0[q] > o0) == take_max) ? c0[q] : o0;
+                    c1[q] = ((c1[q] > o1) == take_max) ? c1[q] : o1;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q & j) continue;
+                    const int e = lane * 4 + q;
+                    const bool up = (e & k) == 0;
+                    {
+                        const unsigned long long x = c0[q], y = c0[q | j];
+                        const unsigned long long hi = x > y ? x : y, lo = x > y ? y : x;
+                        c0[q] = up ? hi : lo;
+                        c0[q | j] = up ? lo : hi;
+                    }
+                    {
+                        const unsigned long long x = c1[q], y = c1[q | j];
+                        const unsigned long long hi = x > y ? x : y, lo = x > y ? y : x;
+                        c1[q] = up ? hi : lo;
+                        c1[q | j] = up ? lo : hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One wave: cut a row's list (n <= 512 entries in LDS) down to the entries at or above a threshold that at least K of
+// them reach and at most `limit` do (limit >= K; ties beyond that are resolved on the ids; limit == K: the exact top K).
+// Returns the new count; *kmin = the smallest key kept (n >= K: an inclusive lower bound of the row's K-th largest key,
+// the K-th key itself when K entries are kept), 0 when n < K (list untouched).
+__device__ __noinline__ int pan_prune(unsigned long long *row, int n, int K, int limit, int min_bits, int id_bits, int lane, unsigned *kmin)
+{
+    *kmin = 0u;
+    if (n < K) return n;
+    unsigned long long c[8], raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        raw[j] = (j * 64 + lane < n) ? row[j * 64 + lane] : 0ULL;
+        c[j] = (j * 64 + lane < n) ? pan_comp(raw[j]) : 0ULL;
+    }
+    unsigned long long T = 0ULL;
+    if (n > limit) {
+        int cnt = n;
+        T = wave_threshold(c, n, K, limit, min_bits, id_bits, &cnt);
+    }
+    int base = 0;
+    unsigned km = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool keep = c[j] >= T && c[j] != 0ULL;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            if (n > limit) row[base + __popcll(m & ((1ULL << lane) - 1ULL))] = raw[j];
+            const unsigned k = (unsigned)(c[j] >> 32);
+            km = k < km ? k : km;
+        }
+        base += __popcll(m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)km, o, 64);
+        km = other < km ? other : km;
+    }
+    *kmin = km;
+    return base;
+}
+
+template <int NTW>
+struct PanGeom {
+    static constexpr int PI = 128 * NTW;                                  // items per panel
+    static constexpr int BW = 4 * NTW;                                    // bitmap words per row
+    static constexpr int BWP = (BW % 8 == 4) ? BW : BW + 4;               // row stride: 16 rows land on 16 distinct banks (stride = 4 mod 8)
+    static constexpr int TPG = (NTW + 7) / 8;                             // tiles per maxima group (8 groups per lane)
+};
+
+template <int NTW, int DC>
+inline size_t pan_lds_bytes()
+{
+    return (size_t)kPanRows * kPanCap * 8 + (size_t)DC * 1024 + 2 * (size_t)kPanRows * PanGeom<NTW>::BWP * 4;
+}
+
+template <int NTW, int DC, int NTG>
+__global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
+{
+    using G = PanGeom<NTW>;
+    constexpr int PI = G::PI, BWP = G::BWP, TPG = G::TPG, NIT = NTW * DC, PF = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pan_smem[];
+    unsigned long long *sList = reinterpret_cast<unsigned long long *>(pan_smem);                 // [16][kPanCap]
+    unsigned *sMax = reinterpret_cast<unsigned *>(pan_smem);                                      // [16][256], first panel only (list still empty)
+    float *sA = reinterpret_cast<float *>(pan_smem + (size_t)kPanRows * kPanCap * 8);              // [DC][4][16] float4: the 16 user rows, k-permuted
+    unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)kPanRows * kPanCap * 8 + (size_t)DC * 1024);
+    __shared__ int sCnt[kPanRows], sCnt0[kPanRows], sUid[kPanRows], sCur[kPanRows], sEnd[kPanRows], sRank[kPanRows][kPanMaxT], sFlag[2], sStrict[kPanRows];
+    __shared__ float sTau[kPanRows];
+    const int tid = threadIdx.x, lane = tid & 63, w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u0 = lane & 15, g0 = lane >> 4;
+    int w = w0, u = u0, g = g0;
+    const int row0 = blockIdx.x * kPanRows;
+    const int n_in = a.n_targets;
+    const int dp = 16 * DC;
+    const int n_panels = (a.n_items + PI - 1) / PI;
+    const unsigned lds_list = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)pan_smem;   // LDS byte address of the lists
+
+    // diagnostic stamps (thread 0): [0] start, [1] after the prologue, [2 + 8 * min(p, 3) + k] end of phase k of panel p, [34] ranks, [35] end
+#define PAN_STAMP(slot) if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 36 + (slot)] = wall_clock64();
+    PAN_STAMP(0)
+    // ---- prologue
+    if (tid < kPanRows) {
+        const int gr = row0 + tid;
+        const int uid = gr < a.nb ? a.user_ids[gr] : -1;
+        sUid[tid] = uid;
+        sCur[tid] = uid >= 0 ? a.seen_ptr[uid] : 0;
+        sEnd[tid] = uid >= 0 ? a.seen_ptr[uid + 1] : 0;
+        sCnt[tid] = 0;
+        sCnt0[tid] = 0;
+        sTau[tid] = -FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < kPanMaxT; ++t) sRank[tid][t] = 0;
+    }
+    if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+    for (int i = tid; i < 2 * kPanRows * BWP; i += kPanNT) sBits[i] = 0u;
+    __syncthreads();
+    const int my_uid = sUid[u];
+    // this lane's user operands of the whole sweep: A[u][16c + 4s + g], s = 0..3
+    const bool full_k = a.d == 16 * DC;   // no k padding: unguarded loads
+    auto load_a = [&](int uid, int c, int gg) -> sel_f32x4 {
+        sel_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (uid >= 0) {
+            const float *src = a.utab + (size_t)uid * a.d + 16 * c + gg;
+            if (full_k) { v.x = src[0]; v.y = src[4]; v.z = src[8]; v.w = src[12]; }
+            else {
+                if (16 * c + gg < a.d) v.x = src[0];
+                if (16 * c + 4 + gg < a.d) v.y = src[4];
+                if (16 * c + 8 + gg < a.d) v.z = src[8];
+                if (16 * c + 12 + gg < a.d) v.w = src[12];
+            }
+        }
+        return v;
+    };
+    for (int i = tid; i < DC * 64; i += kPanNT)
+        *reinterpret_cast<sel_f32x4 *>(sA + (size_t)i * 4) = load_a(sUid[i & 15], i >> 6, (i >> 4) & 3);
+    __syncthreads();
+    // target scores before masking (normal.py:83-85): one extra MFMA tile whose "items" are the targets -- the same k-ordered
+    // chain as every other score; every wave computes it (no LDS hand-off), lanes 0..15 of wave 0 write it out
+    float ts[NTG];
+    int tgt[NTG], cntr[NTG];
+    const float ub = (a.ubias && my_uid >= 0) ? a.ubias[my_uid] : 0.f;
+    {
+        sel_f32x4 tacc = {0.f, 0.f, 0.f, 0.f};
+        if (n_in > 0) {
+            const int tj = a.targets[u < n_in ? u : 0];
+            const float *trow = a.itabp + (size_t)tj * dp + 4 * g;
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const sel_f32x4 b = *reinterpret_cast<const sel_f32x4 *>(trow + 16 * c);
+                const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
+                tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, av.x, tacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, av.y, tacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, tacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, av.w, tacc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+            tgt[t] = t < n_in ? a.targets[t] : -1;
+            float v = tacc[t];                       // lanes 0..15 (g == 0): target t of row u
+            if (a.ubias && t < n_in) v = ((v + ub) + a.ibias[tgt[t]]) + a.mean;
+            if (w == 0 && g == 0 && t < n_in && my_uid >= 0) a.target_score[(size_t)(row0 + u) * a.n_targets + t] = v;
+            ts[t] = __shfl(v, u, 64);
+            cntr[t] = 0;
+        }
+    }
+    PAN_STAMP(1)
+    // Per panel: MFMAs | seen bits of the panel -> bitmap | barrier A | one pass over the registers (mask, target counts, hits)
+    // | slot reservation, writes | barrier B | the rows' owners refresh tau (no barrier: the next MFMAs touch none of it).
+    // The bitmap is double-buffered: panel p reads buffer p & 1, and zeroes the other one for panel p + 1 between A and B.
+    sel_f32x4 acc[NTW];
+#pragma unroll 1
+    for (int p = 0; p < n_panels; ++p) {
+        const int pbase = p * PI;
+        // (opaque copies: per-tile addresses and shifts derived from them are recomputed where they are used instead of being
+        //  hoisted out of the panel loop -- 15 tiles' worth of invariants do not fit the 128-register budget)
+        w = w0; u = u0; g = g0;
+        asm volatile("" : "+s"(w), "+v"(u), "+v"(g));
+        unsigned *bits = sBits + (p & 1) * (kPanRows * BWP), *bits_next = sBits + ((p + 1) & 1) * (kPanRows * BWP);
+        // seen ids of this panel: first loads issued before the MFMAs, consumed after them (32 lanes per row)
+        const int sr = tid >> 5, sj = tid & 31;
+        int seen_cur = sCur[sr];
+        const int seen_end = sEnd[sr];
+        int seen_id = seen_cur + sj < seen_end ? a.seen_idx[seen_cur + sj] : 0x7fffffff;
+
+        const bool force_safe = a.force_safe != 0;
+        if (!force_safe) {
+            // ---- the panel's scores: NTW tiles x DC chunks of 4 MFMAs, item operands PF chunks ahead
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = sel_f32x4{0.f, 0.f, 0.f, 0.f};
+            auto b_ptr = [&](int n) -> const sel_f32x4 * {
+                const int i = n / DC, c = n % DC;
+                int item = pbase + 16 * (w + 8 * i) + u;
+                item = item < a.n_items ? item : a.n_items - 1;
+                return reinterpret_cast<const sel_f32x4 *>(a.itabp + (size_t)item * dp + 16 * c + 4 * g);
+            };
+            sel_f32x4 bq[PF];
+#pragma unroll
+            for (int n = 0; n < PF; ++n) bq[n] = *b_ptr(n < NIT ? n : NIT - 1);
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) {
+                const int i = n / DC, c = n % DC;
+                const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].x, av.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].y, av.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].z, av.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].w, av.w, acc[i], 0, 0, 0);
+                // the slot just consumed takes the operands of PF chunks ahead; the fences keep the compiler from sinking the
+                // load down to its use (it does, to save registers, and then every chunk waits for its own load)
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + PF < NIT) bq[n % PF] = *b_ptr(n + PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 0)
+        // ---- the panel's bitmap: seen items (sorted lists: the consumed lanes of a row form a prefix), columns past the
+        //      catalogue, rows past the block
+        {
+            const int sub = lane & 32;
+            for (;;) {
+                const bool in = seen_id < pbase + PI;
+                if (in) atomicOr(&bits[sr * BWP + ((seen_id - pbase) >> 5)], 1u << ((seen_id - pbase) & 31));
+                const int c32 = __popc((unsigned)(__ballot(in) >> sub));
+                seen_cur += c32;
+                if (c32 < 32) break;
+                seen_id = seen_cur + sj < seen_end ? a.seen_idx[seen_cur + sj] : 0x7fffffff;
+            }
+            if (sj == 0) sCur[sr] = seen_cur;
+            if (pbase + PI > a.n_items || row0 + kPanRows > a.nb) {   // (workgroup-uniform)
+                for (int i = tid; i < kPanRows * G::BW; i += kPanNT) {
+                    const int r = i / G::BW, wd = i % G::BW;
+                    const int lo = pbase + wd * 32;
+                    unsigned m = 0u;
+                    if (sUid[r] < 0 || lo >= a.n_items) m = 0xffffffffu;
+                    else if (lo + 32 > a.n_items) m = 0xffffffffu << (a.n_items - lo);
+                    if (m) atomicOr(&bits[r * BWP + wd], m);
+                }
+            }
+        }
+        __syncthreads();   // ---- barrier A
+
+        PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 1)
+        for (int i = tid; i < kPanRows * BWP; i += kPanNT) bits_next[i] = 0u;   // (last read before barrier B of the panel before)
+        if (tid == 0) sFlag[(p + 1) & 1] = 0;
+        bool safe = force_safe, counted = false;   // counted: this panel's target counts are in
+        const bool first = p == 0;
+        if (!force_safe) {
+            // ---- one pass over the registers: bias, mask, target counts; group maxima in the first panel (one running maximum,
+            //      stored to LDS as a key when its group of TPG tiles is complete), hits against tau in the others
+            float gm = -INFINITY;
+            if (first) {   // groups that do not exist (NTW < 8 * TPG)
+#pragma unroll
+                for (int q = (NTW + TPG - 1) / TPG; q < 8; ++q) sMax[u * 256 + (w * 4 + g) * 8 + q] = 0u;
+            }
+            float tau = first ? INFINITY : sTau[u];
+            int nh = 0;
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int col0 = 16 * (w + 8 * i) + 4 * g;            // panel-relative column of register 0
+                const int id0 = pbase + col0;
+                if (a.ubias) {
+                    float ib[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ib[r] = id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][r] = ((acc[i][r] + ub) + ib[r]) + a.mean;
+                }
+                const unsigned nib = bits[u * BWP + (col0 >> 5)] >> (col0 & 28);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)   // seen / out of range: all ones = a NaN, which loses every comparison and every fmaxf below
+                    acc[i][r] = __uint_as_float(__float_as_uint(acc[i][r]) | (unsigned)(((int)(nib << (31 - r))) >> 31));
+#pragma unroll
+                for (int t = 0; t < NTG; ++t) {
+                    const int tile0 = pbase + 16 * (w + 8 * i);       // wave-uniform
+                    if (tile0 + 16 <= tgt[t]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cntr[t] += acc[i][r] >= ts[t] ? 1 : 0;
+                    } else if (tile0 > tgt[t]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cntr[t] += acc[i][r] > ts[t] ? 1 : 0;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            cntr[t] += (id0 + r != tgt[t] && (acc[i][r] > ts[t] || (acc[i][r] == ts[t] && id0 + r < tgt[t]))) ? 1 : 0;
+                    }
+                }
+                if (first) {
+                    gm = fmaxf(gm, fmaxf(fmaxf(acc[i][0], acc[i][1]), fmaxf(acc[i][2], acc[i][3])));   // (masked scores are NaNs: ignored)
+                    if ((i + 1) % TPG == 0 || i + 1 == NTW) {
+                        sMax[u * 256 + (w * 4 + g) * 8 + i / TPG] = gm == -INFINITY ? 0u : score_key(gm);   // (a group of masked scores only: no maximum)
+                        gm = -INFINITY;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nh += acc[i][r] >= tau ? 1 : 0;
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the tiles' work from being interleaved: 15 tiles of temporaries do not fit)
+            }
+            counted = true;
+            PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 2)
+            if (first) {
+                // ---- tau of the first panel: K-th largest of the 256 group maxima of a row, to 16 bits
+                __syncthreads();
+                {
+                    const uint4 m0 = *reinterpret_cast<const uint4 *>(sMax + (2 * w) * 256 + lane * 4);
+                    const uint4 m1 = *reinterpret_cast<const uint4 *>(sMax + (2 * w + 1) * 256 + lane * 4);
+                    unsigned T0 = 0u, T1 = 0u;   // the two rows of this wave side by side: two independent chains of ballots
+                    for (int bit = 31; bit >= 16; --bit) {
+                        const unsigned t0 = T0 | (1u << bit), t1 = T1 | (1u << bit);
+                        const int c0 = __popcll(__ballot(m0.x >= t0)) + __popcll(__ballot(m0.y >= t0)) + __popcll(__ballot(m0.z >= t0)) +
+                                       __popcll(__ballot(m0.w >= t0));
+                        const int c1 = __popcll(__ballot(m1.x >= t1)) + __popcll(__ballot(m1.y >= t1)) + __popcll(__ballot(m1.z >= t1)) +
+                                       __popcll(__ballot(m1.w >= t1));
+                        if (c0 >= a.K) T0 = t0;
+                        if (c1 >= a.K) T1 = t1;
+                    }
+                    if (lane == 0) { sTau[2 * w] = pan_bound(T0); sTau[2 * w + 1] = pan_bound(T1); }
+                }
+                __syncthreads();
+                tau = sTau[u];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nh += acc[i][r] >= tau ? 1 : 0;
+            }
+            PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 3)
+            // ---- candidates at or above tau -> the row's list.  One reservation per lane; a lane whose range would pass the end
+            //      of the list writes nothing and raises the panel's overflow flag
+            int k = -1;
+            if (nh) {
+                k = atomicAdd(&sCnt[u], nh);
+                if (k + nh > kPanCap) { k = -1; sFlag[p & 1] = 1; }
+            }
+            // the writes, straight-line: per score one compare, skipped when no lane of the wave matches, else an exec-masked
+            // 8-byte LDS store of (~id, score bits) and the bump of the lane's slot address.  (Written as asm: left to the compiler
+            // this loop keeps the 60 compare masks of the counting loop alive in SGPRs and spills accumulators to scratch to build
+            // 64-bit store operands.)
+            if (__ballot(k >= 0)) {
+                const float tau_w = k >= 0 ? tau : INFINITY;      // lanes without a reservation match nothing
+                unsigned addr = lds_list + (unsigned)(u * kPanCap + (k >= 0 ? k : 0)) * 8u;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    unsigned nid = ~(unsigned)(pbase + 16 * (w + 8 * i) + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned long long sv;
+                        asm volatile("v_cmp_ge_f32 vcc, %3, %4\n\t"
+                                     "s_cbranch_vccz .Lpan_skip%=\n\t"
+                                     "s_and_saveexec_b64 %2, vcc\n\t"
+                                     "ds_write2_b32 %0, %1, %3 offset1:1\n\t"
+                                     "v_add_u32 %0, 8, %0\n\t"
+                                     "s_mov_b64 exec, %2\n"
+                                     ".Lpan_skip%=:\n\t"
+                                     "v_add_u32 %1, -1, %1"
+                                     : "+v"(addr), "+v"(nid), "=&s"(sv)
+                                     : "v"(acc[i][r]), "v"(tau_w)
+                                     : "vcc", "memory");
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __syncthreads();   // ---- barrier B
+            safe = sFlag[p & 1] != 0;
+        }
+        PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 4)
+        if (safe) {
+            // ---- safe form: the panel is computed AGAIN, one tile per wave and round (128 consecutive ids per round), every row
+            //      cut back to its exact top K after each round.  Runtime loops, one accumulator block: nothing of it lives in
+            //      the fast path's registers.
+            if (tid < kPanRows) sCnt[tid] = sCnt0[tid];   // the slots written past the old count are dropped
+            __syncthreads();
+            auto exact_cut = [&]() {
+                for (int r = 2 * w; r < 2 * w + 2; ++r) {
+                    unsigned km;
+                    const int m = pan_prune(sList + r * kPanCap, sCnt[r], a.K, a.K, 0, a.id_bits, lane, &km);
+                    if (lane == 0) {
+                        sCnt[r] = m;
+                        sStrict[r] = m >= a.K;
+                        if (m >= a.K) sTau[r] = key_score(km);
+                    }
+                }
+            };
+            exact_cut();
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < NTW; ++i) {
+                const int id0 = pbase + 16 * (w + 8 * i) + 4 * g;
+                int item = pbase + 16 * (w + 8 * i) + u;
+                item = item < a.n_items ? item : a.n_items - 1;
+                const float *brow = a.itabp + (size_t)item * dp + 4 * g;
+                sel_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int c = 0; c < DC; ++c) {
+                    const sel_f32x4 b = *reinterpret_cast<const sel_f32x4 *>(brow + 16 * c);
+                    const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, av.x, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, av.y, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, av.w, t, 0, 0, 0);
+                }
+                const int col0 = 16 * (w + 8 * i) + 4 * g;
+                const unsigned nib = bits[u * BWP + (col0 >> 5)] >> (col0 & 28);
+                // exact: once K entries are held (tau = the K-th key) a later id with s == tau loses the tie -> strict compare;
+                // with fewer than K held everything unmasked so far is in the list and everything unmasked enters
+                const float tau = sTau[u];
+                const bool strict = sStrict[u] != 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sc = t[r];
+                    if (a.ubias) sc = ((sc + ub) + (id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f)) + a.mean;
+                    const bool masked = (nib >> r) & 1u;
+                    if (!counted && !masked) {
+#pragma unroll
+                        for (int q = 0; q < NTG; ++q)
+                            cntr[q] += (id0 + r != tgt[q] && (sc > ts[q] || (sc == ts[q] && id0 + r < tgt[q]))) ? 1 : 0;
+                    }
+                    if (!masked && (!strict || sc > tau)) {
+                        const int slot = atomicAdd(&sCnt[u], 1);
+                        sList[u * kPanCap + slot] = pan_raw(sc, (unsigned)(id0 + r));
+                    }
+                }
+                __syncthreads();
+                exact_cut();
+                __syncthreads();
+            }
+        } else if (p + 1 < n_panels) {
+            // ---- tau for the next panel, by the rows' owners: the (coarse) K-th key of a list that has grown long.  No barrier:
+            //      nothing of this is touched before barrier A of the next panel
+            for (int r = 2 * w; r < 2 * w + 2; ++r) {
+                const int n = sCnt[r];
+                if (n >= a.K && n > kPanCap / 2) {   // (short lists: the old bound is good enough for the next panel)
+                    unsigned km;
+                    const int limit = a.K + 32 < 256 ? a.K + 32 : 256;
+                    const int m = pan_prune(sList + r * kPanCap, n, a.K, limit, 12, a.id_bits, lane, &km);
+                    if (lane == 0) {
+                        sCnt[r] = m;
+                        const float nb = key_score(km);
+                        if (nb > sTau[r]) sTau[r] = nb;
+                    }
+                }
+            }
+        }
+        // the counts the next panel starts from (restored if it overflows), by the rows' owners
+        if (lane < 2) sCnt0[2 * w + lane] = sCnt[2 * w + lane];
+        PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 5)
+    }
+    __syncthreads();
+
+    // ---- target ranks: the 4 lane groups of a wave, then the 8 waves
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) {
+        int v = cntr[t];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0 && t < n_in) atomicAdd(&sRank[u][t], v);
+    }
+    __syncthreads();
+    for (int i = tid; i < kPanRows * n_in; i += kPanNT) {
+        const int r = i / n_in, t = i % n_in;
+        if (sUid[r] >= 0) a.target_rank[(size_t)(row0 + r) * a.n_targets + t] = sRank[r][t];
+    }
+    PAN_STAMP(34)
+    if (a.stamps && tid == 0) {   // diagnostic: candidates held at the end (sum and maximum over the 16 rows)
+        int sm = 0, mx = 0;
+        for (int r = 0; r < kPanRows; ++r) { sm += sCnt[r]; mx = sCnt[r] > mx ? sCnt[r] : mx; }
+        a.stamps[(size_t)blockIdx.x * 36 + 32] = (unsigned long long)sm;
+        a.stamps[(size_t)blockIdx.x * 36 + 33] = (unsigned long long)mx;
+    }
+    // ---- results: a wave per row, the two rows of a wave side by side (two independent chains of lane exchanges)
+    {
+        unsigned long long c[2][4];
+        int nn[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 2 * w + h;
+            int n = row0 + r < a.nb ? sCnt[r] : 0;
+            unsigned long long *row = sList + r * kPanCap;
+            if (n > 256) {
+                unsigned km;
+                n = pan_prune(row, n, a.K, 256, 0, a.id_bits, lane, &km);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[h][q] = lane * 4 + q < n ? pan_comp(row[lane * 4 + q]) : 0ULL;
+            nn[h] = n;
+        }
+        pan_sort256x2(c[0], c[1], lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 2 * w + h;
+            if (row0 + r >= a.nb) continue;
+            int *oid = a.top_ids + (size_t)(row0 + r) * a.K;
+            float *osc = a.top_scores + (size_t)(row0 + r) * a.K;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = lane * 4 + q;
+                if (e < a.K) {
+                    const bool ok = e < nn[h] && c[h][q] != 0ULL;
+                    oid[e] = ok ? (int)(~(unsigned)(c[h][q] & 0xffffffffULL)) : -1;
+                    osc[e] = ok ? key_score((unsigned)(c[h][q] >> 32)) : -INFINITY;
+                }
+            }
+        }
+    }
+    PAN_STAMP(35)
+#undef PAN_STAMP
+}
+
+// ---------------------------------------------------------------- host side
+inline int pan_dc(int d) { return d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16; }
+inline bool pan_supported(int n_items, int d, int K, int n_targets)
+{
+    return K >= 1 && K <= 256 && n_targets <= kPanMaxT && d >= 1 && d <= 256 && n_items >= 1;
+}
+// floats of scratch: the k-permuted item table (rows of 16 * DC floats), 16-byte aligned by the caller
+inline long long pan_scratch_floats(int n_items, int d) { return (long long)n_items * 16 * pan_dc(d) + 4; }
+
+template <int NTW, int DC, int NTG>
+inline hipError_t pan_launch_one(const PanArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    const size_t lds = pan_lds_bytes<NTW, DC>();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_panel_kernel<NTW, DC, NTG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((score_panel_kernel<NTW, DC, NTG>), dim3((a.nb + kPanRows - 1) / kPanRows), dim3(kPanNT), lds, s, a);
+    return hipGetLastError();
+}
+template <int NTW, int DC>
+inline hipError_t pan_launch_tg(const PanArgs &a, hipStream_t s)
+{
+    return a.n_targets <= 1 ? pan_launch_one<NTW, DC, 1>(a, s) : pan_launch_one<NTW, DC, kPanMaxT>(a, s);
+}
+template <int NTW>
+inline hipError_t pan_launch_dc(const PanArgs &a, hipStream_t s)
+{
+#ifdef PAN_DEV   // development builds: one instantiation (15 x 1920-item panels, dim 64, one target)
+    return pan_launch_one<15, 4, 1>(a, s);
+#else
+    switch (pan_dc(a.d)) {
+    case 2: return pan_launch_tg<NTW, 2>(a, s);
+    case 4: return pan_launch_tg<NTW, 4>(a, s);
+    case 8: return pan_launch_tg<NTW, 8>(a, s);
+    default: return pan_launch_tg<NTW, 16>(a, s);
+    }
+#endif
+}
+
+// scratch: pan_scratch_floats(n_items, d) floats, 16-byte aligned
+inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s)
+{
+    int bits = 1;
+    while (bits < 32 && (1LL << bits) < (long long)a.n_items) ++bits;
+    a.id_bits = bits;
+    const char *fs = getenv("RK_PAN_SAFE");   // tests: the safe form for every panel (read per call)
+    a.force_safe = fs ? atoi(fs) : 0;
+    const char *fst = getenv("RK_PAN_STAMPS");   // diagnostic: the stamps go behind the scratch (the caller over-allocates it by 36 * 8 bytes per workgroup + 64)
+    a.stamps = (fst && atoi(fst)) ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + pan_scratch_floats(a.n_items, a.d)) + 63) & ~(uintptr_t)63) : nullptr;
+    const int dc = pan_dc(a.d);
+    const long long n4 = (long long)a.n_items * dc * 4;
+    hipLaunchKernelGGL(pan_permute_kernel, dim3((unsigned)std::min<long long>(2048, (n4 + 255) / 256)), dim3(256), 0, s, a.itab, a.n_items, a.d, dc,
+                       scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    a.itabp = scratch;
+    // panel width: the narrow form while the catalogue fits one or two narrow panels (less padding), else 1920 items
+    const char *fw = getenv("RK_PAN_NTW");
+    const int force = fw ? atoi(fw) : 0;
+    const bool narrow = force ? force == 8 : a.n_items <= 1024;
+    return narrow ? pan_launch_dc<8>(a, s) : pan_launch_dc<15>(a, s);
+}

@@ -9,6 +9,7 @@
 
 #include "gemm.h"
 #include "score_select.h"
+#include "score_panel.h"
 
 // ---------------------------------------------------------------- pass 2
 static constexpr int kMaxK = 256;
@@ -376,9 +377,20 @@ static bool use_fused(int n_items, int dim, int K, int n_targets)
     return (force && atoi(force)) || n_items >= (1 << 18);
 }
 
+// The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  RK_PAN_FORCE=1 takes it wherever
+// it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 / RK_SEL_FORCE=1, which name the other two paths) forbids it; read per call.
+static bool use_panel(int n_items, int dim, int K, int n_targets)
+{
+    const char *off = getenv("RK_PAN_OFF"), *force = getenv("RK_PAN_FORCE"), *soff = getenv("RK_SEL_OFF"), *sforce = getenv("RK_SEL_FORCE");
+    if ((off && atoi(off)) || (soff && atoi(soff)) || (sforce && atoi(sforce))) return false;
+    if (!pan_supported(n_items, dim, K, n_targets)) return false;
+    return (force && atoi(force)) || n_items <= kPanDefaultMaxItems;
+}
+
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
 {
     if (nb <= 0 || n_items <= 0) return 0;
+    if (use_panel(n_items, dim, K, n_targets)) return (int64_t)pan_scratch_floats(n_items, dim);              // the k-permuted item table
     if (use_fused(n_items, dim, K, n_targets)) return (int64_t)sel_scratch_floats(nb, n_items, n_targets);   // candidate slots + counts (per item range)
     return (int64_t)nb * n_items;
 }
@@ -397,6 +409,18 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
     hipStream_t s = (hipStream_t)stream;
+    if (use_panel(n_items, dim, K, n_targets)) {
+        // (no silent fall-through: the caller sized `scratch` for THIS path)
+        if (reinterpret_cast<uintptr_t>(scratch) & 15) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 16-byte aligned (panel form)");
+        PanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nb = nb; a.n_items = n_items; a.d = dim; a.K = K;
+        a.utab = utab; a.user_ids = user_ids; a.itab = itab; a.ubias = ubias; a.ibias = ibias; a.mean = mean;
+        a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
+        a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
+        RK_HIP(score_panel_launch(a, scratch, s));
+        return RK_OK;
+    }
     if (use_fused(n_items, dim, K, n_targets)) {
         // (no silent fall-through to the GEMM path: the caller sized `scratch` for THIS path, 1025 floats per user)
         if (reinterpret_cast<uintptr_t>(scratch) & 7) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 8-byte aligned (fused sweep)");

@@ -1,4 +1,4 @@
-"""Probe (tuning only): rk_score_topk per-call time, fused sweep vs GEMM + selection, on random tables.
+"""Probe (tuning only): rk_score_topk per-call time, panel form vs fused sweep vs GEMM + selection, on random tables (PROBE_MODES=panel,unfused ...).
     python3 scripts/score_probe.py <n_users> <n_items> <dim> [reps]"""
 import os
 import sys
@@ -29,10 +29,12 @@ top_sc = torch.empty(nu, K, device=dev)
 ts = torch.empty(nu, 1, device=dev)
 tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
 out = {}
-for mode in ("fused", "unfused"):
-    if mode == "unfused":
-        os.environ["RK_SEL_OFF"] = "1"
-    chunk = nu if mode == "fused" else max(256, min(8192, (1 << 31) // I))
+modes = os.environ.get("PROBE_MODES", "panel,fused,unfused").split(",")
+for mode in modes:
+    for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_FORCE", "RK_PAN_OFF"):
+        os.environ.pop(k, None)
+    os.environ[{"unfused": "RK_SEL_OFF", "fused": "RK_SEL_FORCE", "panel": "RK_PAN_FORCE"}[mode]] = "1"
+    chunk = nu if mode != "unfused" else max(256, min(8192, (1 << 31) // I))
     need = int(_lib.lib().rk_score_topk_scratch_floats(min(chunk, nu), I, d, K, 1)) + 16384
     scratch = torch.empty(need, device=dev)
 
@@ -53,4 +55,5 @@ for mode in ("fused", "unfused"):
     ms = e0.elapsed_time(e1) / reps
     out[mode] = (top_ids.clone(), tr.clone())
     print(f"{mode:8s} {nu} x {I} x {d}: {ms * 1e3:9.1f} us per evaluation   {2.0 * nu * I * d / ms / 1e9:7.1f} TFLOP/s", flush=True)
-print("identical lists:", bool(torch.equal(out["fused"][0], out["unfused"][0])), "identical ranks:", bool(torch.equal(out["fused"][1], out["unfused"][1])))
+for m in modes[1:]:
+    print(f"{modes[0]} vs {m}: identical lists:", bool(torch.equal(out[modes[0]][0], out[m][0])), "identical ranks:", bool(torch.equal(out[modes[0]][1], out[m][1])))

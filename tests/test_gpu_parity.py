@@ -297,14 +297,31 @@ def fused_scoring():
     os.environ.pop("RK_SEL_FORCE", None)
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.fixture
+def panel_scoring():
+    """RK_PAN_FORCE=1: rk_score_topk takes the register-resident panel form (score_panel.h) wherever it is supported."""
+    import os
+    os.environ["RK_PAN_FORCE"] = "1"
+    yield
+    os.environ.pop("RK_PAN_FORCE", None)
+    os.environ.pop("RK_PAN_SAFE", None)
+    os.environ.pop("RK_PAN_NTW", None)
+
+
+@pytest.mark.parametrize("path", ["panel", "panel_safe", "panel_narrow", "sweep", "gemm"])
 @pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
-def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request):
+def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
     """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
-    so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first) -- on the fused sweep
-    (no score matrix) and on the GEMM + selection path."""
+    so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first) -- on the register-resident panel
+    form (its fast and its safe form, both panel widths), on the fused sweep (no score matrix) and on the GEMM + selection path."""
+    import os
     from recad_amd import _lib
-    request.getfixturevalue("fused_scoring" if fused else "unfused_scoring")
+    fused = path == "sweep"
+    request.getfixturevalue({"sweep": "fused_scoring", "gemm": "unfused_scoring"}.get(path, "panel_scoring"))
+    if path == "panel_safe":
+        os.environ["RK_PAN_SAFE"] = "1"
+    if path == "panel_narrow":
+        os.environ["RK_PAN_NTW"] = "8"
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
@@ -338,8 +355,11 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, fused, request)
                                         _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids] if with_bias else None, ib, 0.25 if with_bias else 0.0)
     # fused: candidate slots + counts (+ per-range target counts), never the score matrix
-    assert (nb * 1025 <= need <= nb * 8 * 1028 + 2) if (fused and d <= 128) else need == nb * I
-    got_scores = None if (fused and d <= 128) else scratch[: nb * I].view(nb, I).cpu().numpy()
+    if path.startswith("panel"):
+        assert need == I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4   # the k-permuted item table
+    else:
+        assert (nb * 1025 <= need <= nb * 8 * 1028 + 2) if (fused and d <= 128) else need == nb * I
+    got_scores = None if ((fused and d <= 128) or path.startswith("panel")) else scratch[: nb * I].view(nb, I).cpu().numpy()
     top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         seen = seen_lists[int(user_ids[b])]
