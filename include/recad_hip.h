@@ -298,10 +298,13 @@ int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v,
  * in); items in the user's seen list (CSR seen_ptr/seen_idx indexed by user_ids[b], ids sorted ascending)
  * are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K] sorted by (score desc, item id
  * asc), padded with -1/-inf; for each target t its score and rank among the unseen items (hit@k <=> rank < k).
- * Two paths, identical results: GEMM into a [nb, n_items] matrix in `scratch` + a selection pass (the default while
- * such a matrix is sensible: n_items < 2^18), or ONE fused sweep over the catalogue that never materialises the
- * scores (recad_amd/csrc/score_select.h; K <= 256, n_targets <= 4, dim <= 128; 1025 floats of scratch per user;
- * the default for larger catalogues).  scratch: device float[rk_score_topk_scratch_floats(...)], 8-byte aligned. */
+ * Three paths, identical results: (1) GEMM into a [nb, n_items] matrix in `scratch` + a selection pass (catalogues of
+ * < 16 384 items, or requests the other two do not take); (2) the register-resident PANEL form, recad_amd/csrc/score_panel.h:
+ * a workgroup holds the scores of 16 / 32 users x 1920 items in its registers, selects from there and never writes a score
+ * (K <= 256, n_targets <= 4, dim <= 256; scratch = a k-permuted copy of the item table, n_items * 16 * ceil(dim / 16) floats;
+ * the default from 16 384 items on); (3) the older fused sweep, recad_amd/csrc/score_select.h (K <= 256, n_targets <= 4,
+ * dim <= 128; 1025 floats of scratch per user; RK_SEL_FORCE=1).  scratch: device float[rk_score_topk_scratch_floats(...)]
+ * for the SAME nb, 16-byte aligned. */
 int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets);
 int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
                   int32_t n_items, const float *ubias, const float *ibias, float mean,

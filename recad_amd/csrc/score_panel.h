@@ -27,12 +27,12 @@
 
 #include "score_select.h"
 
-static constexpr int kPanRows = 16;
+static constexpr int kPanMaxRows = 32;       // user rows per workgroup: 16 or 32
 static constexpr int kPanWaves = 8;
 static constexpr int kPanNT = kPanWaves * 64;
 static constexpr int kPanCap = 384;          // candidate slots per row: K (<= 256) + one safe round (128)
 static constexpr int kPanMaxT = 4;
-static constexpr int kPanDefaultMaxItems = 0;   // rk_score_topk takes this form by default up to this catalogue size (RK_PAN_FORCE=1: always)
+static constexpr int kPanDefaultMinItems = 16384;   // rk_score_topk takes this form by default from this catalogue size on (RK_PAN_FORCE=1: always)
 
 struct PanArgs {
     int nb, n_items, d, K;
@@ -175,28 +175,33 @@ struct PanGeom {
     static constexpr int TPG = (NTW + 7) / 8;                             // tiles per maxima group (8 groups per lane)
 };
 
-template <int NTW, int DC>
+template <int NTW, int DC, int RB>
 inline size_t pan_lds_bytes()
 {
-    return (size_t)kPanRows * kPanCap * 8 + (size_t)DC * 1024 + 2 * (size_t)kPanRows * PanGeom<NTW>::BWP * 4;
+    return (size_t)(16 * RB) * kPanCap * 8 + (size_t)DC * 1024 * RB + 2 * (size_t)(16 * RB) * PanGeom<NTW>::BWP * 4;
 }
 
-template <int NTW, int DC, int NTG>
-__global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
+// RB: blocks of 16 user rows per workgroup.  RB == 1: 128 registers per wave, two workgroups per CU (small user blocks: more
+// workgroups); RB == 2: 32 rows, 256 registers, one workgroup per CU -- every item operand loaded from L2 feeds 8 MFMAs instead
+// of 4 (at 16 rows the sweep is bound by the L2 -> L1 operand traffic: 8 flop per byte), and the lane-parallel epilogue work per
+// workgroup barrier doubles.
+template <int NTW, int DC, int NTG, int RB>
+__global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(const PanArgs a)
 {
     using G = PanGeom<NTW>;
-    constexpr int PI = G::PI, BWP = G::BWP, TPG = G::TPG, NIT = NTW * DC, PF = 3;
+    constexpr int PI = G::PI, BWP = G::BWP, TPG = G::TPG, NIT = NTW * DC, PF = RB == 1 ? 3 : 4, R = 16 * RB;
     extern __shared__ __attribute__((aligned(16))) unsigned char pan_smem[];
-    unsigned long long *sList = reinterpret_cast<unsigned long long *>(pan_smem);                 // [16][kPanCap]
-    unsigned *sMax = reinterpret_cast<unsigned *>(pan_smem);                                      // [16][256], first panel only (list still empty)
-    float *sA = reinterpret_cast<float *>(pan_smem + (size_t)kPanRows * kPanCap * 8);              // [DC][4][16] float4: the 16 user rows, k-permuted
-    unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)kPanRows * kPanCap * 8 + (size_t)DC * 1024);
-    __shared__ int sCnt[kPanRows], sCnt0[kPanRows], sUid[kPanRows], sCur[kPanRows], sEnd[kPanRows], sRank[kPanRows][kPanMaxT], sFlag[2], sStrict[kPanRows];
-    __shared__ float sTau[kPanRows];
+    unsigned long long *sList = reinterpret_cast<unsigned long long *>(pan_smem);                 // [R][kPanCap]
+    unsigned *sMax = reinterpret_cast<unsigned *>(pan_smem);                                      // [R][256], first panel only (lists still empty)
+    float *sA = reinterpret_cast<float *>(pan_smem + (size_t)R * kPanCap * 8);                     // [DC][4][R] float4: the user rows, k-permuted
+    unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)R * kPanCap * 8 + (size_t)DC * 1024 * RB);   // [2][R][BWP]
+    __shared__ int sCnt[kPanMaxRows], sCnt0[kPanMaxRows], sUid[kPanMaxRows], sCur[kPanMaxRows], sEnd[kPanMaxRows], sRank[kPanMaxRows][kPanMaxT],
+        sFlag[2], sStrict[kPanMaxRows];
+    __shared__ float sTau[kPanMaxRows];
     const int tid = threadIdx.x, lane = tid & 63, w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int u0 = lane & 15, g0 = lane >> 4;
     int w = w0, u = u0, g = g0;
-    const int row0 = blockIdx.x * kPanRows;
+    const int row0 = blockIdx.x * R;
     const int n_in = a.n_targets;
     const int dp = 16 * DC;
     const int n_panels = (a.n_items + PI - 1) / PI;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
 #define PAN_STAMP(slot) if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 36 + (slot)] = wall_clock64();
     PAN_STAMP(0)
     // ---- prologue
-    if (tid < kPanRows) {
+    if (tid < R) {
         const int gr = row0 + tid;
         const int uid = gr < a.nb ? a.user_ids[gr] : -1;
         sUid[tid] = uid;
@@ -219,10 +224,9 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         for (int t = 0; t < kPanMaxT; ++t) sRank[tid][t] = 0;
     }
     if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
-    for (int i = tid; i < 2 * kPanRows * BWP; i += kPanNT) sBits[i] = 0u;
+    for (int i = tid; i < 2 * R * BWP; i += kPanNT) sBits[i] = 0u;
     __syncthreads();
-    const int my_uid = sUid[u];
-    // this lane's user operands of the whole sweep: A[u][16c + 4s + g], s = 0..3
+    // the user rows, k-permuted, into LDS: A[row][16c + 4s + g], s = 0..3, as the float4 of (c, g, row)
     const bool full_k = a.d == 16 * DC;   // no k padding: unguarded loads
     auto load_a = [&](int uid, int c, int gg) -> sel_f32x4 {
         sel_f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -238,15 +242,20 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         }
         return v;
     };
-    for (int i = tid; i < DC * 64; i += kPanNT)
-        *reinterpret_cast<sel_f32x4 *>(sA + (size_t)i * 4) = load_a(sUid[i & 15], i >> 6, (i >> 4) & 3);
+    for (int i = tid; i < DC * 4 * R; i += kPanNT)
+        *reinterpret_cast<sel_f32x4 *>(sA + (size_t)i * 4) = load_a(sUid[i % R], i / (4 * R), (i / R) & 3);
     __syncthreads();
+    auto a_op = [&](int c, int rb) -> sel_f32x4 { return *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * R + rb * 16 + u) * 4); };
     // target scores before masking (normal.py:83-85): one extra MFMA tile whose "items" are the targets -- the same k-ordered
     // chain as every other score; every wave computes it (no LDS hand-off), lanes 0..15 of wave 0 write it out
-    float ts[NTG];
-    int tgt[NTG], cntr[NTG];
-    const float ub = (a.ubias && my_uid >= 0) ? a.ubias[my_uid] : 0.f;
-    {
+    float ts[RB][NTG], ub[RB];
+    int tgt[NTG], cntr[RB][NTG];
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) tgt[t] = t < n_in ? a.targets[t] : -1;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int my_uid = sUid[rb * 16 + u];
+        ub[rb] = (a.ubias && my_uid >= 0) ? a.ubias[my_uid] : 0.f;
         sel_f32x4 tacc = {0.f, 0.f, 0.f, 0.f};
         if (n_in > 0) {
             const int tj = a.targets[u < n_in ? u : 0];
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const sel_f32x4 b = *reinterpret_cast<const sel_f32x4 *>(trow + 16 * c);
-                const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
+                const sel_f32x4 av = a_op(c, rb);
                 tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, av.x, tacc, 0, 0, 0);
                 tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, av.y, tacc, 0, 0, 0);
                 tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, tacc, 0, 0, 0);
@@ -263,38 +272,44 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         }
 #pragma unroll
         for (int t = 0; t < NTG; ++t) {
-            tgt[t] = t < n_in ? a.targets[t] : -1;
             float v = tacc[t];                       // lanes 0..15 (g == 0): target t of row u
-            if (a.ubias && t < n_in) v = ((v + ub) + a.ibias[tgt[t]]) + a.mean;
-            if (w == 0 && g == 0 && t < n_in && my_uid >= 0) a.target_score[(size_t)(row0 + u) * a.n_targets + t] = v;
-            ts[t] = __shfl(v, u, 64);
-            cntr[t] = 0;
+            if (a.ubias && t < n_in) v = ((v + ub[rb]) + a.ibias[tgt[t]]) + a.mean;
+            if (w == 0 && g == 0 && t < n_in && my_uid >= 0) a.target_score[(size_t)(row0 + rb * 16 + u) * a.n_targets + t] = v;
+            ts[rb][t] = __shfl(v, u, 64);
+            cntr[rb][t] = 0;
         }
     }
     PAN_STAMP(1)
     // Per panel: MFMAs | seen bits of the panel -> bitmap | barrier A | one pass over the registers (mask, target counts, hits)
     // | slot reservation, writes | barrier B | the rows' owners refresh tau (no barrier: the next MFMAs touch none of it).
     // The bitmap is double-buffered: panel p reads buffer p & 1, and zeroes the other one for panel p + 1 between A and B.
-    sel_f32x4 acc[NTW];
+    // Rows rb * 16 + {2w, 2w + 1} belong to wave w for everything that is done per row.
+    sel_f32x4 acc[RB][NTW];
 #pragma unroll 1
     for (int p = 0; p < n_panels; ++p) {
         const int pbase = p * PI;
         // (opaque copies: per-tile addresses and shifts derived from them are recomputed where they are used instead of being
-        //  hoisted out of the panel loop -- 15 tiles' worth of invariants do not fit the 128-register budget)
+        //  hoisted out of the panel loop -- 15 tiles' worth of invariants do not fit the register budget)
         w = w0; u = u0; g = g0;
         asm volatile("" : "+s"(w), "+v"(u), "+v"(g));
-        unsigned *bits = sBits + (p & 1) * (kPanRows * BWP), *bits_next = sBits + ((p + 1) & 1) * (kPanRows * BWP);
-        // seen ids of this panel: first loads issued before the MFMAs, consumed after them (32 lanes per row)
-        const int sr = tid >> 5, sj = tid & 31;
-        int seen_cur = sCur[sr];
-        const int seen_end = sEnd[sr];
-        int seen_id = seen_cur + sj < seen_end ? a.seen_idx[seen_cur + sj] : 0x7fffffff;
+        unsigned *bits = sBits + (p & 1) * (R * BWP), *bits_next = sBits + ((p + 1) & 1) * (R * BWP);
+        // seen ids of this panel: first loads issued before the MFMAs, consumed after them (32 lanes per row, 16 rows per round)
+        const int sj = tid & 31;
+        int seen_cur[RB], seen_id[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int sr = rb * 16 + (tid >> 5);
+            seen_cur[rb] = sCur[sr];
+            seen_id[rb] = seen_cur[rb] + sj < sEnd[sr] ? a.seen_idx[seen_cur[rb] + sj] : 0x7fffffff;
+        }
 
         const bool force_safe = a.force_safe != 0;
         if (!force_safe) {
-            // ---- the panel's scores: NTW tiles x DC chunks of 4 MFMAs, item operands PF chunks ahead
+            // ---- the panel's scores: NTW tiles x DC chunks of 4 MFMAs per row block, item operands PF chunks ahead
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i] = sel_f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[rb][i] = sel_f32x4{0.f, 0.f, 0.f, 0.f};
             auto b_ptr = [&](int n) -> const sel_f32x4 * {
                 const int i = n / DC, c = n % DC;
                 int item = pbase + 16 * (w + 8 * i) + u;
@@ -307,11 +322,14 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
 #pragma unroll
             for (int n = 0; n < NIT; ++n) {
                 const int i = n / DC, c = n % DC;
-                const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].x, av.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].y, av.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].z, av.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].w, av.w, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const sel_f32x4 av = a_op(c, rb);
+                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].x, av.x, acc[rb][i], 0, 0, 0);
+                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].y, av.y, acc[rb][i], 0, 0, 0);
+                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].z, av.z, acc[rb][i], 0, 0, 0);
+                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].w, av.w, acc[rb][i], 0, 0, 0);
+                }
                 // the slot just consumed takes the operands of PF chunks ahead; the fences keep the compiler from sinking the
                 // load down to its use (it does, to save registers, and then every chunk waits for its own load)
                 __builtin_amdgcn_sched_barrier(0);
@@ -325,17 +343,23 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         //      catalogue, rows past the block
         {
             const int sub = lane & 32;
-            for (;;) {
-                const bool in = seen_id < pbase + PI;
-                if (in) atomicOr(&bits[sr * BWP + ((seen_id - pbase) >> 5)], 1u << ((seen_id - pbase) & 31));
-                const int c32 = __popc((unsigned)(__ballot(in) >> sub));
-                seen_cur += c32;
-                if (c32 < 32) break;
-                seen_id = seen_cur + sj < seen_end ? a.seen_idx[seen_cur + sj] : 0x7fffffff;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int sr = rb * 16 + (tid >> 5);
+                const int seen_end = sEnd[sr];
+                int cur = seen_cur[rb], id = seen_id[rb];
+                for (;;) {
+                    const bool in = id < pbase + PI;
+                    if (in) atomicOr(&bits[sr * BWP + ((id - pbase) >> 5)], 1u << ((id - pbase) & 31));
+                    const int c32 = __popc((unsigned)(__ballot(in) >> sub));
+                    cur += c32;
+                    if (c32 < 32) break;
+                    id = cur + sj < seen_end ? a.seen_idx[cur + sj] : 0x7fffffff;
+                }
+                if (sj == 0) sCur[sr] = cur;
             }
-            if (sj == 0) sCur[sr] = seen_cur;
-            if (pbase + PI > a.n_items || row0 + kPanRows > a.nb) {   // (workgroup-uniform)
-                for (int i = tid; i < kPanRows * G::BW; i += kPanNT) {
+            if (pbase + PI > a.n_items || row0 + R > a.nb) {   // (workgroup-uniform)
+                for (int i = tid; i < R * G::BW; i += kPanNT) {
                     const int r = i / G::BW, wd = i % G::BW;
                     const int lo = pbase + wd * 32;
                     unsigned m = 0u;
@@ -348,71 +372,79 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         __syncthreads();   // ---- barrier A
 
         PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 1)
-        for (int i = tid; i < kPanRows * BWP; i += kPanNT) bits_next[i] = 0u;   // (last read before barrier B of the panel before)
+        for (int i = tid; i < R * BWP; i += kPanNT) bits_next[i] = 0u;   // (last read before barrier B of the panel before)
         if (tid == 0) sFlag[(p + 1) & 1] = 0;
         bool safe = force_safe, counted = false;   // counted: this panel's target counts are in
         const bool first = p == 0;
         if (!force_safe) {
             // ---- one pass over the registers: bias, mask, target counts; group maxima in the first panel (one running maximum,
             //      stored to LDS as a key when its group of TPG tiles is complete), hits against tau in the others
-            float gm = -INFINITY;
-            if (first) {   // groups that do not exist (NTW < 8 * TPG)
+            float tau[RB];
+            int nh[RB];
 #pragma unroll
-                for (int q = (NTW + TPG - 1) / TPG; q < 8; ++q) sMax[u * 256 + (w * 4 + g) * 8 + q] = 0u;
-            }
-            float tau = first ? INFINITY : sTau[u];
-            int nh = 0;
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rb * 16 + u;
+                float gm = -INFINITY;
+                if (first) {   // groups that do not exist (NTW < 8 * TPG)
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const int col0 = 16 * (w + 8 * i) + 4 * g;            // panel-relative column of register 0
-                const int id0 = pbase + col0;
-                if (a.ubias) {
-                    float ib[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ib[r] = id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][r] = ((acc[i][r] + ub) + ib[r]) + a.mean;
+                    for (int q = (NTW + TPG - 1) / TPG; q < 8; ++q) sMax[row * 256 + (w * 4 + g) * 8 + q] = 0u;
                 }
-                const unsigned nib = bits[u * BWP + (col0 >> 5)] >> (col0 & 28);
+                tau[rb] = first ? INFINITY : sTau[row];
+                nh[rb] = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)   // seen / out of range: all ones = a NaN, which loses every comparison and every fmaxf below
-                    acc[i][r] = __uint_as_float(__float_as_uint(acc[i][r]) | (unsigned)(((int)(nib << (31 - r))) >> 31));
+                for (int i = 0; i < NTW; ++i) {
+                    const int col0 = 16 * (w + 8 * i) + 4 * g;            // panel-relative column of register 0
+                    const int id0 = pbase + col0;
+                    if (a.ubias) {
+                        float ib[4];
 #pragma unroll
-                for (int t = 0; t < NTG; ++t) {
-                    const int tile0 = pbase + 16 * (w + 8 * i);       // wave-uniform
-                    if (tile0 + 16 <= tgt[t]) {
+                        for (int r = 0; r < 4; ++r) ib[r] = id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) cntr[t] += acc[i][r] >= ts[t] ? 1 : 0;
-                    } else if (tile0 > tgt[t]) {
+                        for (int r = 0; r < 4; ++r) acc[rb][i][r] = ((acc[rb][i][r] + ub[rb]) + ib[r]) + a.mean;
+                    }
+                    const unsigned nib = bits[row * BWP + (col0 >> 5)] >> (col0 & 28);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) cntr[t] += acc[i][r] > ts[t] ? 1 : 0;
+                    for (int r = 0; r < 4; ++r)   // seen / out of range: all ones = a NaN, which loses every comparison and every fmaxf below
+                        acc[rb][i][r] = __uint_as_float(__float_as_uint(acc[rb][i][r]) | (unsigned)(((int)(nib << (31 - r))) >> 31));
+#pragma unroll
+                    for (int t = 0; t < NTG; ++t) {
+                        const int tile0 = pbase + 16 * (w + 8 * i);       // wave-uniform
+                        if (tile0 + 16 <= tgt[t]) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] >= ts[rb][t] ? 1 : 0;
+                        } else if (tile0 > tgt[t]) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] > ts[rb][t] ? 1 : 0;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                cntr[rb][t] += (id0 + r != tgt[t] && (acc[rb][i][r] > ts[rb][t] || (acc[rb][i][r] == ts[rb][t] && id0 + r < tgt[t]))) ? 1 : 0;
+                        }
+                    }
+                    if (first) {
+                        gm = fmaxf(gm, fmaxf(fmaxf(acc[rb][i][0], acc[rb][i][1]), fmaxf(acc[rb][i][2], acc[rb][i][3])));   // (masked scores are NaNs: ignored)
+                        if ((i + 1) % TPG == 0 || i + 1 == NTW) {
+                            sMax[row * 256 + (w * 4 + g) * 8 + i / TPG] = gm == -INFINITY ? 0u : score_key(gm);   // (a group of masked scores only: no maximum)
+                            gm = -INFINITY;
+                        }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            cntr[t] += (id0 + r != tgt[t] && (acc[i][r] > ts[t] || (acc[i][r] == ts[t] && id0 + r < tgt[t]))) ? 1 : 0;
+                        for (int r = 0; r < 4; ++r) nh[rb] += acc[rb][i][r] >= tau[rb] ? 1 : 0;
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // (keeps the tiles' work from being interleaved: 15 tiles of temporaries do not fit)
                 }
-                if (first) {
-                    gm = fmaxf(gm, fmaxf(fmaxf(acc[i][0], acc[i][1]), fmaxf(acc[i][2], acc[i][3])));   // (masked scores are NaNs: ignored)
-                    if ((i + 1) % TPG == 0 || i + 1 == NTW) {
-                        sMax[u * 256 + (w * 4 + g) * 8 + i / TPG] = gm == -INFINITY ? 0u : score_key(gm);   // (a group of masked scores only: no maximum)
-                        gm = -INFINITY;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) nh += acc[i][r] >= tau ? 1 : 0;
-                }
-                __builtin_amdgcn_sched_barrier(0);   // (keeps the tiles' work from being interleaved: 15 tiles of temporaries do not fit)
             }
             counted = true;
             PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 2)
             if (first) {
                 // ---- tau of the first panel: K-th largest of the 256 group maxima of a row, to 16 bits
                 __syncthreads();
-                {
-                    const uint4 m0 = *reinterpret_cast<const uint4 *>(sMax + (2 * w) * 256 + lane * 4);
-                    const uint4 m1 = *reinterpret_cast<const uint4 *>(sMax + (2 * w + 1) * 256 + lane * 4);
-                    unsigned T0 = 0u, T1 = 0u;   // the two rows of this wave side by side: two independent chains of ballots
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int ra = rb * 16 + 2 * w;
+                    const uint4 m0 = *reinterpret_cast<const uint4 *>(sMax + ra * 256 + lane * 4);
+                    const uint4 m1 = *reinterpret_cast<const uint4 *>(sMax + (ra + 1) * 256 + lane * 4);
+                    unsigned T0 = 0u, T1 = 0u;   // two rows side by side: two independent chains of ballots
                     for (int bit = 31; bit >= 16; --bit) {
                         const unsigned t0 = T0 | (1u << bit), t1 = T1 | (1u << bit);
                         const int c0 = __popcll(__ballot(m0.x >= t0)) + __popcll(__ballot(m0.y >= t0)) + __popcll(__ballot(m0.z >= t0)) +
@@ -422,51 +454,58 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
                         if (c0 >= a.K) T0 = t0;
                         if (c1 >= a.K) T1 = t1;
                     }
-                    if (lane == 0) { sTau[2 * w] = pan_bound(T0); sTau[2 * w + 1] = pan_bound(T1); }
+                    if (lane == 0) { sTau[ra] = pan_bound(T0); sTau[ra + 1] = pan_bound(T1); }
                 }
                 __syncthreads();
-                tau = sTau[u];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i)
+                for (int rb = 0; rb < RB; ++rb) {
+                    tau[rb] = sTau[rb * 16 + u];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) nh += acc[i][r] >= tau ? 1 : 0;
+                    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) nh[rb] += acc[rb][i][r] >= tau[rb] ? 1 : 0;
+                }
             }
             PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 3)
-            // ---- candidates at or above tau -> the row's list.  One reservation per lane; a lane whose range would pass the end
-            //      of the list writes nothing and raises the panel's overflow flag
-            int k = -1;
-            if (nh) {
-                k = atomicAdd(&sCnt[u], nh);
-                if (k + nh > kPanCap) { k = -1; sFlag[p & 1] = 1; }
-            }
-            // the writes, straight-line: per score one compare, skipped when no lane of the wave matches, else an exec-masked
-            // 8-byte LDS store of (~id, score bits) and the bump of the lane's slot address.  (Written as asm: left to the compiler
-            // this loop keeps the 60 compare masks of the counting loop alive in SGPRs and spills accumulators to scratch to build
-            // 64-bit store operands.)
-            if (__ballot(k >= 0)) {
-                const float tau_w = k >= 0 ? tau : INFINITY;      // lanes without a reservation match nothing
-                unsigned addr = lds_list + (unsigned)(u * kPanCap + (k >= 0 ? k : 0)) * 8u;
+            // ---- candidates at or above tau -> the row's list.  One reservation per lane and row block; a lane whose range would
+            //      pass the end of the list writes nothing and raises the panel's overflow flag.
+            //      The writes are straight-line: per score one compare, skipped when no lane of the wave matches, else an exec-masked
+            //      8-byte LDS store of (~id, score bits) and the bump of the lane's slot address.  (Written as asm: left to the
+            //      compiler this loop keeps the compare masks of the counting loop alive in SGPRs and spills accumulators to scratch
+            //      to build 64-bit store operands.)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    unsigned nid = ~(unsigned)(pbase + 16 * (w + 8 * i) + 4 * g);
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rb * 16 + u;
+                int k = -1;
+                if (nh[rb]) {
+                    k = atomicAdd(&sCnt[row], nh[rb]);
+                    if (k + nh[rb] > kPanCap) { k = -1; sFlag[p & 1] = 1; }
+                }
+                if (__ballot(k >= 0)) {
+                    const float tau_w = k >= 0 ? tau[rb] : INFINITY;      // lanes without a reservation match nothing
+                    unsigned addr = lds_list + (unsigned)(row * kPanCap + (k >= 0 ? k : 0)) * 8u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        unsigned long long sv;
-                        asm volatile("v_cmp_ge_f32 vcc, %3, %4\n\t"
-                                     "s_cbranch_vccz .Lpan_skip%=\n\t"
-                                     "s_and_saveexec_b64 %2, vcc\n\t"
-                                     "ds_write2_b32 %0, %1, %3 offset1:1\n\t"
-                                     "v_add_u32 %0, 8, %0\n\t"
-                                     "s_mov_b64 exec, %2\n"
-                                     ".Lpan_skip%=:\n\t"
-                                     "v_add_u32 %1, -1, %1"
-                                     : "+v"(addr), "+v"(nid), "=&s"(sv)
-                                     : "v"(acc[i][r]), "v"(tau_w)
-                                     : "vcc", "memory");
+                    for (int i = 0; i < NTW; ++i) {
+                        unsigned nid = ~(unsigned)(pbase + 16 * (w + 8 * i) + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            unsigned long long sv;
+                            asm volatile("v_cmp_ge_f32 vcc, %3, %4\n\t"
+                                         "s_cbranch_vccz .Lpan_skip%=\n\t"
+                                         "s_and_saveexec_b64 %2, vcc\n\t"
+                                         "ds_write2_b32 %0, %1, %3 offset1:1\n\t"
+                                         "v_add_u32 %0, 8, %0\n\t"
+                                         "s_mov_b64 exec, %2\n"
+                                         ".Lpan_skip%=:\n\t"
+                                         "v_add_u32 %1, -1, %1"
+                                         : "+v"(addr), "+v"(nid), "=&s"(sv)
+                                         : "v"(acc[rb][i][r]), "v"(tau_w)
+                                         : "vcc", "memory");
+                        }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();   // ---- barrier B
             safe = sFlag[p & 1] != 0;
         }
@@ -475,10 +514,11 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
             // ---- safe form: the panel is computed AGAIN, one tile per wave and round (128 consecutive ids per round), every row
             //      cut back to its exact top K after each round.  Runtime loops, one accumulator block: nothing of it lives in
             //      the fast path's registers.
-            if (tid < kPanRows) sCnt[tid] = sCnt0[tid];   // the slots written past the old count are dropped
+            if (tid < R) sCnt[tid] = sCnt0[tid];   // the slots written past the old count are dropped
             __syncthreads();
             auto exact_cut = [&]() {
-                for (int r = 2 * w; r < 2 * w + 2; ++r) {
+                for (int q = 0; q < 2 * RB; ++q) {
+                    const int r = (q >> 1) * 16 + 2 * w + (q & 1);
                     unsigned km;
                     const int m = pan_prune(sList + r * kPanCap, sCnt[r], a.K, a.K, 0, a.id_bits, lane, &km);
                     if (lane == 0) {
@@ -496,35 +536,39 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
                 int item = pbase + 16 * (w + 8 * i) + u;
                 item = item < a.n_items ? item : a.n_items - 1;
                 const float *brow = a.itabp + (size_t)item * dp + 4 * g;
-                sel_f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                for (int c = 0; c < DC; ++c) {
-                    const sel_f32x4 b = *reinterpret_cast<const sel_f32x4 *>(brow + 16 * c);
-                    const sel_f32x4 av = *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * 16 + u) * 4);
-                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, av.x, t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, av.y, t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, av.w, t, 0, 0, 0);
-                }
                 const int col0 = 16 * (w + 8 * i) + 4 * g;
-                const unsigned nib = bits[u * BWP + (col0 >> 5)] >> (col0 & 28);
-                // exact: once K entries are held (tau = the K-th key) a later id with s == tau loses the tie -> strict compare;
-                // with fewer than K held everything unmasked so far is in the list and everything unmasked enters
-                const float tau = sTau[u];
-                const bool strict = sStrict[u] != 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sc = t[r];
-                    if (a.ubias) sc = ((sc + ub) + (id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f)) + a.mean;
-                    const bool masked = (nib >> r) & 1u;
-                    if (!counted && !masked) {
-#pragma unroll
-                        for (int q = 0; q < NTG; ++q)
-                            cntr[q] += (id0 + r != tgt[q] && (sc > ts[q] || (sc == ts[q] && id0 + r < tgt[q]))) ? 1 : 0;
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = rb * 16 + u;
+                    sel_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                    for (int c = 0; c < DC; ++c) {
+                        const sel_f32x4 b = *reinterpret_cast<const sel_f32x4 *>(brow + 16 * c);
+                        const sel_f32x4 av = a_op(c, rb);
+                        t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, av.x, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, av.y, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, av.w, t, 0, 0, 0);
                     }
-                    if (!masked && (!strict || sc > tau)) {
-                        const int slot = atomicAdd(&sCnt[u], 1);
-                        sList[u * kPanCap + slot] = pan_raw(sc, (unsigned)(id0 + r));
+                    const unsigned nib = bits[row * BWP + (col0 >> 5)] >> (col0 & 28);
+                    // exact: once K entries are held (tau = the K-th key) a later id with s == tau loses the tie -> strict compare;
+                    // with fewer than K held everything unmasked so far is in the list and everything unmasked enters
+                    const float tau = sTau[row];
+                    const bool strict = sStrict[row] != 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sc = t[r];
+                        if (a.ubias) sc = ((sc + ub[rb]) + (id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f)) + a.mean;
+                        const bool masked = (nib >> r) & 1u;
+                        if (!counted && !masked) {
+#pragma unroll
+                            for (int q = 0; q < NTG; ++q)
+                                cntr[rb][q] += (id0 + r != tgt[q] && (sc > ts[rb][q] || (sc == ts[rb][q] && id0 + r < tgt[q]))) ? 1 : 0;
+                        }
+                        if (!masked && (!strict || sc > tau)) {
+                            const int slot = atomicAdd(&sCnt[row], 1);
+                            sList[row * kPanCap + slot] = pan_raw(sc, (unsigned)(id0 + r));
+                        }
                     }
                 }
                 __syncthreads();
@@ -534,7 +578,8 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         } else if (p + 1 < n_panels) {
             // ---- tau for the next panel, by the rows' owners: the (coarse) K-th key of a list that has grown long.  No barrier:
             //      nothing of this is touched before barrier A of the next panel
-            for (int r = 2 * w; r < 2 * w + 2; ++r) {
+            for (int q = 0; q < 2 * RB; ++q) {
+                const int r = (q >> 1) * 16 + 2 * w + (q & 1);
                 const int n = sCnt[r];
                 if (n >= a.K && n > kPanCap / 2) {   // (short lists: the old bound is good enough for the next panel)
                     unsigned km;
@@ -549,38 +594,41 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
             }
         }
         // the counts the next panel starts from (restored if it overflows), by the rows' owners
-        if (lane < 2) sCnt0[2 * w + lane] = sCnt[2 * w + lane];
+        if (lane < 2 * RB) { const int r = (lane >> 1) * 16 + 2 * w + (lane & 1); sCnt0[r] = sCnt[r]; }
         PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 5)
     }
     __syncthreads();
 
     // ---- target ranks: the 4 lane groups of a wave, then the 8 waves
 #pragma unroll
-    for (int t = 0; t < NTG; ++t) {
-        int v = cntr[t];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (g == 0 && t < n_in) atomicAdd(&sRank[u][t], v);
-    }
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+            int v = cntr[rb][t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0 && t < n_in) atomicAdd(&sRank[rb * 16 + u][t], v);
+        }
     __syncthreads();
-    for (int i = tid; i < kPanRows * n_in; i += kPanNT) {
+    for (int i = tid; i < R * n_in; i += kPanNT) {
         const int r = i / n_in, t = i % n_in;
         if (sUid[r] >= 0) a.target_rank[(size_t)(row0 + r) * a.n_targets + t] = sRank[r][t];
     }
     PAN_STAMP(34)
-    if (a.stamps && tid == 0) {   // diagnostic: candidates held at the end (sum and maximum over the 16 rows)
+    if (a.stamps && tid == 0) {   // diagnostic: candidates held at the end (sum and maximum over the rows)
         int sm = 0, mx = 0;
-        for (int r = 0; r < kPanRows; ++r) { sm += sCnt[r]; mx = sCnt[r] > mx ? sCnt[r] : mx; }
+        for (int r = 0; r < R; ++r) { sm += sCnt[r]; mx = sCnt[r] > mx ? sCnt[r] : mx; }
         a.stamps[(size_t)blockIdx.x * 36 + 32] = (unsigned long long)sm;
         a.stamps[(size_t)blockIdx.x * 36 + 33] = (unsigned long long)mx;
     }
-    // ---- results: a wave per row, the two rows of a wave side by side (two independent chains of lane exchanges)
-    {
+    // ---- results: a wave per row, two rows side by side (two independent chains of lane exchanges)
+#pragma unroll 1
+    for (int rb = 0; rb < RB; ++rb) {
         unsigned long long c[2][4];
         int nn[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int r = 2 * w + h;
+            const int r = rb * 16 + 2 * w + h;
             int n = row0 + r < a.nb ? sCnt[r] : 0;
             unsigned long long *row = sList + r * kPanCap;
             if (n > 256) {
@@ -594,7 +642,7 @@ __global__ __launch_bounds__(kPanNT, 4) void score_panel_kernel(const PanArgs a)
         pan_sort256x2(c[0], c[1], lane);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int r = 2 * w + h;
+            const int r = rb * 16 + 2 * w + h;
             if (row0 + r >= a.nb) continue;
             int *oid = a.top_ids + (size_t)(row0 + r) * a.K;
             float *osc = a.top_scores + (size_t)(row0 + r) * a.K;
@@ -621,37 +669,45 @@ inline bool pan_supported(int n_items, int d, int K, int n_targets)
 }
 // floats of scratch: the k-permuted item table (rows of 16 * DC floats), 16-byte aligned by the caller
 inline long long pan_scratch_floats(int n_items, int d) { return (long long)n_items * 16 * pan_dc(d) + 4; }
+// user rows per workgroup: 32 once that still gives every other CU a workgroup (RK_PAN_ROWS=16|32 for tuning / tests, read per call)
+inline int pan_rows(int nb)
+{
+    const char *fr = getenv("RK_PAN_ROWS");
+    const int force = fr ? atoi(fr) : 0;
+    if (force == 16 || force == 32) return force;
+    return nb >= 32 * 128 ? 32 : 16;
+}
 
-template <int NTW, int DC, int NTG>
+template <int NTW, int DC, int NTG, int RB>
 inline hipError_t pan_launch_one(const PanArgs &a, hipStream_t s)
 {
     static bool attr_set = false;
-    const size_t lds = pan_lds_bytes<NTW, DC>();
+    const size_t lds = pan_lds_bytes<NTW, DC, RB>();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_panel_kernel<NTW, DC, NTG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_panel_kernel<NTW, DC, NTG, RB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((score_panel_kernel<NTW, DC, NTG>), dim3((a.nb + kPanRows - 1) / kPanRows), dim3(kPanNT), lds, s, a);
+    hipLaunchKernelGGL((score_panel_kernel<NTW, DC, NTG, RB>), dim3((a.nb + 16 * RB - 1) / (16 * RB)), dim3(kPanNT), lds, s, a);
     return hipGetLastError();
 }
-template <int NTW, int DC>
+template <int NTW, int DC, int RB>
 inline hipError_t pan_launch_tg(const PanArgs &a, hipStream_t s)
 {
-    return a.n_targets <= 1 ? pan_launch_one<NTW, DC, 1>(a, s) : pan_launch_one<NTW, DC, kPanMaxT>(a, s);
+    return a.n_targets <= 1 ? pan_launch_one<NTW, DC, 1, RB>(a, s) : pan_launch_one<NTW, DC, kPanMaxT, RB>(a, s);
 }
-template <int NTW>
+template <int NTW, int RB>
 inline hipError_t pan_launch_dc(const PanArgs &a, hipStream_t s)
 {
-#ifdef PAN_DEV   // development builds: one instantiation (15 x 1920-item panels, dim 64, one target)
-    return pan_launch_one<15, 4, 1>(a, s);
+#ifdef PAN_DEV   // development builds: one instantiation per row count (1920-item panels, dim <= 64, one target)
+    return pan_launch_one<15, 4, 1, RB>(a, s);
 #else
     switch (pan_dc(a.d)) {
-    case 2: return pan_launch_tg<NTW, 2>(a, s);
-    case 4: return pan_launch_tg<NTW, 4>(a, s);
-    case 8: return pan_launch_tg<NTW, 8>(a, s);
-    default: return pan_launch_tg<NTW, 16>(a, s);
+    case 2: return pan_launch_tg<NTW, 2, RB>(a, s);
+    case 4: return pan_launch_tg<NTW, 4, RB>(a, s);
+    case 8: return pan_launch_tg<NTW, 8, RB>(a, s);
+    default: return pan_launch_tg<NTW, 16, RB>(a, s);
     }
 #endif
 }
@@ -677,5 +733,6 @@ inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s)
     const char *fw = getenv("RK_PAN_NTW");
     const int force = fw ? atoi(fw) : 0;
     const bool narrow = force ? force == 8 : a.n_items <= 1024;
-    return narrow ? pan_launch_dc<8>(a, s) : pan_launch_dc<15>(a, s);
+    if (narrow) return pan_launch_dc<8, 1>(a, s);   // (small catalogues: 16-row workgroups only)
+    return pan_rows(a.nb) == 32 ? pan_launch_dc<15, 2>(a, s) : pan_launch_dc<15, 1>(a, s);
 }

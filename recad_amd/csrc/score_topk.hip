@@ -377,20 +377,25 @@ static bool use_fused(int n_items, int dim, int K, int n_targets)
     return (force && atoi(force)) || n_items >= (1 << 18);
 }
 
-// The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  RK_PAN_FORCE=1 takes it wherever
-// it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 / RK_SEL_FORCE=1, which name the other two paths) forbids it; read per call.
-static bool use_panel(int n_items, int dim, int K, int n_targets)
+// The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  Default for catalogues of >= 16 384
+// items (measured, MI355X, against GEMM + selection: 16 384 x 34 474 x 64 1.36 vs 1.91 ms, 16 384 x 131 072 x 64 4.43 vs 6.76 ms,
+// 54 617 x 34 474 x 128 6.65 vs 7.77 ms, 8 192 x 131 072 x 256 5.71 vs 6.49 ms; 16 384 x 500 000 x 64 15.4 ms vs 18.6 for the
+// fused sweep; at ml1m size it loses, 105 vs 98 us); dim > 128 only with 32-row workgroups (>= 4096 users: the 16-row form is bound
+// by its L2 operand traffic there).  RK_PAN_FORCE=1 takes it wherever it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 /
+// RK_SEL_FORCE=1, which name the other two paths) forbids it; read per call.
+static bool use_panel(int nb, int n_items, int dim, int K, int n_targets)
 {
     const char *off = getenv("RK_PAN_OFF"), *force = getenv("RK_PAN_FORCE"), *soff = getenv("RK_SEL_OFF"), *sforce = getenv("RK_SEL_FORCE");
     if ((off && atoi(off)) || (soff && atoi(soff)) || (sforce && atoi(sforce))) return false;
     if (!pan_supported(n_items, dim, K, n_targets)) return false;
-    return (force && atoi(force)) || n_items <= kPanDefaultMaxItems;
+    if (force && atoi(force)) return true;
+    return n_items >= kPanDefaultMinItems && (dim <= 128 || pan_rows(nb) == 32);
 }
 
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
 {
     if (nb <= 0 || n_items <= 0) return 0;
-    if (use_panel(n_items, dim, K, n_targets)) return (int64_t)pan_scratch_floats(n_items, dim);              // the k-permuted item table
+    if (use_panel(nb, n_items, dim, K, n_targets)) return (int64_t)pan_scratch_floats(n_items, dim);              // the k-permuted item table
     if (use_fused(n_items, dim, K, n_targets)) return (int64_t)sel_scratch_floats(nb, n_items, n_targets);   // candidate slots + counts (per item range)
     return (int64_t)nb * n_items;
 }
@@ -409,7 +414,7 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
     hipStream_t s = (hipStream_t)stream;
-    if (use_panel(n_items, dim, K, n_targets)) {
+    if (use_panel(nb, n_items, dim, K, n_targets)) {
         // (no silent fall-through: the caller sized `scratch` for THIS path)
         if (reinterpret_cast<uintptr_t>(scratch) & 15) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 16-byte aligned (panel form)");
         PanArgs a;

@@ -30,7 +30,8 @@ top_sc = torch.zeros(nu, K, device=dev)
 ts = torch.empty(nu, 1, device=dev)
 tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
 need = int(_lib.lib().rk_score_topk_scratch_floats(nu, I, d, K, 1))
-n_wg = (nu + 15) // 16
+rows = int(os.environ.get("RK_PAN_ROWS", 32 if nu >= 4096 else 16))
+n_wg = (nu + rows - 1) // rows
 scratch = torch.zeros(need + n_wg * 72 + 64, device=dev)
 for _ in range(3):
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), nu, _lib.ptr(ids), _lib.ptr(itab), I, None, None, 0.0, _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids),
@@ -42,7 +43,7 @@ st = scratch.view(torch.uint8)[off: off + n_wg * 288].view(torch.int64).view(n_w
 phases = ["mfma + loads", "bitmap + barrier", "pass 1 (mask, counts, maxima)", "bound (first panel)", "collect + overflow check", "tau / prune + barrier"]
 n_pan = min(4, (I + 1919) // 1920 if I > 1024 else 1)
 tot = st[:, 35] - st[:, 0]
-print(f"workgroups {n_wg}; median workgroup lifetime {np.median(tot) / 100:.2f} us, kernel span {(st[:, 35].max() - st[:, 0].min()) / 100:.2f} us")
+print(f"workgroups {n_wg} of {rows} rows; median workgroup lifetime {np.median(tot) / 100:.2f} us, kernel span {(st[:, 35].max() - st[:, 0].min()) / 100:.2f} us")
 print(f"  {'prologue':32s} median {np.median(st[:, 1] - st[:, 0]) / 100:7.2f} us")
 prev = st[:, 1]
 for p_ in range(n_pan):
@@ -53,4 +54,4 @@ for p_ in range(n_pan):
 print(f"  {'ranks':32s} median {np.median(st[:, 34] - prev) / 100:7.2f} us   (after panel {n_pan - 1}; later panels of a longer sweep are in here)")
 print(f"  {'sort + output':32s} median {np.median(st[:, 35] - st[:, 34]) / 100:7.2f} us")
 print(f"  start spread {(st[:, 0].max() - st[:, 0].min()) / 100:.2f} us, end spread {(st[:, 35].max() - st[:, 35].min()) / 100:.2f} us")
-print(f"  candidates held at the end: mean per row {st[:, 32].mean() / 16:.1f}, largest row {st[:, 33].max():.0f}")
+print(f"  candidates held at the end: mean per row {st[:, 32].mean() / rows:.1f}, largest row {st[:, 33].max():.0f}")

@@ -306,9 +306,10 @@ def panel_scoring():
     os.environ.pop("RK_PAN_FORCE", None)
     os.environ.pop("RK_PAN_SAFE", None)
     os.environ.pop("RK_PAN_NTW", None)
+    os.environ.pop("RK_PAN_ROWS", None)
 
 
-@pytest.mark.parametrize("path", ["panel", "panel_safe", "panel_narrow", "sweep", "gemm"])
+@pytest.mark.parametrize("path", ["panel", "panel32", "panel_safe", "panel_narrow", "sweep", "gemm"])
 @pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
 def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
     """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
@@ -322,6 +323,8 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
         os.environ["RK_PAN_SAFE"] = "1"
     if path == "panel_narrow":
         os.environ["RK_PAN_NTW"] = "8"
+    if path.startswith("panel"):
+        os.environ["RK_PAN_ROWS"] = "32" if path == "panel32" else "16"
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
@@ -1593,9 +1596,11 @@ def test_fused_sweep_item_ranges(gpu_device, splits, fused_scoring):
 
 
 @pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
+@pytest.mark.parametrize("path", ["panel", "sweep"])
 @pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
-def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, fused_scoring):
-    """The fused scoring + selection sweep (score_select.h) on rows built to stress its threshold logic: constant
+def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path, request):
+    """The register-resident panel form (score_panel.h; config 1: 32-row workgroups, config 2: the narrow panels) and the
+    fused scoring + selection sweep (score_select.h) on rows built to stress their threshold logic: constant
     and few-valued rows (every score ties), scores ascending with the item id (every item beats the running
     threshold: repeated compactions), descending, long runs of seen items inside one tile, rows with fewer than
     K unseen items -- bit-identical lists, scores and ranks to the oracle's scan (ties: lower id first).
@@ -1603,8 +1608,13 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, fused_scoring):
     import os
     rng = np.random.default_rng(I + K)
     nu, d = 90, 16
-    if config:
+    request.getfixturevalue("panel_scoring" if path == "panel" else "fused_scoring")
+    if config and path == "sweep":
         os.environ["RK_SEL_CONFIG"] = str(config)   # force the 16-row / 64-row workgroup shape
+    if path == "panel":
+        os.environ["RK_PAN_ROWS"] = "32" if config == 1 else "16"
+        if config == 2:
+            os.environ["RK_PAN_NTW"] = "8"
     try:
         utab = np.zeros((nu, d), np.float32)
         itab = np.zeros((I, d), np.float32)
@@ -1647,6 +1657,7 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, fused_scoring):
                 assert np.array_equal(ts[b], rts) and np.array_equal(tr[b], rtr), (kind, b)
     finally:
         os.environ.pop("RK_SEL_CONFIG", None)
+        os.environ.pop("RK_PAN_ROWS", None)
 
 
 def _spmm_rows_host(rp, c, v, x, rows):
@@ -1659,12 +1670,13 @@ def _spmm_rows_host(rp, c, v, x, rows):
     return out
 
 
-@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("config4", 64, "default")])
+@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("c4s", 64, "gemm"), ("config4", 64, "default")])
 def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128),
     config 4 / 4 (250 K x 125 K, 25 M edges, d=64: rows of > 100 K nonzeros, i.e. hundreds of cross-workgroup
     pieces, 32-bit gather offsets at 96 MB tables) and config 4 itself (1 M x 500 K x 100 M edges: 200 M nonzeros,
-    384 MB tables, a 500 K-item catalogue scored through the fused sweep).  The oracle cannot replay these sizes in seconds, so:
+    384 MB tables, a 500 K-item catalogue; 'default' scores through the register-resident panel form at these sizes, 'fused'
+    and 'gemm' force the other two paths).  The oracle cannot replay these sizes in seconds, so:
     size-independent properties (linearity, symmetry, spectral bound of the normalised adjacency, determinism),
     float64 host restatements of SAMPLED rows (the longest rows included), a train step that moves the loss, and
     bit-exact top-K lists / target ranks against the oracle on sampled users."""
@@ -1672,6 +1684,8 @@ def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     from recad_amd.evaluate import eligible_users_device, full_catalog_topk
     if mode == "fused":
         request.getfixturevalue("fused_scoring")
+    if mode == "gemm":
+        request.getfixturevalue("unfused_scoring")
     if shape in ("c4s", "config4"):
         dd = synth.make_device(shape, gpu_device)
         d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
