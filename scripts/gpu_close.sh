@@ -3,7 +3,8 @@
 #   gpurun --timeout 2400 -- scripts/gpu_close.sh r03
 # -> gpurun_out/<tag>_*: GPU tests, smoke, the driver-style and the default bench line, the as-is graph, the ordered
 #    scatter, the larger shapes, rocprofv3 kernel stats of the default bench, PMC traffic of the dominant kernel
-#    (FETCH_SIZE / WRITE_SIZE / L2 hits in separate passes), the LDS kernel's in-kernel stamps and SQ counters.
+#    (FETCH_SIZE / WRITE_SIZE / L2 hits in separate passes), the LDS kernel's in-kernel stamps and SQ counters, the scoring
+#    paths side by side (score_probe), the panel form's stamps and SQ counters.
 tag=${1:-run}
 o=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -42,6 +43,14 @@ timeout 400 bash scripts/lds_pmc.sh > $o/${tag}_spmm_lds_sq_counters.txt 2>&1
 timeout 300 bash scripts/step_trace.sh > $o/${tag}_step_trace.txt 2>&1; cat $o/${tag}_step_trace.txt
 timeout 300 bash scripts/call_trace.sh > $o/${tag}_call_trace.txt 2>&1
 timeout 600 python scripts/bench_victims.py > /dev/null 2>&1; cp $o/bench_victims.json $o/${tag}_bench_victims.json
+# the register-resident panel scoring form against GEMM + selection (and the older sweep), its phase stamps and SQ counters
+( for shape in "5893 3702 64 20" "16384 34474 64 5" "54617 34474 128 3" "8192 34474 256 5" "16384 131072 64 3"; do
+    PROBE_MODES=panel,unfused timeout 300 python3 scripts/score_probe.py $shape 2>/dev/null | grep -v amdgpu.ids
+  done
+  PROBE_MODES=panel,fused,unfused timeout 600 python3 scripts/score_probe.py 16384 500000 64 2 2>/dev/null | grep -v amdgpu.ids
+  RK_PAN_ROWS=16 PROBE_MODES=panel timeout 300 python3 scripts/score_probe.py 54617 34474 128 3 2>/dev/null | grep "^panel" | sed 's/^panel /panel (16-row workgroups) /' ) > $o/${tag}_score_probe.txt; cat $o/${tag}_score_probe.txt
+( RK_PAN_ROWS=16 timeout 120 python3 scripts/pan_stamps.py 2>/dev/null | grep -v amdgpu.ids; timeout 200 python3 scripts/pan_stamps.py 54617 34474 128 2>/dev/null | grep -v amdgpu.ids ) > $o/${tag}_pan_stamps.txt
+timeout 900 bash scripts/pan_pmc.sh 16384 34474 64 > $o/${tag}_pan_sq_counters.txt 2>&1
 python3 - <<PY
 import json
 for n in ("bench_s20", "bench", "bench_asis", "bench_ordered", "bench_ldsoff", "bench_yelp_d128", "bench_c4s", "bench_config4", "bench_profiled"):
