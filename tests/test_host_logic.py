@@ -314,3 +314,33 @@ def test_ctypes_descriptors_match_the_header(tmp_path):
         assert C.sizeof(cls) == int(out[st]), (st, C.sizeof(cls), out[st])
         for f in fields:
             assert getattr(cls, rename.get(f, f)).offset == int(out[f"{st}.{f}"]), (st, f)
+
+
+def test_score_topk_path_selection_by_scratch_size(monkeypatch):
+    """rk_score_topk_scratch_floats (host code of the C ABI, no GPU needed) names the path rk_score_topk will take for a
+    request: GEMM + selection (a [nb, n_items] matrix) below 16 384 items, the register-resident panel form (a k-permuted copy
+    of the item table) from there on -- dim > 128 only with 32-row workgroups, i.e. >= 4096 users --, the older fused sweep
+    (1025 floats per user) when forced, and GEMM + selection for requests neither fused form takes (more than 4 targets)."""
+    from recad_amd import _lib
+    for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_OFF", "RK_PAN_FORCE", "RK_PAN_ROWS", "RK_SEL_SPLITS"):
+        monkeypatch.delenv(k, raising=False)
+    f = lambda nb, I, d, K=100, T=1: int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, T))
+    panel = lambda I, d: I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4
+    assert f(5893, 3702, 64) == 5893 * 3702                      # ml1m: GEMM + selection
+    assert f(16384, 34474, 64) == panel(34474, 64)
+    assert f(54617, 34474, 128) == panel(34474, 128)
+    assert f(150, 34474, 100) == panel(34474, 100)               # k padded to a multiple of 16
+    assert f(8192, 34474, 256) == panel(34474, 256)              # 32-row workgroups
+    assert f(1000, 34474, 256) == 1000 * 34474                   # dim > 128 with 16-row workgroups: GEMM + selection
+    assert f(16384, 500000, 64) == panel(500000, 64)
+    assert f(4096, 500000, 64, 100, 5) == 4096 * 500000          # five targets: neither fused form
+    assert f(4096, 34474, 64, 300) == 4096 * 34474               # K > 256
+    monkeypatch.setenv("RK_PAN_OFF", "1")
+    assert f(16384, 34474, 64) == 16384 * 34474
+    assert 4096 * 1025 <= f(4096, 500000, 64) <= 4096 * 1028 + 2  # >= 2^18 items: the older sweep
+    monkeypatch.delenv("RK_PAN_OFF")
+    monkeypatch.setenv("RK_PAN_FORCE", "1")
+    assert f(5893, 3702, 64) == panel(3702, 64)
+    monkeypatch.delenv("RK_PAN_FORCE")
+    monkeypatch.setenv("RK_SEL_OFF", "1")
+    assert f(16384, 500000, 64) == 16384 * 500000
