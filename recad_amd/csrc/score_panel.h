@@ -17,9 +17,12 @@
 //     lower bound of the K-th largest score; with groups of 8 scores about 1.25 K scores lie above it); afterwards the
 //     (coarse) K-th largest key of the row's list.  Later panels hold larger item ids, so "s >= tau" keeps a superset of
 //     the final top K whatever the ties.
-//   * a row whose list would overflow (tie-heavy or constant rows, K near 256) sends the workgroup through the SAFE
-//     form of the panel: one tile per wave and round (128 consecutive ids), every row cut back to its exact top K
-//     composites after each round -- exact by construction, slow, and only taken by degenerate rows.
+//   * a row whose list would overflow in a panel (scores that grow with the item id, a panel of systematically better items)
+//     gets its bound RAISED first: a bisection on the key space that counts straight from the registers finds a key T with
+//     K <= #(list and panel entries >= T) <= 256, the lists are cut to it and the panel is collected again.  Rows that no
+//     bound can separate (tie-heavy or constant rows, K near 256) send the workgroup through the SAFE form of the panel:
+//     computed again, one tile per wave and round (128 consecutive ids), every row cut back to its exact top K composites
+//     after each round -- exact by construction, slow, and only taken by degenerate rows.
 //   * at the end a wave per row cuts the list to <= 256 entries, sorts them (bitonic, 4 per lane) and writes the K
 //     results: (score desc, id asc) exactly like the oracle's scan.
 #pragma once
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
     float *sA = reinterpret_cast<float *>(pan_smem + (size_t)R * kPanCap * 8);                     // [DC][4][R] float4: the user rows, k-permuted
     unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)R * kPanCap * 8 + (size_t)DC * 1024 * RB);   // [2][R][BWP]
     __shared__ int sCnt[kPanMaxRows], sCnt0[kPanMaxRows], sUid[kPanMaxRows], sCur[kPanMaxRows], sEnd[kPanMaxRows], sRank[kPanMaxRows][kPanMaxT],
-        sFlag[2], sStrict[kPanMaxRows];
+        sFlag[2], sStrict[kPanMaxRows], sTot[kPanMaxRows], sCLo[kPanMaxRows], sAct[2], sFail;
+    __shared__ unsigned sLo[kPanMaxRows], sHi[kPanMaxRows];
     __shared__ float sTau[kPanMaxRows];
     const int tid = threadIdx.x, lane = tid & 63, w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int u0 = lane & 15, g0 = lane >> 4;
@@ -473,6 +477,8 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
             //      8-byte LDS store of (~id, score bits) and the bump of the lane's slot address.  (Written as asm: left to the
             //      compiler this loop keeps the compare masks of the counting loop alive in SGPRs and spills accumulators to scratch
             //      to build 64-bit store operands.)
+#pragma unroll 1
+            for (int attempt = 0;; ++attempt) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rb * 16 + u;
@@ -508,6 +514,98 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();   // ---- barrier B
             safe = sFlag[p & 1] != 0;
+            if (!safe || attempt == 1) break;
+            // ---- a list would overflow: the bound was too low for this panel (scores that grow with the item id, a panel of
+            //      systematically better items).  Raise it, per row, to a key T with K <= #(list and panel entries >= T) <= 256 --
+            //      a bisection on the key space that counts straight from the registers -- cut the lists to it and collect again.
+            //      Rows tied beyond that at their K-th key are left to the safe form.
+            if (tid < R) {
+                const unsigned klo = score_key(sTau[tid]);
+                sCLo[tid] = sCnt[tid] > kPanCap ? 0x7fffffff : 0;      // (sCnt: every lane's hits were added, so it is the exact count at tau)
+                sCnt[tid] = sCnt0[tid];
+                sLo[tid] = klo < 0x00800000u ? 0x00800000u : klo;
+                sHi[tid] = 0xffffffffu;
+                sTot[tid] = 0;
+            }
+            if (tid == 0) { sFlag[p & 1] = 0; sFail = 0; }
+            __syncthreads();
+#pragma unroll 1
+            for (int it = 0; it < 40; ++it) {
+                if (tid == 0) sAct[it & 1] = 0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = rb * 16 + u;
+                    const unsigned lo = sLo[row], hi = sHi[row];
+                    if (lo < hi && sCLo[row] > 256) {
+                        const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
+                        const float fm = key_score(mid);   // (a NaN pattern above +inf: nothing compares >= it, count 0)
+                        int c = 0;
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) c += acc[rb][i][r] >= fm ? 1 : 0;
+                        if (c) atomicAdd(&sTot[row], c);
+                    }
+                }
+                __syncthreads();
+                for (int q = 0; q < 2 * RB; ++q) {
+                    const int r = (q >> 1) * 16 + 2 * w + (q & 1);
+                    const unsigned lo = sLo[r], hi = sHi[r];
+                    if (lo < hi && sCLo[r] > 256) {   // (wave-uniform)
+                        const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
+                        const int n0 = sCnt0[r];
+                        int c = sTot[r];
+#pragma unroll
+                        for (int j = 0; j < kPanCap / 64; ++j) {
+                            const bool ge = j * 64 + lane < n0 && (unsigned)(pan_comp(sList[r * kPanCap + j * 64 + lane]) >> 32) >= mid;
+                            c += __popcll(__ballot(ge));
+                        }
+                        if (lane == 0) {
+                            if (c >= a.K) { sLo[r] = mid; sCLo[r] = c; } else sHi[r] = mid - 1u;
+                            sTot[r] = 0;
+                            const unsigned nlo = c >= a.K ? mid : lo, nhi = c >= a.K ? hi : mid - 1u;
+                            if (nlo < nhi && (c >= a.K ? c : sCLo[r]) > 256) sAct[it & 1] = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (!sAct[it & 1]) break;
+            }
+            // the lists cut to the new bounds (rows that did not search keep theirs)
+            for (int q = 0; q < 2 * RB; ++q) {
+                const int r = (q >> 1) * 16 + 2 * w + (q & 1);
+                if (sCLo[r] == 0) continue;               // this row fitted
+                if (sCLo[r] > 256) { if (lane == 0) sFail = 1; continue; }
+                const unsigned T = sLo[r];
+                const int n0 = sCnt0[r];
+                unsigned long long e[kPanCap / 64];
+                bool keep[kPanCap / 64];
+#pragma unroll
+                for (int j = 0; j < kPanCap / 64; ++j) {
+                    e[j] = j * 64 + lane < n0 ? sList[r * kPanCap + j * 64 + lane] : 0ULL;
+                    keep[j] = j * 64 + lane < n0 && (unsigned)(pan_comp(e[j]) >> 32) >= T;
+                }
+                int base = 0;
+#pragma unroll
+                for (int j = 0; j < kPanCap / 64; ++j) {
+                    const unsigned long long m = __ballot(keep[j]);
+                    if (keep[j]) sList[r * kPanCap + base + __popcll(m & ((1ULL << lane) - 1ULL))] = e[j];
+                    base += __popcll(m);
+                }
+                if (lane == 0) { sCnt[r] = base; sCnt0[r] = base; sTau[r] = key_score(T); }   // (sCnt0: what the safe form would restore)
+            }
+            __syncthreads();
+            if (sFail) break;                             // (safe is still set: the safe form takes the panel)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                tau[rb] = sTau[rb * 16 + u];
+                nh[rb] = 0;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nh[rb] += acc[rb][i][r] >= tau[rb] ? 1 : 0;
+            }
+            }
         }
         PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 4)
         if (safe) {

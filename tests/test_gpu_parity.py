@@ -1597,13 +1597,15 @@ def test_fused_sweep_item_ranges(gpu_device, splits, fused_scoring):
 
 @pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
 @pytest.mark.parametrize("path", ["panel", "sweep"])
-@pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
+@pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 100, 1, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
 def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path, request):
     """The register-resident panel form (score_panel.h; config 1: 32-row workgroups, config 2: the narrow panels) and the
     fused scoring + selection sweep (score_select.h) on rows built to stress their threshold logic: constant
     and few-valued rows (every score ties), scores ascending with the item id (every item beats the running
     threshold: repeated compactions), descending, long runs of seen items inside one tile, rows with fewer than
-    K unseen items -- bit-identical lists, scores and ranks to the oracle's scan (ties: lower id first).
+    K unseen items -- bit-identical lists, scores and ranks to the oracle's scan (ties: lower id first).  For the panel form
+    the ascending rows overflow a list in every panel (its bound refinement by counting), the constant and few-valued ones cannot
+    be separated by any bound (its safe form).
     The scores are made of exact pieces (zero dot product + item bias) where the pattern matters."""
     import os
     rng = np.random.default_rng(I + K)
