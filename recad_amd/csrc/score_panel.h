@@ -524,10 +524,33 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
                 sCLo[tid] = sCnt[tid] > kPanCap ? 0x7fffffff : 0;      // (sCnt: every lane's hits were added, so it is the exact count at tau)
                 sCnt[tid] = sCnt0[tid];
                 sLo[tid] = klo < 0x00800000u ? 0x00800000u : klo;
-                sHi[tid] = 0xffffffffu;
+                sHi[tid] = 0u;
                 sTot[tid] = 0;
             }
             if (tid == 0) { sFlag[p & 1] = 0; sFail = 0; }
+            __syncthreads();
+            // the search ends at the largest key in sight: the panel's maximum per row (registers) and the list's (its owner)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rb * 16 + u;
+                if (sCLo[row] > 256) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) m = fmaxf(m, fmaxf(fmaxf(acc[rb][i][0], acc[rb][i][1]), fmaxf(acc[rb][i][2], acc[rb][i][3])));
+                    if (m != -INFINITY) atomicMax(&sHi[row], score_key(m));
+                }
+            }
+            for (int q = 0; q < 2 * RB; ++q) {
+                const int r = (q >> 1) * 16 + 2 * w + (q & 1);
+                if (sCLo[r] > 256) {   // (wave-uniform)
+                    const int n0 = sCnt0[r];
+                    unsigned km = 0u;
+#pragma unroll
+                    for (int j = 0; j < kPanCap / 64; ++j)
+                        if (j * 64 + lane < n0) { const unsigned k = (unsigned)(pan_comp(sList[r * kPanCap + j * 64 + lane]) >> 32); km = k > km ? k : km; }
+                    if (km) atomicMax(&sHi[r], km);
+                }
+            }
             __syncthreads();
 #pragma unroll 1
             for (int it = 0; it < 40; ++it) {
