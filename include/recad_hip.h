@@ -299,10 +299,11 @@ int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v,
  * are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K] sorted by (score desc, item id
  * asc), padded with -1/-inf; for each target t its score and rank among the unseen items (hit@k <=> rank < k).
  * Three paths, identical results: (1) GEMM into a [nb, n_items] matrix in `scratch` + a selection pass (catalogues of
- * < 16 384 items, or requests the other two do not take); (2) the register-resident PANEL form, recad_amd/csrc/score_panel.h:
+ * < 16 384 items, small user blocks, or requests the other two do not take); (2) the register-resident PANEL form, recad_amd/csrc/score_panel.h:
  * a workgroup holds the scores of 16 / 32 users x 1920 items in its registers, selects from there and never writes a score
  * (K <= 256, n_targets <= 4, dim <= 256; scratch = a k-permuted copy of the item table, n_items * 16 * ceil(dim / 16) floats;
- * the default from 16 384 items on); (3) the older fused sweep, recad_amd/csrc/score_select.h (K <= 256, n_targets <= 4,
+ * the default from 16 384 items on for blocks of >= 8192 users, >= 4096 at dim <= 64: it parallelises over the users only);
+ * (3) the older fused sweep, recad_amd/csrc/score_select.h (K <= 256, n_targets <= 4,
  * dim <= 128; 1025 floats of scratch per user; RK_SEL_FORCE=1).  scratch: device float[rk_score_topk_scratch_floats(...)]
  * for the SAME nb, 16-byte aligned. */
 int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets);

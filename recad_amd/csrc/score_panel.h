@@ -790,13 +790,16 @@ inline bool pan_supported(int n_items, int d, int K, int n_targets)
 }
 // floats of scratch: the k-permuted item table (rows of 16 * DC floats), 16-byte aligned by the caller
 inline long long pan_scratch_floats(int n_items, int d) { return (long long)n_items * 16 * pan_dc(d) + 4; }
-// user rows per workgroup: 32 once that still gives every other CU a workgroup (RK_PAN_ROWS=16|32 for tuning / tests, read per call)
-inline int pan_rows(int nb)
+// user rows per workgroup: 32 (one workgroup per CU, every item operand feeds 8 MFMAs) pays from 8192 users on when the sweep is
+// operand-bound -- dim > 64 or catalogues of >= 65 536 items; measured 8 192 x 34 474 x 128 1.05 vs 1.18 ms, 16 384 x 131 072 x 64
+// 4.43 vs 4.72, but 4 096 x 34 474 x 64 0.69 vs 0.47 and 8 192 x 34 474 x 64 0.73 vs 0.70 (RK_PAN_ROWS=16|32 for tuning / tests,
+// read per call)
+inline int pan_rows(int nb, int n_items, int d)
 {
     const char *fr = getenv("RK_PAN_ROWS");
     const int force = fr ? atoi(fr) : 0;
     if (force == 16 || force == 32) return force;
-    return nb >= 32 * 128 ? 32 : 16;
+    return nb >= 8192 && (d > 64 || n_items >= 65536) ? 32 : 16;
 }
 
 template <int NTW, int DC, int NTG, int RB>
@@ -855,5 +858,5 @@ inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s)
     const int force = fw ? atoi(fw) : 0;
     const bool narrow = force ? force == 8 : a.n_items <= 1024;
     if (narrow) return pan_launch_dc<8, 1>(a, s);   // (small catalogues: 16-row workgroups only)
-    return pan_rows(a.nb) == 32 ? pan_launch_dc<15, 2>(a, s) : pan_launch_dc<15, 1>(a, s);
+    return pan_rows(a.nb, a.n_items, a.d) == 32 ? pan_launch_dc<15, 2>(a, s) : pan_launch_dc<15, 1>(a, s);
 }

@@ -377,19 +377,21 @@ static bool use_fused(int n_items, int dim, int K, int n_targets)
     return (force && atoi(force)) || n_items >= (1 << 18);
 }
 
-// The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  Default for catalogues of >= 16 384
-// items (measured, MI355X, against GEMM + selection: 16 384 x 34 474 x 64 1.36 vs 1.91 ms, 16 384 x 131 072 x 64 4.43 vs 6.76 ms,
-// 54 617 x 34 474 x 128 6.65 vs 7.77 ms, 8 192 x 131 072 x 256 5.71 vs 6.49 ms; 16 384 x 500 000 x 64 15.4 ms vs 18.6 for the
-// fused sweep; at ml1m size it loses, 105 vs 98 us); dim > 128 only with 32-row workgroups (>= 4096 users: the 16-row form is bound
-// by its L2 operand traffic there).  RK_PAN_FORCE=1 takes it wherever it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 /
-// RK_SEL_FORCE=1, which name the other two paths) forbids it; read per call.
+// The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  It parallelises over the USERS only
+// (16 or 32 per workgroup, the catalogue swept panel by panel), so it is the default for catalogues of >= 16 384 items AND enough
+// users to fill the chip: >= 8192, or >= 4096 at dim <= 64.  Measured on MI355X against GEMM + selection (ms): 16 384 x 34 474 x 64
+// 1.36 vs 1.91, 16 384 x 131 072 x 64 4.43 vs 6.76, 54 617 x 34 474 x 128 6.65 vs 7.77, 8 192 x 131 072 x 256 5.71 vs 6.49,
+// 4 096 x 34 474 x 64 0.47 vs 0.51, 4 096 x 500 000 x 64 5.56 vs 6.44; 16 384 x 500 000 x 64 15.4 vs 18.6 for the older fused
+// sweep; and where it is NOT taken: 5 893 x 3 702 x 64 0.105 vs 0.098, 2 048 x 131 072 x 64 1.55 vs 1.02, 4 096 x 34 474 x 128
+// 0.72 vs 0.64.  RK_PAN_FORCE=1 takes it wherever it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 / RK_SEL_FORCE=1, which name
+// the other two paths) forbids it; read per call.
 static bool use_panel(int nb, int n_items, int dim, int K, int n_targets)
 {
     const char *off = getenv("RK_PAN_OFF"), *force = getenv("RK_PAN_FORCE"), *soff = getenv("RK_SEL_OFF"), *sforce = getenv("RK_SEL_FORCE");
     if ((off && atoi(off)) || (soff && atoi(soff)) || (sforce && atoi(sforce))) return false;
     if (!pan_supported(n_items, dim, K, n_targets)) return false;
     if (force && atoi(force)) return true;
-    return n_items >= kPanDefaultMinItems && (dim <= 128 || pan_rows(nb) == 32);
+    return n_items >= kPanDefaultMinItems && (nb >= 8192 || (nb >= 4096 && dim <= 64));
 }
 
 RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)

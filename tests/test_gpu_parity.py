@@ -1672,13 +1672,13 @@ def _spmm_rows_host(rp, c, v, x, rows):
     return out
 
 
-@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("c4s", 64, "gemm"), ("config4", 64, "default")])
+@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("c4s", 64, "panel"), ("config4", 64, "default"), ("config4", 64, "panel")])
 def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128),
     config 4 / 4 (250 K x 125 K, 25 M edges, d=64: rows of > 100 K nonzeros, i.e. hundreds of cross-workgroup
     pieces, 32-bit gather offsets at 96 MB tables) and config 4 itself (1 M x 500 K x 100 M edges: 200 M nonzeros,
-    384 MB tables, a 500 K-item catalogue; 'default' scores through the register-resident panel form at these sizes, 'fused'
-    and 'gemm' force the other two paths).  The oracle cannot replay these sizes in seconds, so:
+    384 MB tables, a 500 K-item catalogue; the few sampled users score through GEMM + selection by default, 'fused' and
+    'panel' force the other two paths).  The oracle cannot replay these sizes in seconds, so:
     size-independent properties (linearity, symmetry, spectral bound of the normalised adjacency, determinism),
     float64 host restatements of SAMPLED rows (the longest rows included), a train step that moves the loss, and
     bit-exact top-K lists / target ranks against the oracle on sampled users."""
@@ -1686,8 +1686,8 @@ def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     from recad_amd.evaluate import eligible_users_device, full_catalog_topk
     if mode == "fused":
         request.getfixturevalue("fused_scoring")
-    if mode == "gemm":
-        request.getfixturevalue("unfused_scoring")
+    if mode == "panel":
+        request.getfixturevalue("panel_scoring")
     if shape in ("c4s", "config4"):
         dd = synth.make_device(shape, gpu_device)
         d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}

@@ -318,8 +318,8 @@ def test_ctypes_descriptors_match_the_header(tmp_path):
 
 def test_score_topk_path_selection_by_scratch_size(monkeypatch):
     """rk_score_topk_scratch_floats (host code of the C ABI, no GPU needed) names the path rk_score_topk will take for a
-    request: GEMM + selection (a [nb, n_items] matrix) below 16 384 items, the register-resident panel form (a k-permuted copy
-    of the item table) from there on -- dim > 128 only with 32-row workgroups, i.e. >= 4096 users --, the older fused sweep
+    request: GEMM + selection (a [nb, n_items] matrix) below 16 384 items or for user blocks too small to fill the chip, the
+    register-resident panel form (a k-permuted copy of the item table) otherwise, the older fused sweep
     (1025 floats per user) when forced, and GEMM + selection for requests neither fused form takes (more than 4 targets)."""
     from recad_amd import _lib
     for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_OFF", "RK_PAN_FORCE", "RK_PAN_ROWS", "RK_SEL_SPLITS"):
@@ -329,15 +329,17 @@ def test_score_topk_path_selection_by_scratch_size(monkeypatch):
     assert f(5893, 3702, 64) == 5893 * 3702                      # ml1m: GEMM + selection
     assert f(16384, 34474, 64) == panel(34474, 64)
     assert f(54617, 34474, 128) == panel(34474, 128)
-    assert f(150, 34474, 100) == panel(34474, 100)               # k padded to a multiple of 16
-    assert f(8192, 34474, 256) == panel(34474, 256)              # 32-row workgroups
-    assert f(1000, 34474, 256) == 1000 * 34474                   # dim > 128 with 16-row workgroups: GEMM + selection
+    assert f(8192, 34474, 100) == panel(34474, 100)              # k padded to a multiple of 16
+    assert f(8192, 34474, 256) == panel(34474, 256)
+    assert f(4096, 34474, 64) == panel(34474, 64)                # 4096 users fill the chip at dim <= 64 ...
+    assert f(4096, 34474, 128) == 4096 * 34474                   # ... not beyond
+    assert f(2048, 131072, 64) == 2048 * 131072                  # few users: the GEMM parallelises over the items too
     assert f(16384, 500000, 64) == panel(500000, 64)
-    assert f(4096, 500000, 64, 100, 5) == 4096 * 500000          # five targets: neither fused form
-    assert f(4096, 34474, 64, 300) == 4096 * 34474               # K > 256
+    assert f(8192, 500000, 64, 100, 5) == 8192 * 500000          # five targets: neither fused form
+    assert f(8192, 34474, 64, 300) == 8192 * 34474               # K > 256
     monkeypatch.setenv("RK_PAN_OFF", "1")
     assert f(16384, 34474, 64) == 16384 * 34474
-    assert 4096 * 1025 <= f(4096, 500000, 64) <= 4096 * 1028 + 2  # >= 2^18 items: the older sweep
+    assert 8192 * 1025 <= f(8192, 500000, 64) <= 8192 * 1028 + 2  # >= 2^18 items: the older sweep
     monkeypatch.delenv("RK_PAN_OFF")
     monkeypatch.setenv("RK_PAN_FORCE", "1")
     assert f(5893, 3702, 64) == panel(3702, 64)
