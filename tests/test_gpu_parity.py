@@ -309,7 +309,7 @@ def panel_scoring():
     os.environ.pop("RK_PAN_ROWS", None)
 
 
-@pytest.mark.parametrize("path", ["panel", "panel32", "panel_safe", "panel_narrow", "sweep", "gemm"])
+@pytest.mark.parametrize("path", ["panel", "panel32", "panel_safe", "panel32_safe", "panel_narrow", "sweep", "gemm"])
 @pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
 def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
     """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
@@ -319,12 +319,12 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
     from recad_amd import _lib
     fused = path == "sweep"
     request.getfixturevalue({"sweep": "fused_scoring", "gemm": "unfused_scoring"}.get(path, "panel_scoring"))
-    if path == "panel_safe":
+    if path in ("panel_safe", "panel32_safe"):
         os.environ["RK_PAN_SAFE"] = "1"
     if path == "panel_narrow":
         os.environ["RK_PAN_NTW"] = "8"
     if path.startswith("panel"):
-        os.environ["RK_PAN_ROWS"] = "32" if path == "panel32" else "16"
+        os.environ["RK_PAN_ROWS"] = "32" if path.startswith("panel32") else "16"
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
