@@ -51,8 +51,9 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--graph-steps", type=int, default=32, help="train steps per hipGraph replay (0 = plain launches)")
-    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for cpu_baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle replay of the timed path (parity object, cpu_baseline_port)")
+    ap.add_argument("--parity-steps", type=int, default=0, help="oracle steps laid next to the timed run (0 = 25 at ml1m size, 3 at yelp size)")
     ap.add_argument("--no-topk", action="store_true", help="skip the evaluation leg")
     ap.add_argument("--deterministic", action="store_true",
                     help="ordered (bit-reproducible) gradient scatter instead of float atomics (fused and row-sharded paths; labelled in config)")
@@ -140,31 +141,49 @@ def dry_run_worker(args, rank, world):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
-def cpu_baseline_port(d, graph, dim, layers, batch, triplets, n_steps_req, budget_s=10.0):
-    """The CPU oracle (a 1-thread C port of the reference path) on a bounded sample of the same
-    workload: the first few train steps of the same epoch.  Checker code, timed -- not shipped."""
+def oracle_replay(d, graph, layers, batch, triplets, user0, item0, n_steps):
+    """n_steps train steps of the CPU oracle (1-thread C restatement of lightgcn.py:137-169) on the SAME triplets, from the
+    SAME initial tables as the GPU run.  Checker code: -> per-step losses, final tables, seconds (graph build excluded)."""
     from oracle import oracle as orc
 
     U, I = d["n_users"], d["n_items"]
     ptr, idx = d["train"] if graph == "train" else d["test"]
     csr = orc.build_norm_adj(U, I, np.asarray(ptr).astype(np.int32), np.asarray(idx).astype(np.int32))
-    rng = np.random.default_rng(2023)
-    user = (rng.standard_normal((U, dim), dtype=np.float32) * 0.1).astype(np.float32)
-    item = (rng.standard_normal((I, dim), dtype=np.float32) * 0.1).astype(np.float32)
+    user, item = np.array(user0, dtype=np.float32, copy=True), np.array(item0, dtype=np.float32, copy=True)
     st = orc.AdamState(user.shape, item.shape)
     users, pos, neg = triplets
-    avail = len(users) // batch
+    losses = []
     t0 = time.perf_counter()
-    orc.lightgcn_step(csr, user, item, st, users[:batch], pos[:batch], neg[:batch], layers)
-    one = time.perf_counter() - t0
-    n = int(max(1, min(avail - 1, n_steps_req or max(2, budget_s / max(one, 1e-3)))))
-    t0 = time.perf_counter()
-    for s in range(1, n + 1):
-        orc.lightgcn_step(csr, user, item, st, users[s * batch:(s + 1) * batch], pos[s * batch:(s + 1) * batch],
-                          neg[s * batch:(s + 1) * batch], layers)
-    el = time.perf_counter() - t0
-    return {"value": n * batch / el, "unit": "interactions/s", "cores": 1, "kind": "port", "impl": "c-oracle",
-            "sample": f"{n} train steps of {batch} triplets on the same graph (oracle/recad_oracle.c, 1 thread, {el:.1f} s)"}
+    for s in range(n_steps):
+        sl = slice(s * batch, (s + 1) * batch)
+        losses.append(orc.lightgcn_step(csr, user, item, st, users[sl], pos[sl], neg[sl], layers))
+    return {"losses": np.asarray(losses, dtype=np.float64), "user": user, "item": item, "seconds": time.perf_counter() - t0,
+            "steps": n_steps}
+
+
+def relerr_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def run_steps(victim, triplets, B, lo, n_steps):
+    """Steps [lo, lo + n_steps) of the resident triplets through the victim's epoch call -- the timed call of this bench
+    (after victim.reserve(): one whole-call hipGraph replay for <= 64 steps, chunk graphs beyond)."""
+    users, pos, neg = triplets
+    sl = slice(lo * B, (lo + n_steps) * B)
+    return victim._run_epoch(users[sl], pos[sl], neg[sl], B)
+
+
+def parity_object(rep, gpu_losses, gpu_tables, tables_from):
+    """The self-validation every N = 1 run carries: the timed path next to the oracle on its own inputs."""
+    n = min(len(gpu_losses), rep["steps"])
+    lo = np.abs(np.asarray(gpu_losses[:n], dtype=np.float64) - rep["losses"][:n]) / np.abs(rep["losses"][:n])
+    out = {"steps": int(n), "max_rel_loss_err": float(lo.max()), "loss_tol": 1e-5, "tables_relerr": None, "tables_tol": 1e-4,
+           "tables_from": tables_from, "oracle": "oracle/recad_oracle.c (orc_lightgcn_step_general), same triplets, same initial tables"}
+    if gpu_tables is not None:
+        out["tables_relerr"] = max(relerr_max(gpu_tables[0], rep["user"]), relerr_max(gpu_tables[1], rep["item"]))
+    out["ok"] = bool(out["max_rel_loss_err"] <= out["loss_tol"] and (out["tables_relerr"] is None or out["tables_relerr"] <= out["tables_tol"]))
+    return out
 
 
 def mfma_gemm_probe(dev, nb=8192, n_items=34474, dim=256, reps=40):
@@ -281,7 +300,10 @@ def worker(args):
             c.append(ep[k])
         have += len(ep["users"])
     users, pos, neg = (torch.cat(c)[:need].contiguous() for c in cols)
-    host_triplets = tuple(t[: B * 64].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline sample
+    host_triplets = tuple(t[: B * 64].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline / parity sample
+    want_parity = world == 1 and not rows_mode and not big and not args.no_parity
+    n_par = min(args.warmup + args.steps, args.parity_steps or (25 if args.workload in ("ml1m", "tiny") else 3), 64) if want_parity else 0
+    init_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (victim.embedding_user.weight, victim.embedding_item.weight)) if want_parity else None
 
     sharded = None
     if rows_mode:
@@ -307,10 +329,10 @@ def worker(args):
         victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
 
     def run(lo, n_steps):
-        sl = slice(lo * B, (lo + n_steps) * B)
         if sharded is not None:
+            sl = slice(lo * B, (lo + n_steps) * B)
             return sharded.train_epoch(users[sl], pos[sl], neg[sl], B)
-        return victim._run_epoch(users[sl], pos[sl], neg[sl], B)
+        return run_steps(victim, (users, pos, neg), B, lo, n_steps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -318,13 +340,22 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm_losses = None
     if args.warmup > 0:
-        run(0, args.warmup)
+        wp = run(0, args.warmup)
+        if want_parity:
+            warm_losses = wp.sum(dim=1).double().cpu().numpy()   # (the loss buffer is reused by the timed call)
     barrier()
     t0 = time.perf_counter()
     partials = run(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    run_losses = run_tables = None
+    if want_parity:   # what the timed path produced, to be laid next to the oracle below (outside the timed region)
+        tl = partials.sum(dim=1).double().cpu().numpy()
+        run_losses = tl if warm_losses is None else np.concatenate([warm_losses, tl])
+        if args.warmup + args.steps == n_par:
+            run_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (victim.embedding_user.weight, victim.embedding_item.weight))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -461,9 +492,38 @@ def worker(args):
     mfma = None
     if rank == 0 and world == 1 and not args.no_topk and not big and not args.force_collectives:
         mfma = mfma_gemm_probe(dev)
-    cpu = cpu_aten = None
+    cpu = cpu_aten = parity = None
+    if want_parity:
+        # the oracle on the timed run's own triplets from the victim's own initial tables: parity of the timed path AND the
+        # 1-thread C baseline (cpu_baseline_port) from one replay
+        rep = oracle_replay(d, args.graph, args.layers, B, host_triplets, init_tables[0], init_tables[1], n_par)
+        tables_from = "the timed run (warm-up + timed steps)"
+        if run_tables is None:
+            # a longer run: its first n_par losses are compared as they are; the tables through a second victim started from
+            # the same initial tables and run through the same reserve() -> whole-call hipGraph sequence for n_par steps
+            torch.manual_seed(2023)
+            v2 = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers,
+                                   deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
+            v2.graph_steps = args.graph_steps
+            v2.embedding_user.weight.data.copy_(torch.from_numpy(init_tables[0]))
+            v2.embedding_item.weight.data.copy_(torch.from_numpy(init_tables[1]))
+            w2 = min(args.warmup, max(n_par // 5, 0))
+            v2.reserve(max(w2, n_par - w2) * B, B)
+            l2 = []
+            if w2:
+                l2.append(run_steps(v2, (users, pos, neg), B, 0, w2).sum(dim=1).double().cpu().numpy())
+            l2.append(run_steps(v2, (users, pos, neg), B, w2, n_par - w2).sum(dim=1).double().cpu().numpy())
+            l2 = np.concatenate(l2)
+            run_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (v2.embedding_user.weight, v2.embedding_item.weight))
+            tables_from = f"a second victim from the same initial tables through the same call sequence ({w2} + {n_par - w2} steps)"
+            assert np.allclose(l2, run_losses[:n_par], rtol=1e-5), "the replay leg must reproduce the timed run's losses"
+            del v2
+        parity = parity_object(rep, run_losses, run_tables, tables_from)
+        parity["spmm"] = "lds" if victim._ws.get("lds") is not None else "csr"
+        cpu = {"value": rep["steps"] * B / rep["seconds"], "unit": "interactions/s", "cores": 1, "kind": "port", "impl": "c-oracle",
+               "sample": f"{rep['steps']} train steps of {B} triplets on the same graph from the victim's initial tables "
+                         f"(oracle/recad_oracle.c, 1 thread, {rep['seconds']:.1f} s) -- the replay the parity object is computed from"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
-        cpu = cpu_baseline_port(d, args.graph, args.dim, args.layers, B, host_triplets, args.cpu_steps)
         cpu_aten = cpu_baseline_aten(d, args.graph, args.dim, args.layers, B, host_triplets)
 
     if rank == 0:
@@ -488,7 +548,7 @@ def worker(args):
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
-            "cpu_baseline_port": cpu, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
+            "cpu_baseline_port": cpu, "parity": parity, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
         if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
             same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]

@@ -102,7 +102,9 @@ typedef struct rk_spmm_epilogue {
     float lr, beta1, beta2, eps;
     /* optional frontier of the gather operand: device uint32 bitmap over x's rows, bit c clear => x[c] is all zeros and
      * the entries (r, c) are skipped (first backward layer of a train step: x = dL/dlight is non-zero on the minibatch's
-     * rows only).  Same sums, bit for bit; NULL = gather everything.  rk_rows_mark_bits sets / clears the bits. */
+     * rows only).  The surviving terms keep their CSR order but are dealt to the wave's lane groups anew, so a filtered sum
+     * equals the unfiltered one up to summation order (rounding, ~1e-7 relative) and is deterministic for a fixed bitmap;
+     * NULL = gather everything.  rk_rows_mark_bits sets / clears the bits. */
     const uint32_t *src_filter;
 } rk_spmm_epilogue;
 int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,

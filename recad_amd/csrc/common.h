@@ -28,6 +28,21 @@ extern thread_local char rk_err_buf[512];
 
 static constexpr int kWave = 64;
 
+// "Done once per DEVICE" flag for hipFuncSetAttribute (the attribute is applied to the current device's code object; a
+// process that moves to a second GPU must set it there too).  The call is idempotent, so two host threads racing here at
+// worst both make it.
+struct RkPerDeviceOnce {
+    unsigned long long mask[4] = {0ULL, 0ULL, 0ULL, 0ULL};   // up to 256 devices
+    bool need(int *dev_out)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) { *dev_out = -1; return true; }
+        *dev_out = dev;
+        return !(__atomic_load_n(&mask[dev >> 6], __ATOMIC_ACQUIRE) & (1ULL << (dev & 63)));
+    }
+    void done(int dev) { if (dev >= 0) __atomic_fetch_or(&mask[dev >> 6], 1ULL << (dev & 63), __ATOMIC_RELEASE); }
+};
+
 // Row r of a logical [n_rows, d] matrix stored as two blocks (rows < split in lo, the rest in hi).
 __device__ __forceinline__ const float *row2(const float *lo, const float *hi, int split, int r, int d)
 {

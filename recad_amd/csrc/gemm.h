@@ -780,13 +780,14 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // asynchronous launch; returns the hipError_t of the launch
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
-    static bool attr_set = false;
+    static RkPerDeviceOnce attr_once;
     static const int variant = getenv("RK_GEMM_VARIANT") ? atoi(getenv("RK_GEMM_VARIANT")) : 0;
-    if (!attr_set) {
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<128, 2, 2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<128>(2));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done(attr_dev);
     }
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
     if (nwg128 < 384 && variant != 3 && !g.a_ridx && !g.a_rmod) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
@@ -810,13 +811,14 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
                                  reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 64>),
                                  reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 32>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 32>),
                                  reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 32>)};
-            static bool deep_attr = false;
-            if (!deep_attr) {
+            static RkPerDeviceOnce deep_attr;
+            int deep_attr_dev;
+            if (deep_attr.need(&deep_attr_dev)) {
                 for (const void *f : fn) {
                     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * deep_floats<2, 64>() * (int)sizeof(float));
                     if (e != hipSuccess) return e;
                 }
-                deep_attr = true;
+                deep_attr.done(deep_attr_dev);
             }
             const int fl_a = half ? (fa == 1 ? deep_floats<1, 32>() : deep_floats<2, 32>()) : (fa == 1 ? deep_floats<1, 64>() : deep_floats<2, 64>());
             const int fl_b = fb == 1 ? deep_floats<1, 64>() : deep_floats<2, 64>();
@@ -842,13 +844,14 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
             (!g.acc_init || g.a_rmod > 0) && !g.drop_thresh24) {
             const void *fn[2] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>)};
-            static bool wide_attr = false;
-            if (!wide_attr) {
+            static RkPerDeviceOnce wide_attr;
+            int wide_attr_dev;
+            if (wide_attr.need(&wide_attr_dev)) {
                 for (const void *f : fn) {
                     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wide_floats<2>() * (int)sizeof(float));
                     if (e != hipSuccess) return e;
                 }
-                wide_attr = true;
+                wide_attr.done(wide_attr_dev);
             }
             int gx = (Ni + 127) / 128, gy = (g.M + 127) / 128;
             const size_t lds = (size_t)(wide_floats<1>() + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);

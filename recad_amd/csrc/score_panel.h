@@ -805,13 +805,14 @@ inline int pan_rows(int nb, int n_items, int d)
 template <int NTW, int DC, int NTG, int RB>
 inline hipError_t pan_launch_one(const PanArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
+    static RkPerDeviceOnce attr_once;
     const size_t lds = pan_lds_bytes<NTW, DC, RB>();
-    if (!attr_set) {
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_panel_kernel<NTW, DC, NTG, RB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done(attr_dev);
     }
     hipLaunchKernelGGL((score_panel_kernel<NTW, DC, NTG, RB>), dim3((a.nb + 16 * RB - 1) / (16 * RB)), dim3(kPanNT), lds, s, a);
     return hipGetLastError();

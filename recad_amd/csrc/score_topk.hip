@@ -345,11 +345,12 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     // beyond (14000 items, 56 KB: 285 vs 202 us -- two workgroups per CU)
     static const size_t lds_row_max = getenv("RK_TOPK_LDS_KB") ? (size_t)atoi(getenv("RK_TOPK_LDS_KB")) * 1024 : 40 * 1024;
     if (row_bytes <= lds_row_max) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static RkPerDeviceOnce attr_once;
+        int attr_dev;
+        if (attr_once.need(&attr_dev)) {
             RK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_rows_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr_set = true;
+            attr_once.done(attr_dev);
         }
         // (one wave per short row -- NT = 64 -- was measured too: 333 vs 250 us for 5950 x 3702)
         hipLaunchKernelGGL((topk_rows_kernel<true>), dim3(nb), dim3(kTopkNT), row_bytes, s, scores, n_items, user_ids, seen_ptr, seen_idx,

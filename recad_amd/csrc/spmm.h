@@ -56,8 +56,9 @@ struct SpmmArgs {
     // Frontier-sparse gather operand (first backward layer of a train step: x = dL/dlight is non-zero only on the
     // minibatch's <= 3B rows): bit c clear => x[c] is all zeros and entry (r, c) is skipped.  Every 64-entry chunk of
     // the column stream is tested against the bitmap and the hits are compacted (ds_permute) before the row gathers,
-    // so the launch moves sum_{s in batch} deg(s) rows instead of nnz; the surviving terms keep their order, i.e.
-    // the sums are bit-identical to the unfiltered launch.
+    // so the launch moves sum_{s in batch} deg(s) rows instead of nnz.  The surviving terms keep their order in the
+    // stream but are dealt to the lane groups anew (gather_round takes entry t*NG+grp of the COMPACTED chunk), so a
+    // filtered sum equals the unfiltered one up to summation order -- deterministic for a fixed bitmap, not bit-equal.
     const unsigned *src_filter;
     unsigned *mark_bits;         // set the bits of the current minibatch (first forward layer)
     unsigned *clear_bits;        // zero the bitmap (last backward layer)

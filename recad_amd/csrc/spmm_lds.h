@@ -360,8 +360,9 @@ inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStre
     const dim3 grid(info.n_wg), block(kLdsThreads);
 #define RK_LDS_CASE(A, B)                                                                                                  \
     do {                                                                                                                    \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
+        static RkPerDeviceOnce attr_once;                                                                                   \
+        int attr_dev_;                                                                                                      \
+        if (attr_once.need(&attr_dev_)) {                                                                                   \
             /* the gather addresses table rows by ABSOLUTE LDS address (table at 0): the kernel must own no static LDS */  \
             hipFuncAttributes fa_;                                                                                          \
             hipError_t e_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>));            \
@@ -370,7 +371,7 @@ inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStre
             e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_lds_kernel<A, B>),                      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes - 64);             \
             if (e_ != hipSuccess) return e_;                                                                                \
-            attr_set = true;                                                                                                \
+            attr_once.done(attr_dev_);                                                                                      \
         }                                                                                                                   \
         hipLaunchKernelGGL((spmm_lds_kernel<A, B>), grid, block, (size_t)info.lds_bytes, s, a);                              \
     } while (0)

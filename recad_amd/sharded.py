@@ -295,7 +295,6 @@ class ShardedLightGCN:
         self.gprop, self.gego = z(W * M, d), z(W * M, d)  # replicated, zero outside a step
         self.t = 0
         self._plan = None
-        self._src_filter = None
         # Step capture: one full-batch train step -- its ~2 L C^2 + 6 kernel launches AND its collectives -- recorded once into a
         # graph (torch.cuda.CUDAGraph on the launch stream: the C-ABI launches go to torch's current stream, so they are
         # captured with the RCCL calls) and replayed per step; the step's indices are copied into fixed staging buffers first
@@ -386,7 +385,7 @@ class ShardedLightGCN:
         return full[: self.U].contiguous(), full[self.U:].contiguous()
 
     # ------------------------------------------------------------------ propagation (shared by train / eval)
-    def _layer(self, x, ready, first_add, final_kw, gather_into):
+    def _layer(self, x, ready, first_add, final_kw, gather_into, src_filter=None):
         """One propagation layer on the owned rows: y_c = sum_k tile[c][k] . x (+ first_add_c), the partial sums chained through
         the SpMM's `add` epilogue in self.y.  Source chunk k is the OUTER loop: its tiles only need gathered chunk k of x
         (`ready[k]`: the pending all-gather works of that chunk, or None), so they run while the later chunks are still in
@@ -407,8 +406,8 @@ class ShardedLightGCN:
                 add = first_add(c) if first else ybuf[rs]
                 kw = dict(final_kw(c)) if final else {}
                 want_y = kw.pop("want_y", True)
-                if getattr(self, "_src_filter", None) is not None:
-                    kw["src_filter"] = self._src_filter
+                if src_filter is not None:
+                    kw["src_filter"] = src_filter   # (an argument, not instance state: an exception mid-step cannot leave it set)
                 ops.spmm(self.tiles[c][k], x, add=add, y=ybuf[rs] if (not final or want_y) else None, **kw)
                 if final and gather_into is not None:
                     pending[c] = self._all_gather_chunk(ybuf[rs], gather_into, c, True)
@@ -447,9 +446,16 @@ class ShardedLightGCN:
         n_steps = (int(n_triplets) + batch - 1) // batch
         dev = self.device
         if self._plan is None or self._plan["cap_steps"] < n_steps or self._plan["batch"] != batch:
+            # `rows` (the minibatch's compact light rows) is baked into the captured step graph: it is allocated once per
+            # batch size and survives a growing epoch; only the per-step loss rows (copied out after a replay, never captured)
+            # are re-sized.  A new batch size drops the captured graph with the buffer it was recorded on.
+            rows = None if (self._plan is None or self._plan["batch"] != batch) else self._plan["rows"]
+            if rows is None:
+                rows = torch.zeros(3 * batch, self.d, device=dev, dtype=torch.float32)
+                self._graph = None
             self._plan = {"cap_steps": n_steps, "batch": batch,
                           "loss": torch.zeros(n_steps, _lib.RK_LOSS_PARTIALS, device=dev, dtype=torch.float32),
-                          "rows": torch.zeros(3 * batch, self.d, device=dev, dtype=torch.float32)}
+                          "rows": rows}
         return self._plan
 
     def _epoch_plan(self, users, pos, neg, batch):
@@ -516,7 +522,6 @@ class ShardedLightGCN:
         for j in range(1, L + 1):
             last = j == L
             nxt = self.xfull[j & 1]
-            self._src_filter = frontier if j == 1 else None
             if not self.tiled:
                 ready = self._ready_all(ready)
 
@@ -527,9 +532,8 @@ class ShardedLightGCN:
             def final_kw(c, last=last):
                 rs = slice(c * lay.Mc, (c + 1) * lay.Mc)
                 return {"adam": dict(adam, p=self.e0[rs], m=self.m[rs], v=self.v[rs]), "want_y": False} if last else {}
-            ready = self._layer(x, ready, first_add, final_kw, None if last else nxt)
+            ready = self._layer(x, ready, first_add, final_kw, None if last else nxt, src_filter=frontier if j == 1 else None)
             x = nxt
-        self._src_filter = None
         # only the minibatch's rows of the replicated gradient buffers are non-zero
         ops.zero_rows(self.gprop, self.gego, idx_pos3)
         if frontier is not None:

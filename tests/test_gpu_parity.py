@@ -248,19 +248,32 @@ def _eval_against_golden(g, m, device):
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hr_rows
     users = eligible_users(g["train_ptr"], g["train_idx"], g["target_ids"])
     assert np.array_equal(users, g["eval_users"])
-    res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=100, chunk=1000)
+    K = 100
+    res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=K + 1, chunk=1000)   # (the 101st score decides ties at the @100 cutoff)
     rows = hr_rows(users, res, g["topks"])
     ref = g["eval_rows"]
     assert rows.shape == ref.shape and np.array_equal(rows[:, 0], ref[:, 0])
     assert np.allclose(rows[:, 1], ref[:, 1], rtol=1e-5, atol=1e-6)
     tie_free = g["top_min_gap"] > G.TIE_RTOL
     assert np.array_equal(rows[tie_free, 2:], ref[tie_free, 2:])
-    for k in range(len(g["topks"])):  # HR@K within 1e-4 relative (north_star)
-        assert abs(rows[:, 2 + k].mean() - ref[:, 2 + k].mean()) <= 1e-4 * max(ref[:, 2 + k].mean(), 1e-12) + 1.0 / len(rows)
+    # HR@K within 1e-4 relative (north_star) + what the CUTOFF-ambiguous rows can move: rows whose target score is within
+    # the observed GPU-vs-reference score noise of the score on the other side of the @k boundary -- there the reference's
+    # own hit flag is decided by rounding (or, at exact ties, by numpy's unspecified quicksort order).
+    T = len(g["target_ids"])
+    assert T == 1
+    ts, rank, sc = res["target_score"][:, 0].astype(np.float64), res["target_rank"][:, 0], res["top_scores"].astype(np.float64)
+    tol = 4.0 * np.abs(rows[:, 1] - ref[:, 1]).max() + 1e-12
+    for q, k in enumerate(g["topks"]):
+        k = int(k)
+        other = np.where(rank < k, sc[:, min(k, K)], sc[:, k - 1])   # first item outside the cutoff / last item inside it
+        amb = np.isfinite(other) & (np.abs(ts - other) <= tol)
+        assert abs(rows[:, 2 + q].mean() - ref[:, 2 + q].mean()) <= 1e-4 * max(ref[:, 2 + q].mean(), 1e-12) + amb.sum() / len(rows), (k, int(amb.sum()))
+        assert amb.sum() <= 0.02 * len(rows) + 2, (k, int(amb.sum()))   # the allowance must stay a handful of rows, not a blanket
     es = int(g["eval_stride"])
-    mine = [(res["top_ids"][r], res["top_scores"][r]) for r in range(0, len(users), es)]
+    mine = [(res["top_ids"][r][:K], res["top_scores"][r][:K]) for r in range(0, len(users), es)]
     exact = G.compare_topk_lists(mine, g["top_ids"], g["top_scores"])
     assert exact >= 0.97 * len(mine), exact
+    res = dict(res, top_ids=res["top_ids"][:, :K], top_scores=res["top_scores"][:, :K])
     return res, users
 
 
@@ -493,6 +506,71 @@ def test_defense_workflow_on_device(gpu_device):
     assert np.allclose(g.val.cpu().numpy(), ov, rtol=4e-7, atol=0)
 
 
+def _ncf_fp64_gate_arbiter(m, g, emb, W, b, pw, pb, names, pick):
+    """fp64 arbiter for the step-1 NCF gradients (ncf.py:112-131,143-147) of golden batch 0, which the victim `m` has just
+    run gradient-only (its activations are still in the workspace).  Checks, and returns the number of ambiguous gates:
+    (a) the reference's golden gradients equal fp64 autograd's (ATen's blocked sums decide every gate like fp64 does);
+    (b) every ReLU gate the GPU decides differently from fp64 sits on a pre-activation that is zero to within fp32
+        summation noise (|z| <= 1e-5 of the layer's rms pre-activation);
+    (c) the fp64 gradient WITH THE GPU'S GATES equals the GPU's gradient to fp32 rounding for every tensor."""
+    f, L = int(g["factor"]), int(g["layers"])
+    n0 = int(g["batch_len"][0])
+    u, i, y = (torch.from_numpy(g["batches"][0, k, :n0].astype(np.int64)) for k in range(3))
+    ug, ig, um, im = (torch.from_numpy(a).double() for a in emb)
+    W64 = [torch.from_numpy(a).double() for a in W]
+    b64 = [torch.from_numpy(a).double() for a in b]
+    pw64, pb64 = torch.from_numpy(pw).double().view(-1), float(np.asarray(pb).reshape(-1)[0])
+    # the GPU's gates: acts[l + 1] (post-ReLU output of layer l) > 0, layout ncf.hip act_off()
+    mb = m._ws["max_batch"]
+    acts, off, gates = m._ws["acts"], 0, []
+    for l in range(L + 1):
+        width = f * 2 ** (L - l)
+        if l >= 1:
+            gates.append((acts[off: off + n0 * width].view(n0, width) > 0).cpu())
+        off += mb * width
+    # fp64 forward
+    xs, zs = [torch.cat([um[u], im[i]], dim=1)], []
+    for l in range(L):
+        zs.append(xs[-1] @ W64[l].t() + b64[l])
+        xs.append(torch.relu(zs[-1]))
+    gmf = ug[u] * ig[i]
+    logit = torch.cat([gmf, xs[-1]], dim=1) @ pw64 + pb64
+    assert abs(float(torch.nn.functional.binary_cross_entropy_with_logits(logit, y.double())) - g["losses"][0]) <= 1e-6 * abs(g["losses"][0])
+    n_amb = 0
+    for l in range(L):
+        flip = gates[l] != (zs[l] > 0)
+        n_amb += int(flip.sum())
+        if flip.any():
+            assert float(zs[l][flip].abs().max()) <= 1e-5 * float(zs[l].pow(2).mean().sqrt()), (l, int(flip.sum()))
+
+    def backward(gate):
+        d0 = (torch.sigmoid(logit) - y.double()) / n0
+        dcat = d0.unsqueeze(1) * pw64.unsqueeze(0)
+        out = {"predict_layer.weight": (d0.unsqueeze(1) * torch.cat([gmf, xs[-1]], dim=1)).sum(0), "predict_layer.bias": d0.sum().view(1)}
+        dg = dcat[:, :f]
+        out["embed_user_GMF.weight"] = torch.zeros_like(ug).index_add_(0, u, dg * ig[i])
+        out["embed_item_GMF.weight"] = torch.zeros_like(ig).index_add_(0, i, dg * ug[u])
+        dx = dcat[:, f:]
+        for l in range(L - 1, -1, -1):
+            dz = dx * gate[l].double()
+            out[f"MLP_layers.{3 * l + 1}.weight"] = dz.t() @ xs[l]
+            out[f"MLP_layers.{3 * l + 1}.bias"] = dz.sum(0)
+            dx = dz @ W64[l]
+        E = um.shape[1]
+        out["embed_user_MLP.weight"] = torch.zeros_like(um).index_add_(0, u, dx[:, :E])
+        out["embed_item_MLP.weight"] = torch.zeros_like(im).index_add_(0, i, dx[:, E:])
+        return out
+    g_true = backward([z > 0 for z in zs])
+    g_gpu_gates = backward(gates)
+    for nme, gr in zip(names, m._ws["grad"]):
+        ref = g["grad1_" + nme]
+        t64 = pick(nme, g_true[nme].numpy())
+        assert np.abs(ref.reshape(t64.shape) - t64).max() <= 2e-6 * np.abs(t64).max(), ("golden vs fp64", nme)
+        got, want = gr.cpu().numpy().astype(np.float64), g_gpu_gates[nme].numpy().reshape(tuple(gr.shape))
+        assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max(), ("gpu vs fp64 with the gpu's gates", nme, np.abs(got - want).max() / np.abs(want).max())
+    return n_amb
+
+
 @pytest.mark.parametrize("name", ["ncf_dev_f8_l3", "ncf_game_f32_l5", "ncf_game_f256_l3", "ncf_game_f256_l5"])
 def test_ncf_train_golden(gpu_device, name):
     """NCF against the reference's goldens; the two f256 cases are BASELINE.json config 5 (Amazon-game,
@@ -526,24 +604,32 @@ def test_ncf_train_golden(gpu_device, name):
     part = m._run_epoch(b0["users"], b0["items"], b0["labels"], n0, apply_update=False)
     assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
     big = f >= 256
-
-    def grad_close(nme, got, ref):
-        """Step-1 gradients vs the reference.  At factor_num=256 a few pre-activations of the 1024 x (1024..4096) tower
-        are zero to within summation noise, and ATen's blocked sums and the k-ordered fmaf chain (GPU == oracle) put
-        them on opposite sides of the ReLU gate.  One flipped gate in an upper layer changes that sample's dX through
-        the dense weights, i.e. adds a rank-1 term to EVERY lower dW: many elements move, each by <= 1e-3 of the
-        largest (the CPU oracle shows the same 7e-4 / 9e-4 against this golden; checked tightly against it below)."""
-        ref = ref.reshape(got.shape)
-        err = np.abs(got - ref).max() / np.abs(ref).max()
-        return (err < 2e-5 if not big else err <= 3e-2), err   # L=5: the oracle itself is 1.1e-2 from this golden on dW of layer 0
-
-    for nme, gr in zip(names, m._ws["grad"]):
-        ok, err = grad_close(nme, pick(nme, gr), g["grad1_" + nme])
-        assert ok, (nme, err)
-    if name == "ncf_game_f256_l3":
-        # and tightly against the oracle (same summation order): 3 s of CPU for this tower
+    if not big:
+        for nme, gr in zip(names, m._ws["grad"]):
+            got, ref = pick(nme, gr), g["grad1_" + nme]
+            err = np.abs(got - ref.reshape(got.shape)).max() / np.abs(ref).max()
+            assert err < 2e-5, (nme, err)
+    else:
+        # factor_num = 256: step-1 gradients of the lower tower layers differ from the golden by up to 1e-3 (L = 3) / 1e-2
+        # (L = 5) of the largest entry.  The fp64 arbiter below shows what that is: a handful of the 1.8 M (L = 3) / 8 M
+        # (L = 5) pre-activations are zero to within fp32 summation noise, the k-ordered fmaf chain (GPU == oracle) and
+        # ATen's blocked sums land on opposite sides of the ReLU gate there, and a flipped gate adds a rank-1 term of weight
+        # 1/B to every lower dW.  (ATen's sums are the more accurate ones: the golden agrees with fp64 autograd to 4e-7.)
+        # So the pin is: (1) every gate the GPU decides differently from fp64 sits on a numerically-zero pre-activation --
+        # the tie-ambiguous positions of this path, like equal scores in a top-K list; (2) with the gates forced to the
+        # GPU's choice the fp64 gradient equals the GPU's to fp32 rounding, for EVERY tensor -- no 3e-2 allowance.
+        n_amb = _ncf_fp64_gate_arbiter(m, g, (ug, ig, um, im), W, b, pw, pb, names, pick)
+        assert n_amb <= 64, n_amb
+    if big:
+        # and tightly against the oracle (same summation order): the whole batch at L = 3 (3 s of CPU), a 128-sample batch
+        # at L = 5 (the reference default depth, default.py:123-125: 10 s of CPU)
         P = orc.NCFParams(f, L, ug, ig, um, im, W, b, pw, pb)
-        _, ograds = orc.ncf_step(P, *(g["batches"][0, k, :n0] for k in range(3)), apply_update=False)
+        nq = n0 if L <= 3 else 128
+        if nq != n0:
+            for gr in m._ws["grad"]:
+                gr.zero_()
+            m._run_epoch(b0["users"][:nq], b0["items"][:nq], b0["labels"][:nq], nq, apply_update=False)
+        _, ograds = orc.ncf_step(P, *(g["batches"][0, k, :nq] for k in range(3)), apply_update=False)
         for nme, gr, og in zip(names, m._ws["grad"], ograds):
             assert G.relerr(gr.cpu().numpy(), og.reshape(tuple(gr.shape))) < 2e-5, nme
     for gr in m._ws["grad"]:
@@ -565,9 +651,9 @@ def test_ncf_train_golden(gpu_device, name):
             ok, info = G.adam_close(pick(nme, params[nme]), g["final_" + nme], 1e-3, steps, outlier_frac=5e-3, travel_frac=0.5)
             assert ok, (nme, info)
     elif name == "ncf_game_f256_l3":
-        # f256: most entries of the first tower layers have gradients BELOW the reference's own summation noise at this
-        # init (see grad_close), so Adam's sign-like first steps differ entry by entry between ATen and ANY k-ordered
-        # implementation: the trained tables are pinned by the oracle replaying the same steps instead (10 s of CPU)
+        # f256: most entries of the first tower layers have gradients BELOW fp32 summation noise at this init, so Adam's
+        # sign-like first steps differ entry by entry between ATen and ANY k-ordered implementation: the trained tables
+        # are pinned by the oracle replaying the same steps instead (10 s of CPU)
         for s_ in range(steps):
             nb_ = int(g["batch_len"][s_])
             orc.ncf_step(P, *(g["batches"][s_, k, :nb_] for k in range(3)))
@@ -575,6 +661,31 @@ def test_ncf_train_golden(gpu_device, name):
             ok, info = G.adam_close(params[nme].detach().cpu().numpy(), ref.reshape(tuple(params[nme].shape)), 1e-3, steps,
                                     outlier_frac=5e-3, travel_frac=0.5)
             assert ok, (nme, info)
+    else:
+        # f256 / L = 5 (the reference's default depth): the same pin on a model restarted from the initial tensors and
+        # trained for 3 steps of 64 samples, GPU and oracle side by side (the oracle needs 5 s per such step)
+        m2 = model.from_config("victim", "ncf", factor_num=f, num_layers=L).I(dataset=ds)
+        for p_, a in zip((m2.embed_user_GMF, m2.embed_item_GMF, m2.embed_user_MLP, m2.embed_item_MLP), (ug, ig, um, im)):
+            p_.weight.data.copy_(torch.from_numpy(a))
+        for l, x in enumerate([x for x in m2.MLP_layers if isinstance(x, torch.nn.Linear)]):
+            x.weight.data.copy_(torch.from_numpy(W[l]))
+            x.bias.data.copy_(torch.from_numpy(b[l]))
+        m2.predict_layer.weight.data.copy_(torch.from_numpy(pw))
+        m2.predict_layer.bias.data.copy_(torch.from_numpy(pb))
+        m2 = m2.to(gpu_device)
+        nb_, st_ = 64, 3
+        cols = [torch.from_numpy(g["batches"][1, k, : nb_ * st_].astype(np.int64)).to(gpu_device) for k in range(3)]
+        gl = m2._run_epoch(*cols, nb_).sum(dim=1).double().cpu().numpy()
+        P2 = orc.NCFParams(f, L, ug, ig, um, im, W, b, pw, pb)
+        for s_ in range(st_):
+            ol, _ = orc.ncf_step(P2, *(g["batches"][1, k, s_ * nb_:(s_ + 1) * nb_] for k in range(3)))
+            assert abs(gl[s_] - ol) <= LOSS_RTOL * abs(ol), (s_, gl[s_], ol)
+        p2 = dict(m2.named_parameters())
+        for nme, ref in zip(names, P2.tensors()):
+            ok, info = G.adam_close(p2[nme].detach().cpu().numpy(), ref.reshape(tuple(p2[nme].shape)), 1e-3, st_,
+                                    outlier_frac=5e-3, travel_frac=0.5)
+            assert ok, (nme, info)
+        del m2, p2
     if name == "ncf_dev_f8_l3":
         _eval_against_golden(g, m, gpu_device)
     if "f256" in name:
@@ -593,6 +704,18 @@ def test_ncf_train_golden(gpu_device, name):
             ref_ids = set(int(x) for x in g["top_ids"][r] if x >= 0)
             assert len(ref_ids & set(int(x) for x in res["top_ids"][r])) >= 0.9 * len(ref_ids), r
             assert np.allclose(res["top_scores"][r][:5], g["top_scores"][r][:5], rtol=2e-3, atol=1e-5)
+        # and the evaluation path itself (per-user layer-0 prefix + pair GEMM, rk_ncf_forward over the catalogue) on THIS
+        # model's trained tensors against the oracle's forward: a sample of one user's scores, tight
+        Pt = orc.NCFParams(f, L, *(params[n_].detach().cpu().numpy() for n_ in names[:4]),
+                           [params[n_].detach().cpu().numpy() for n_ in names[4:4 + L]],
+                           [params[n_].detach().cpu().numpy() for n_ in names[4 + L:4 + 2 * L]],
+                           params[names[-2]].detach().cpu().numpy(), params[names[-1]].detach().cpu().numpy())
+        uid = torch.as_tensor(users[:1].astype(np.int32), device=gpu_device)
+        row = torch.empty(1, m.num_items, device=gpu_device)
+        m.score_matrix(uid, row)
+        its = np.random.default_rng(5).choice(m.num_items, 256 if L <= 3 else 96, replace=False)
+        osc = orc.ncf_forward(Pt, np.full(len(its), int(users[0])), its)
+        assert np.allclose(row[0].cpu().numpy()[its], osc, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("name,chunks", [("lightgcn_game_d64_tg", 1), ("lightgcn_game_d64_tg", 3), ("lightgcn_dev_d128_l2_tg", 2)])
@@ -844,6 +967,97 @@ def test_full_size_properties_ml1m(gpu_device):
     # idempotence: evaluating twice gives identical lists
     res2 = full_catalog_topk(m, users, ptr, idx, [0, 17], K=100)
     assert np.array_equal(res2["top_ids"], ti)
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "ordered"])
+@pytest.mark.parametrize("lds", [True, False])
+def test_lightgcn_timed_path_vs_oracle_ml1m(gpu_device, lds, scatter):
+    """The driver-timed path at ITS OWN size (BASELINE.json config[1]: ml1m-shaped 5950 x 3702, 469K train edges, d = 64,
+    L = 3, B = 1024) through exactly bench.py's sequence -- victim.reserve() -> 5 warm-up steps -> 20 steps, each call ONE
+    whole-call hipGraph replay (prologue pack, LdsEpi::cnt closed-form reg gradient, sliced Adam state, unpack on the LDS
+    path) -- against the oracle's lightgcn.py:137-169 restatement on the same triplets from the same tables: per-step loss
+    <= 1e-5 relative, trained tables <= 1e-4 of the largest entry; LDS and row-gather SpMM, atomic and ordered scatter."""
+    import bench
+    from recad_amd import dataset, model, synth
+    W, K, B, dim, layers = 5, 20, 1024, 64, 3
+    d = synth.make("ml1m")
+    ds = dataset.from_config("implicit", "ml1m", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], need_graph=True,
+                             device=gpu_device, graph_source="train", pairwise_batch_size=B, seed=1234)
+    torch.manual_seed(2023)
+    m = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=layers, deterministic=scatter == "ordered").I(dataset=ds)
+    m.use_lds = lds
+    m = m.to(gpu_device)
+    m.graph_steps = 32
+    ep = ds.generate_epoch()
+    trip = tuple(ep[k][: (W + K) * B].contiguous() for k in LGN_KEYS)
+    u0, i0 = (p.detach().cpu().numpy().copy() for p in (m.embedding_user.weight, m.embedding_item.weight))
+    m.reserve(max(W, K) * B, B)
+    l_warm = bench.run_steps(m, trip, B, 0, W).sum(dim=1).double().cpu().numpy()
+    l_run = bench.run_steps(m, trip, B, W, K).sum(dim=1).double().cpu().numpy()
+    assert _took_lds(m) == lds
+    rep = bench.oracle_replay(d, "train", layers, B, tuple(t.cpu().numpy() for t in trip), u0, i0, W + K)
+    par = bench.parity_object(rep, np.concatenate([l_warm, l_run]),
+                              tuple(p.detach().cpu().numpy() for p in (m.embedding_user.weight, m.embedding_item.weight)), "test")
+    assert par["steps"] == W + K
+    assert par["max_rel_loss_err"] <= LOSS_RTOL, par
+    assert par["tables_relerr"] <= TABLE_RTOL, par
+    assert int(m.optimizer.state[m.embedding_user.weight]["step"].item()) == W + K
+
+
+def test_sharded_capture_survives_a_growing_epoch(gpu_device):
+    """the captured step graph bakes the pointer of the plan's compact light-row buffer; a later, LONGER epoch at
+    the same batch size re-sizes the plan.  The buffer must survive that (or the graph be dropped): a 3-step epoch, then a
+    9-step epoch on one trainer with capture on, against the eager trainer -- ordered scatter, so bit for bit."""
+    from recad_amd.sharded import ShardedLightGCN
+    g = G.load("lightgcn_game_d64_tg")
+    U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    rng = np.random.default_rng(9)
+    B, n1, n2 = 256, 3 * 256, 9 * 256
+    users, pos, neg = (torch.from_numpy(rng.integers(0, hi, n2)).to(gpu_device) for hi in (U, I, I))
+    outs = []
+    for capture in (False, None):
+        tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device), chunks=2,
+                             deterministic=True, capture=capture)
+        l1 = tr.train_epoch(users[:n1], pos[:n1], neg[:n1], B).numpy().copy()
+        rows_before = tr._plan["rows"].data_ptr()
+        junk = [torch.full((3 * B, d), 7.0, device=gpu_device) for _ in range(4)]   # would land in a freed `rows` block
+        l2 = tr.train_epoch(users, pos, neg, B).numpy().copy()
+        assert tr._plan["cap_steps"] == 9 and tr._plan["rows"].data_ptr() == rows_before
+        assert (tr._graph is not None) == (capture is None)
+        del junk
+        tu, ti = tr.tables()
+        outs.append((l1, l2, tu.cpu().numpy(), ti.cpu().numpy()))
+    a, b = outs
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("d", [64, 128, 100])
+def test_spmm_src_filter_contract(gpu_device, d):
+    """rk_spmm_epilogue.src_filter (frontier-sparse first backward layer): x is non-zero on the marked rows only; the
+    filtered launch equals the unfiltered one up to summation order (the compaction re-deals the surviving terms to the lane
+    groups: include/recad_hip.h), is bit-reproducible for a fixed bitmap, and both match the oracle."""
+    from recad_amd.sharded import HipOps
+    rng = np.random.default_rng(100 + d)
+    n = 3000
+    rowptr, col, val = _rand_csr(rng, n, 40, long_rows=[(5, 2900), (77, 700), (9, 0)])
+    ops = HipOps()
+    slab = ops.make_slab(rowptr, col, val, gpu_device)
+    hot = rng.choice(n, 300, replace=False)
+    x = np.zeros((n, d), dtype=np.float32)
+    x[hot] = rng.standard_normal((len(hot), d), dtype=np.float32)
+    xt = torch.from_numpy(x).to(gpu_device)
+    bits = ops.new_row_bits(n, gpu_device)
+    ops.mark_rows(bits, torch.from_numpy(hot.astype(np.int64)).to(gpu_device), True)
+    ys = [torch.empty(n, d, device=gpu_device) for _ in range(3)]
+    ops.spmm(slab, xt, y=ys[0])
+    ops.spmm(slab, xt, y=ys[1], src_filter=bits)
+    ops.spmm(slab, xt, y=ys[2], src_filter=bits)
+    ref = orc.spmm(rowptr, col, val, x)
+    assert torch.equal(ys[1], ys[2]), "deterministic for a fixed bitmap"
+    assert G.relerr(ys[0].cpu().numpy(), ref) < 2e-6 and G.relerr(ys[1].cpu().numpy(), ref) < 2e-6
+    assert G.relerr(ys[1].cpu().numpy(), ys[0].cpu().numpy()) < 1e-6
 
 
 def test_state_dict_roundtrip_and_device_moves(gpu_device):

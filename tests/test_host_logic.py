@@ -44,12 +44,13 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{f} imports the oracle"
-    # helper scripts neither; bench.py only inside its cpu_baseline leg, __graft_entry__.py only inside smoke()
+    # helper scripts neither; bench.py only inside the oracle replay its parity / cpu_baseline_port leg runs (the checker,
+    # timed -- never the thing measured), __graft_entry__.py only inside smoke()
     for f in os.listdir(os.path.join(ROOT, "scripts")):
         if f.endswith((".py", ".sh")):
             src = open(os.path.join(ROOT, "scripts", f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"scripts/{f} imports the oracle"
-    for f, fn in (("bench.py", "cpu_baseline_port"), ("__graft_entry__.py", "smoke")):
+    for f, fn in (("bench.py", "oracle_replay"), ("__graft_entry__.py", "smoke")):
         src = open(os.path.join(ROOT, f)).read()
         hits = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle", src, re.M)]
         assert len(hits) == 1, (f, hits)
