@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 7
+#define RK_ABI_VERSION 8
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -237,12 +237,22 @@ typedef struct rk_lightgcn_desc {
                                                * gradient is applied in closed form (lambda / nb * count * E0) and the BPR kernel
                                                * scatters three rows per triplet instead of six; coef must then hold
                                                * 3 * RK_MAX_GRAPH_STEPS floats */
+    int32_t *lds_sync;                        /* optional (ABI 8), int32[RK_LDS_SYNC_WORDS], zero-initialised, this handle's own: with
+                                               * it the L propagation layers of a forward / backward pass run as ONE launch (<= 4
+                                               * layers per launch) whose workgroups hand the layers over to each other per column
+                                               * group through agent-scope counters kept here (recad_amd/csrc/spmm_lds.h:
+                                               * spmm_lds_multi_kernel; same sums, same bits as one launch per layer).  Word
+                                               * RK_LDS_SYNC_ERR is set if a wait ever gave up (rk_lightgcn_sync_status). */
 } rk_lightgcn_desc;
+#define RK_LDS_SYNC_WORDS 2560
+#define RK_LDS_SYNC_ERR 2336
 #define RK_MAX_GRAPH_STEPS 64
 
 typedef struct rk_lightgcn *rk_lightgcn_t;
 
 int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *out);
+/* *status = desc.lds_sync[RK_LDS_SYNC_ERR] (0 = every in-launch hand-off completed; no lds_sync: 0).  Synchronises the stream. */
+int rk_lightgcn_sync_status(rk_lightgcn_t h, int32_t *status, void *stream);
 int rk_lightgcn_destroy(rk_lightgcn_t h);
 
 /* LightGCN.computer(), recad/model/victim/lightgcn.py:82-113: desc.light[N,dim] =

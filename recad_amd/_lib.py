@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
+RK_LDS_SYNC_WORDS = 2560
 
 
 class HipLibraryMissing(RuntimeError):
@@ -65,6 +66,7 @@ class LightGCNDesc(C.Structure):
         ("row_bits", C.c_void_p),
         ("keep_prob", C.c_float), ("reserved3", C.c_int32), ("drop_seed", C.c_uint64), ("tpos", C.c_void_p),
         ("lds_plan", C.c_void_p), ("lds_info", LdsInfo), ("lsum", C.c_void_p), ("e0s", C.c_void_p), ("ms", C.c_void_p), ("vs", C.c_void_p), ("cnt", C.c_void_p),
+        ("lds_sync", C.c_void_p),
     ]
 
 
@@ -127,6 +129,7 @@ _SIGNATURES = {
     "rk_bpr_rows_ordered": [_I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "rk_lightgcn_create": [C.POINTER(LightGCNDesc), C.POINTER(_P)],
     "rk_lightgcn_destroy": [_P],
+    "rk_lightgcn_sync_status": [_P, C.POINTER(_I32), _P],
     "rk_lightgcn_propagate": [_P, _P],
     "rk_lightgcn_propagate_dropout": [_P, C.c_uint64, _P],
     "rk_lightgcn_train_epoch": [_P, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _P],

@@ -1,6 +1,7 @@
 // LightGCN victim hot path on gfx950: propagate (lightgcn.py:82-113), BPR train step
 // (lightgcn.py:137-169) as 2L+1 launches per step, optionally replayed from a hipGraph.
 #include <algorithm>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -8,6 +9,7 @@
 #include "spmm_lds.h"
 
 thread_local char rk_err_buf[512] = "";
+static_assert(LS_WORDS <= RK_LDS_SYNC_WORDS && LS_ERR == RK_LDS_SYNC_ERR, "include/recad_hip.h and spmm_lds.h disagree about the sync words");
 
 struct rk_lightgcn {
     rk_lightgcn_desc d;
@@ -421,6 +423,7 @@ static int check_desc(const rk_lightgcn_desc &d)
         if (d.lds_info.n_users != d.n_users || d.lds_info.n_items != d.n_items || d.lds_info.dim != d.dim || d.lds_info.n_wg <= 0)
             RK_FAIL(RK_EINVAL, "lightgcn: lds_info does not describe this graph / dim");
         if (reinterpret_cast<uintptr_t>(d.lds_plan) & 15) RK_FAIL(RK_EINVAL, "lightgcn: lds_plan must be 16-byte aligned");
+        if (d.lds_sync && (reinterpret_cast<uintptr_t>(d.lds_sync) & 127)) RK_FAIL(RK_EINVAL, "lightgcn: lds_sync must be 128-byte aligned");
     }
     if (((size_t)d.n_users + d.n_items) * d.dim * sizeof(float) >= (1ULL << 32))
         RK_FAIL(RK_EINVAL, "lightgcn: (U+I)*dim*4 must be < 4 GiB (32-bit gather offsets)");
@@ -435,6 +438,16 @@ RK_EXPORT int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *ou
     rk_lightgcn *h = new rk_lightgcn();
     h->d = *desc;
     *out = h;
+    return RK_OK;
+}
+
+RK_EXPORT int rk_lightgcn_sync_status(rk_lightgcn_t h, int32_t *status, void *stream)
+{
+    if (!h || !status) RK_FAIL(RK_EINVAL, "rk_lightgcn_sync_status: bad arguments");
+    *status = 0;
+    if (!h->d.lds_sync) return RK_OK;
+    RK_HIP(hipMemcpyAsync(status, h->d.lds_sync + LS_ERR, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return RK_OK;
 }
 
@@ -503,18 +516,42 @@ static int lds_sync(const rk_lightgcn_desc &d, bool with_moments, int to_sliced,
         job.zero[1] = clear_gego ? d.gego : nullptr;   // (only the ordered scatter writes gego on this path)
         job.zero_i = d.cnt;
     }
+    if (to_sliced) job.zero_sync = d.lds_sync;   // (nullable) a call starts from clean hand-off counters
     hipLaunchKernelGGL(lds_pack_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, s, g, job, to_sliced);
     RK_CHECK_LAUNCH();
     return RK_OK;
 }
+
+// phases [p0, p1) of a pass as ONE multi-phase launch (spmm_lds_multi_kernel); every phase but the last publishes
+static int launch_lds_multi(const rk_lightgcn_desc &d, const LdsInfo &li, const LdsArgs *ph, int n, hipStream_t s)
+{
+    for (int p0 = 0; p0 < n; p0 += kLdsMaxPhases) {
+        const int m = std::min(kLdsMaxPhases, n - p0);
+        if (m == 1) { RK_HIP(spmm_lds_launch(li, ph[p0], s)); continue; }
+        LdsMultiArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.plan = d.lds_plan; ma.sync = d.lds_sync; ma.n_phases = m;
+        for (int k = 0; k < m; ++k) {
+            ma.ph[k].x = ph[p0 + k].x;
+            ma.ph[k].e = ph[p0 + k].e;
+            ma.ph[k].e.publish = (k + 1 < m) ? 1 : 0;
+            if (ma.ph[k].e.bump && k + 1 < m) RK_FAIL(RK_EINVAL, "internal: only the last phase of a launch may bump the step counter");
+        }
+        RK_HIP(spmm_lds_multi_launch(li, ma, s));
+    }
+    return RK_OK;
+}
+
+static bool lds_fused(const rk_lightgcn_desc &d) { return d.lds_sync != nullptr && d.n_layers >= 2; }
 
 static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s, bool training)
 {
     const int L = d.n_layers;
     const LdsInfo li = lds_info(d);
     float *bufs[2] = {d.buf_a, d.buf_b};
+    std::vector<LdsArgs> ph((size_t)L);
     for (int l = 1; l <= L; ++l) {
-        LdsArgs a;
+        LdsArgs &a = ph[(size_t)l - 1];
         memset(&a, 0, sizeof(a));
         a.plan = d.lds_plan;
         a.x = (l == 1) ? d.e0s : bufs[l & 1];
@@ -524,8 +561,9 @@ static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s, bool tra
         a.e.sum_rm = (l == L) ? 1 : 0;
         a.e.sum_scale = (l == L) ? 1.0f / (float)(L + 1) : 1.0f;
         if (training && l == 1) a.e.zero_cnt = d.cnt;   // (nullable) the incidence counts of the previous step
-        RK_HIP(spmm_lds_launch(li, a, s));
     }
+    if (lds_fused(d)) return launch_lds_multi(d, li, ph.data(), L, s);
+    for (int l = 0; l < L; ++l) RK_HIP(spmm_lds_launch(li, ph[(size_t)l], s));
     return RK_OK;
 }
 
@@ -534,8 +572,9 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
     const int N = d.n_users + d.n_items, L = d.n_layers;
     const LdsInfo li = lds_info(d);
     float *bufs[2] = {d.buf_a, d.buf_b};
+    std::vector<LdsArgs> ph((size_t)L);
     for (int j = 1; j <= L; ++j) {
-        LdsArgs a;
+        LdsArgs &a = ph[(size_t)j - 1];
         memset(&a, 0, sizeof(a));
         a.plan = d.lds_plan;
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
@@ -559,8 +598,9 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
         } else {
             a.e.y = bufs[(j + 1) & 1];
         }
-        RK_HIP(spmm_lds_launch(li, a, s));
     }
+    if (lds_fused(d)) { int rc = launch_lds_multi(d, li, ph.data(), L, s); if (rc) return rc; }
+    else for (int j = 0; j < L; ++j) RK_HIP(spmm_lds_launch(li, ph[(size_t)j], s));
     if (L == 1) {   // gprop is the gather operand of the only backward SpMM: cleaned by a kernel (see launch_backward)
         const long long n4 = (long long)N * d.dim / 4;
         hipLaunchKernelGGL(zero_f4_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s,

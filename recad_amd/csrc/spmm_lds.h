@@ -34,7 +34,7 @@ __host__ __device__ __forceinline__ size_t sl_off(const LdsDims &g, int r, int k
 // plan buffer (device int32 words), header words
 enum {
     LP_MAGIC = 0, LP_NWG, LP_U, LP_I, LP_D, LP_LSU, LP_LSI, LP_NBLK0, LP_NBLK1, LP_WG_OFS, LP_BLK_OFS, LP_DINV_OFS,
-    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_HDR_WORDS = 32
+    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_MQ_OFS, LP_HDR_WORDS = 32
 };
 static constexpr int kLdsMagic = 0x4c445331;  // "LDS1"
 // block descriptor words (one per (half, row block), shared by all slices)
@@ -64,6 +64,9 @@ struct LdsEpi {
     const int *cnt;
     const float *creg, *reg_p;
     int *zero_cnt;               // nullable: cnt is cleared here (a launch in which nobody reads it)
+    // multi-phase launch (spmm_lds_multi_kernel): a later phase of the SAME launch gathers / reads y and sum_out -- they are
+    // stored write-through (sc1) and the workgroup's arrival is counted
+    int publish;
 };
 
 struct LdsArgs {
@@ -80,6 +83,27 @@ __device__ __forceinline__ float4 f4_plus(float4 a, float4 b) { return make_floa
 typedef float lds_f4n __attribute__((ext_vector_type(4)));
 typedef const lds_f4n __attribute__((address_space(3))) *lds_f4_ptr;
 
+// ---- in-launch hand-off traffic (multi-phase launch): every byte a later phase reads was stored write-through (sc1) and
+// is loaded with sc1 buffer loads (L1 bypassed; cdna_hip_programming.md Guideline 16 R1, MI355X_MICROARCH.md visibility table
+// row 1: one lane per storing workgroup adds to an agent-scope counter behind every wave's vmcnt(0) + the workgroup barrier,
+// the consumer polls it with an sc1 load, a workgroup barrier, then ONLY sc1 loads of the handed-off bytes).
+typedef unsigned lds_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lds_rsrc(const float *p, size_t n_floats)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, p ? (int)(unsigned)(n_floats * 4) : 0, 0x00020000);
+}
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, size_t float_off)
+{
+    const lds_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(unsigned)(float_off * 4), 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, size_t float_off, float4 v)
+{
+    lds_u4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)(unsigned)(float_off * 4), 0, 16);
+}
+
 // epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
 // the row's sum is ready
 struct LdsRowOps {
@@ -89,8 +113,10 @@ struct LdsRowOps {
     size_t so, ro;
 };
 
-template <int LP>
-__device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds)
+// HAND: a phase of the multi-phase launch -- x / add / sum_in may have been written by OTHER workgroups of this launch (sc1
+// loads only), y / sliced sum_out are published write-through when e.publish is set.
+template <int LP, bool HAND = false>
+__device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds)
 {
     constexpr int SL = 64 / LP, S = 4 * LP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,7 +127,7 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
     const float *dinv = reinterpret_cast<const float *>(plan + plan[LP_DINV_OFS]);
     const float *dsrc = dinv + (half ? 0 : U), *ddst = dinv + (half ? U : 0);
     // the source class's slice table: n_src * S contiguous floats
-    const float4 *s4 = reinterpret_cast<const float4 *>(a.x + (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S);
+    const float4 *s4 = reinterpret_cast<const float4 *>(ax + (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S);
     const int n4 = n_src * LP;
     // LDS row of source row c: sources sorted by degree are dealt round-robin over the 16 / LP bank classes, so the hot
     // columns (an item half the users rated) do not pile up in one class of every lane group
@@ -112,11 +138,14 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
     const uint4 *stream = reinterpret_cast<const uint4 *>(plan) + bd[LB_STREAM_OFS];
     const int n_rows = bd[LB_NROWS], row0 = bd[LB_ROW0];
     const int *pp = plan + bd[LB_PP_OFS];
-    const LdsEpi &e = a.e;
+    const size_t nd = (size_t)(U + I) * (size_t)d;
+    const __amdgpu_buffer_rsrc_t rs_x = lds_rsrc(HAND ? ax : nullptr, nd), rs_add = lds_rsrc(HAND ? e.add : nullptr, nd),
+                                 rs_sum = lds_rsrc(HAND && e.sum_out ? e.sum_in : nullptr, nd);
+    const size_t x_off = (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S;   // first float of the slice table
     const int lso = half ? plan[LP_LSI] : plan[LP_LSU];  // slice width (log2) of the OUTPUT class's block
     const size_t cls_base = half ? (size_t)U * d : 0;
     const int node0 = half ? U : 0;
-    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 0] = wall_clock64();
+    if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 0] = wall_clock64();
     // LDS layout: [slice table][16 / LP zero rows, one per bank class][chunk partials][task descriptors (int2)][queue head]
     // (the table sits at LDS address 0, so an entry's address is its stream word shifted)
     float4 *tab = lds;
@@ -135,8 +164,13 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
         o.p0 = pp[lr]; o.p1 = pp[lr + 1];
         o.dr = ddst[r];
         o.addv = make_float4(0.f, 0.f, 0.f, 0.f); o.sumv = o.addv;
-        if (e.add) o.addv = *reinterpret_cast<const float4 *>(e.add + o.so);
-        if (e.sum_out) o.sumv = *reinterpret_cast<const float4 *>(e.sum_in + o.so);
+        if (HAND) {
+            if (e.add) o.addv = ld16_sc1(rs_add, o.so);
+            if (e.sum_out) o.sumv = ld16_sc1(rs_sum, o.so);
+        } else {
+            if (e.add) o.addv = *reinterpret_cast<const float4 *>(e.add + o.so);
+            if (e.sum_out) o.sumv = *reinterpret_cast<const float4 *>(e.sum_in + o.so);
+        }
         return o;
     };
     // this thread's first epilogue row: its operand loads fly under the staging and the gather
@@ -151,7 +185,7 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * kLdsThreads;
-            if (i < n4) { v[u] = s4[i]; s[u] = dsrc[i / LP]; pr[u] = perm[i / LP]; }
+            if (i < n4) { v[u] = HAND ? ld16_sc1(rs_x, x_off + (size_t)i * 4) : s4[i]; s[u] = dsrc[i / LP]; pr[u] = perm[i / LP]; }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -161,7 +195,7 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
     }
     if (tid < 16) tab[n4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding entries' rows
     __syncthreads();
-    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 1] = wall_clock64();
+    if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 1] = wall_clock64();
     // ---- phase 2: tasks, longest first, popped from an LDS counter; the next task's descriptor, destination and
     // first stream block are requested while the current one is walked
     auto pop = [&]() {
@@ -253,7 +287,7 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
         t = tn; tk = tkn; st = stn; my_dst = dstn; c0 = n0; c1 = n1;
     }
     __syncthreads();
-    if (e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 2] = wall_clock64();
     // ---- phase 3: per output row, chunk partials in CSR order, dinv of the row, fused epilogue
     for (int i = tid; i < n_rows * LP; i += kLdsThreads) {
         const int j = i % LP;
@@ -286,8 +320,17 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e.zero1) *reinterpret_cast<float4 *>(e.zero1 + o.so) = z;
         if (e.zero2) *reinterpret_cast<float4 *>(e.zero2 + o.so) = z;
-        if (e.y) *reinterpret_cast<float4 *>(e.y + (e.y_rm ? o.ro : o.so)) = v;
-        if (e.sum_out) *reinterpret_cast<float4 *>(e.sum_out + (e.sum_rm ? o.ro : o.so)) = f4_scale(f4_plus(o.sumv, v), e.sum_scale);
+        if (HAND && e.publish) {
+            // (one descriptor per destination; a null pointer gives zero records: the store is dropped)
+            if (e.y) { if (e.y_rm) *reinterpret_cast<float4 *>(e.y + o.ro) = v; else st16_sc1(lds_rsrc(e.y, nd), o.so, v); }
+            if (e.sum_out) {
+                const float4 sv = f4_scale(f4_plus(o.sumv, v), e.sum_scale);
+                if (e.sum_rm) *reinterpret_cast<float4 *>(e.sum_out + o.ro) = sv; else st16_sc1(lds_rsrc(e.sum_out, nd), o.so, sv);
+            }
+        } else {
+            if (e.y) *reinterpret_cast<float4 *>(e.y + (e.y_rm ? o.ro : o.so)) = v;
+            if (e.sum_out) *reinterpret_cast<float4 *>(e.sum_out + (e.sum_rm ? o.ro : o.so)) = f4_scale(f4_plus(o.sumv, v), e.sum_scale);
+        }
         if (e.adam) {
             const float step_size = e.coef[0], bc2s = e.coef[1];
             const float w1 = (float)(1.0 - (double)e.b1), w2 = (float)(1.0 - (double)e.b2);
@@ -302,7 +345,7 @@ __device__ __forceinline__ void lds_body(const LdsArgs &a, const int *__restrict
             if (e.shadow) *reinterpret_cast<float4 *>(e.shadow + o.so) = pw;
         }
     }
-    if (e.stamps) {
+    if (!HAND && e.stamps) {
         __syncthreads();
         if (tid == 0) e.stamps[blockIdx.x * 4 + 3] = wall_clock64();
     }
@@ -320,8 +363,98 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_kernel(const LdsArgs a)
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
     const int4 wg = reinterpret_cast<const int4 *>(plan + plan[LP_WG_OFS])[blockIdx.x];  // {half, slice, row block, 0}
-    if (wg.x == 0) lds_body<LPA>(a, plan, 0, wg.y, wg.z, lds_dyn);
-    else lds_body<LPB>(a, plan, 1, wg.y, wg.z, lds_dyn);
+    if (wg.x == 0) lds_body<LPA>(a.x, a.e, plan, 0, wg.y, wg.z, lds_dyn);
+    else lds_body<LPB>(a.x, a.e, plan, 1, wg.y, wg.z, lds_dyn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Multi-phase launch: the L propagation layers of a forward (or backward) pass in ONE launch.
+//
+// Y[:, s] = A . X[:, s] holds per column slice for every layer, so a workgroup (half, s, block) of layer l+1 depends only on
+// the workgroups of the same column GROUP (the 2 x n_blk workgroups that produce and consume columns [g G, (g+1) G), G = the
+// wider of the two halves' slice widths) of layer l -- not on the grid.  Work items = (phase, half, slice, block); the plan
+// deals the groups to up to 8 QUEUES (a group never straddles queues) and lists every queue's items; a queue's items are
+// handed out in phase-major order by one agent-scope ticket counter, and an item of phase p starts when its group's arrival
+// counter shows that all members finished phase p-1 (that one wait also covers every buffer that is re-used two phases
+// later: within a group all hazards are between consecutive phases).
+// Deadlock-free WITHOUT assuming that the whole grid is resident: an item only ever waits for items with smaller tickets of
+// its own queue, and those have been taken by workgroups that are running.  Placement-independent: the hand-off is
+// "payload sc1 + agent-scope counter" (see ld16_sc1 above); workgroup b pulls from queue (b % 8) % n_queues, which keeps a
+// group on one XCD under round-robin dispatch -- speed only (the re-staged slice tables are then same-XCD traffic).
+// sync words (int32, caller-owned, one launch at a time, zero before the first launch; the last workgroup to leave zeroes
+// them again, and every train / propagate call's prologue does too):
+enum { LS_HEAD = 0 /* 8 queue heads, one per 128-byte line */, LS_ARRIVE = 8 * 32 /* per group, one line each */,
+       LS_MAX_GROUPS = 64, LS_DONE = LS_ARRIVE + LS_MAX_GROUPS * 32, LS_ERR = LS_DONE + 32, LS_WORDS = LS_ERR + 32 };
+// plan words at LP_MQ_OFS: {n_queues, n_groups, G, 0}, then n_queues x {n_items, first int4 of its list (in int4 units from
+// the plan's start)}, then n_groups x members; the lists hold int4 {half, slice, block, group}
+static constexpr int kLdsMaxPhases = 4;
+static constexpr unsigned kLdsSpinLimit = 1u << 26;   // polls before a waiter gives up (sets LS_ERR; ~ seconds)
+
+struct LdsPhase {
+    const float *x;
+    LdsEpi e;
+};
+struct LdsMultiArgs {
+    const int *plan;
+    int *sync;
+    int n_phases, bc_ofs;   // bc_ofs: byte offset of a 16-byte broadcast slot behind the body's LDS layout
+    LdsPhase ph[kLdsMaxPhases];
+};
+
+template <int LPA, int LPB>
+__global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMultiArgs a)
+{
+    extern __shared__ float4 lds_dyn[];
+    const int *__restrict__ plan = a.plan;
+    const int tid = threadIdx.x;
+    const LdsEpi &el = a.ph[a.n_phases - 1].e;
+    if (el.bump && blockIdx.x == 0 && tid == 0) {
+        el.state[ST_STEP_BASE] += el.bump;
+        el.state[ST_ADAM_T] += el.bump;
+    }
+    const int *mq = plan + plan[LP_MQ_OFS];
+    const int n_queues = mq[0], n_groups = mq[1];
+    const int q = (int)(blockIdx.x & 7) % n_queues;
+    const int n_items = mq[4 + 2 * q];
+    const int4 *list = reinterpret_cast<const int4 *>(plan) + mq[4 + 2 * q + 1];
+    const int *members = mq + 4 + 2 * n_queues;
+    volatile int *bc = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_dyn) + a.bc_ofs);
+    int *head = a.sync + LS_HEAD + q * 32;
+    const int total = n_items * a.n_phases;
+    for (;;) {
+        if (tid == 0) bc[0] = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(bc[0]);   // uniform: the phase's arguments below are scalar loads
+        if (t >= total) break;
+        const int phase = t / n_items;
+        const int4 wg = list[t - phase * n_items];   // {half, slice, block, group}
+        int *arrive = a.sync + LS_ARRIVE + wg.w * 32;
+        if (phase > 0 && tid == 0) {
+            // every member of the group has finished the previous phase (its stores drained before its add)
+            const int need = members[wg.w] * phase;
+            unsigned spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kLdsSpinLimit) { __hip_atomic_store(a.sync + LS_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+        }
+        __syncthreads();   // after the poll, before EVERY load of handed-off bytes; also: bc has been read by everybody
+        const LdsPhase &ph = a.ph[phase];   // (kernel-argument memory: uniform loads at a uniform offset, no copy)
+        if (wg.x == 0) lds_body<LPA, true>(ph.x, ph.e, plan, 0, wg.y, wg.z, lds_dyn);
+        else lds_body<LPB, true>(ph.x, ph.e, plan, 1, wg.y, wg.z, lds_dyn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
+        __syncthreads();                                    // ... before the ONE lane that signals for all of them
+        if (tid == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // leave the sync words zero for the next launch: the last workgroup out (nobody reads or adds after its own done-add)
+    if (tid == 0) bc[1] = __hip_atomic_fetch_add(a.sync + LS_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(bc[1]) == (int)gridDim.x - 1) {
+        if (tid < 8) __hip_atomic_store(a.sync + LS_HEAD + tid * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < n_groups) __hip_atomic_store(a.sync + LS_ARRIVE + tid * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(a.sync + LS_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // row-major [N, d] <-> sliced; one float4 per thread
@@ -330,11 +463,14 @@ struct LdsPackJob {
     int n;
     float *zero[2];         // nullable: [N, d] buffers cleared by the same launch (a train call's scatter targets)
     int *zero_i;            // nullable: int32[N] cleared too (incidence counts)
+    int *zero_sync;         // nullable: the multi-phase launch's LS_WORDS sync words (a call starts from clean counters whatever came before)
 };
 static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
 {
     const int d4 = g.d / 4;
     const long long n = (long long)(g.U + g.I) * d4;
+    if (job.zero_sync && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < LS_WORDS; i += blockDim.x) job.zero_sync[i] = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / d4), k = (int)(i % d4) * 4;
         const size_t so = sl_off(g, r, k), ro = (size_t)r * g.d + k;
@@ -384,5 +520,40 @@ inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStre
     else if (info.lpa == 2 && info.lpb == 4) RK_LDS_CASE(2, 4);
     else return hipErrorInvalidValue;
 #undef RK_LDS_CASE
+    return hipGetLastError();
+}
+
+// n_phases <= kLdsMaxPhases phases in one launch; `a.ph[*]`, `a.plan`, `a.sync`, `a.n_phases` filled by the caller
+inline hipError_t spmm_lds_multi_launch(const LdsInfo &info, LdsMultiArgs &a, hipStream_t s)
+{
+    const dim3 grid(info.n_wg), block(kLdsThreads);
+    a.bc_ofs = (info.lds_bytes + 15) & ~15;
+    const size_t lds = (size_t)a.bc_ofs + 16;
+    if (lds > (size_t)(kLdsMaxBytes - 64)) return hipErrorInvalidValue;
+#define RK_LDS_MCASE(A, B)                                                                                                 \
+    do {                                                                                                                    \
+        static RkPerDeviceOnce attr_once;                                                                                   \
+        int attr_dev_;                                                                                                      \
+        if (attr_once.need(&attr_dev_)) {                                                                                   \
+            hipFuncAttributes fa_;                                                                                          \
+            hipError_t e_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void *>(&spmm_lds_multi_kernel<A, B>));      \
+            if (e_ != hipSuccess) return e_;                                                                                \
+            if (fa_.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;   /* table at LDS address 0 */               \
+            e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_lds_multi_kernel<A, B>),                          \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes - 64);                        \
+            if (e_ != hipSuccess) return e_;                                                                                \
+            attr_once.done(attr_dev_);                                                                                      \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((spmm_lds_multi_kernel<A, B>), grid, block, lds, s, a);                                           \
+    } while (0)
+    if (info.lpa == 2 && info.lpb == 1) RK_LDS_MCASE(2, 1);
+    else if (info.lpa == 1 && info.lpb == 2) RK_LDS_MCASE(1, 2);
+    else if (info.lpa == 1 && info.lpb == 1) RK_LDS_MCASE(1, 1);
+    else if (info.lpa == 2 && info.lpb == 2) RK_LDS_MCASE(2, 2);
+    else if (info.lpa == 4 && info.lpb == 4) RK_LDS_MCASE(4, 4);
+    else if (info.lpa == 4 && info.lpb == 2) RK_LDS_MCASE(4, 2);
+    else if (info.lpa == 2 && info.lpb == 4) RK_LDS_MCASE(2, 4);
+    else return hipErrorInvalidValue;
+#undef RK_LDS_MCASE
     return hipGetLastError();
 }

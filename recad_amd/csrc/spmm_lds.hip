@@ -259,6 +259,36 @@ RK_EXPORT int rk_lds_plan_build_host(int32_t n_users, int32_t n_items, const int
             ++taken[x];
         }
     }
+    // ---- work-item queues of the multi-phase launch (spmm_lds.h, spmm_lds_multi_kernel): column groups of G floats (the
+    // wider slice width) are dealt to min(8, n_groups) queues, a group never straddles queues; inside a queue the items are
+    // interleaved by row block so that both halves of every group advance together.
+    {
+        const int G = std::max(hp[0].S, hp[1].S), n_groups = dim / G, n_queues = std::min(8, n_groups);
+        while (w.size() & 3) w.push_back(0);
+        w[LP_MQ_OFS] = (int32_t)w.size();
+        const size_t hdr = w.size();
+        w.resize(hdr + 4 + 2 * (size_t)n_queues + (size_t)n_groups, 0);
+        w[hdr] = n_queues; w[hdr + 1] = n_groups; w[hdr + 2] = G;
+        for (int g = 0; g < n_groups; ++g)
+            w[hdr + 4 + 2 * (size_t)n_queues + (size_t)g] = (G / hp[0].S) * hp[0].n_blk + (G / hp[1].S) * hp[1].n_blk;
+        for (int q = 0; q < n_queues; ++q) {
+            while (w.size() & 3) w.push_back(0);
+            const size_t first = w.size();
+            int n_items = 0;
+            const int rounds = std::max(hp[0].n_blk, hp[1].n_blk);
+            for (int k = 0; k < rounds; ++k)
+                for (int g = q; g < n_groups; g += n_queues)
+                    for (int h = 0; h < 2; ++h) {
+                        if (k >= hp[h].n_blk) continue;
+                        for (int sl = g * G / hp[h].S; sl < (g + 1) * G / hp[h].S; ++sl) {
+                            w.insert(w.end(), {h, sl, k, g});
+                            ++n_items;
+                        }
+                    }
+            w[hdr + 4 + 2 * (size_t)q] = n_items;
+            w[hdr + 4 + 2 * (size_t)q + 1] = (int32_t)(first / 4);
+        }
+    }
     // ---- LDS row of every source row.  Identity, except that the kHot highest-degree sources are dealt round-robin over
     // the 16 / LP bank classes (each swaps rows with a cold source that sits in the wanted class): an item that half the
     // users rated would otherwise load its class in every lane group.  Cold rows keep their natural order, so the staging

@@ -66,6 +66,9 @@ class LightGCN(BaseVictim):
         # when it is the faster kernel -- staging the slice tables costs ~2 us per launch whatever the graph holds, so sparse
         # graphs (the reference's as-is test-edge graphs: 10 nonzeros per row, 7.3 vs 6.6 us per launch) stay on the row gather
         self.use_lds = "auto"
+        # LDS path: the L layers of a forward / backward pass as ONE launch whose workgroups hand the layers over to each other
+        # per column group (csrc/spmm_lds.h, spmm_lds_multi_kernel) instead of L launches; False = one launch per layer
+        self.fuse_layers = True
         # ordered (bit-reproducible) gradient scatter instead of float atomics: one more launch per step and a sort of
         # the epoch's triplets (rk_lightgcn_set_deterministic); not a reference option (its CUDA path is atomic too)
         self.deterministic = bool(config.get("deterministic", False))
@@ -130,7 +133,7 @@ class LightGCN(BaseVictim):
         key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
-               bool(self.deterministic), str(self.use_lds))
+               bool(self.deterministic), str(self.use_lds), bool(self.fuse_layers))
         if self._handle is not None and self._handle_key == key:
             return self._handle
         self._drop_handle()
@@ -156,6 +159,8 @@ class LightGCN(BaseVictim):
         ws["spmm_scratch"] = None if lds else g.new_scratch(d)  # this handle's own long-row counters / partial slots
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
+        fuse = bool(lds) and bool(self.fuse_layers) and self.n_layers >= 2 and not os.environ.get("RK_LDS_NO_FUSE")
+        ws["lds_sync"] = torch.zeros(_lib.RK_LDS_SYNC_WORDS, device=dev, dtype=torch.int32) if fuse else None   # this handle's own hand-off counters
         for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
             ws[k] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         desc = _lib.LightGCNDesc(
@@ -175,13 +180,23 @@ class LightGCN(BaseVictim):
             keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
             drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]),
             lds_plan=_lib.ptr(lds[0]) if lds else None, lds_info=lds[1] if lds else _lib.LdsInfo(),
-            lsum=_lib.ptr(ws["lsum"]), e0s=_lib.ptr(ws["e0s"]), ms=_lib.ptr(ws["ms"]), vs=_lib.ptr(ws["vs"]), cnt=_lib.ptr(ws["cnt"]))
+            lsum=_lib.ptr(ws["lsum"]), e0s=_lib.ptr(ws["e0s"]), ms=_lib.ptr(ws["ms"]), vs=_lib.ptr(ws["vs"]), cnt=_lib.ptr(ws["cnt"]),
+            lds_sync=_lib.ptr(ws["lds_sync"]))
         h = C.c_void_p()
         _lib.check(_lib.lib().rk_lightgcn_create(C.byref(desc), C.byref(h)), "rk_lightgcn_create")
         if self.deterministic:
             _lib.check(_lib.lib().rk_lightgcn_set_deterministic(h, 1), "rk_lightgcn_set_deterministic")
         self._handle, self._handle_key, self._ws = h, key, ws
         return h
+
+    def check_handoffs(self):
+        """Raise if an in-launch hand-off of the fused multi-layer propagation ever gave up waiting (rk_lightgcn_sync_status);
+        synchronises the stream, so it is called where the host waits anyway (after an epoch's loss read-back)."""
+        if self._handle is not None and self._ws is not None and self._ws.get("lds_sync") is not None:
+            st = C.c_int32(0)
+            _lib.check(_lib.lib().rk_lightgcn_sync_status(self._handle, C.byref(st), _lib.stream_ptr()), "rk_lightgcn_sync_status")
+            if st.value:
+                raise _lib.HipCallError("LightGCN: a hand-off wait of the multi-layer propagation launch timed out (results invalid)")
 
     def _drop_handle(self):
         if getattr(self, "_handle", None) is not None:
@@ -289,6 +304,7 @@ class LightGCN(BaseVictim):
         if self._fused_adam:
             partials = self._run_epoch(users, pos, neg, batch)
             step_losses = partials.sum(dim=1).double().cpu()  # ONE device->host sync per epoch
+            self.check_handoffs()
         else:
             step_losses = self._unfused_epoch((users, pos, neg), batch, self._grad_step)
         mean_loss = float(step_losses.sum().item() / len(step_losses))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/recad_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().rk_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().rk_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():

@@ -10,7 +10,7 @@ import pytest
 from recad_amd import _lib, synth
 
 H = dict(MAGIC=0, NWG=1, U=2, I=3, D=4, LSU=5, LSI=6, NBLK0=7, NBLK1=8, WG_OFS=9, BLK_OFS=10, DINV_OFS=11, LDS_BYTES=12,
-         CHUNK=13, NWORDS=14, PERM0=15, PERM1=16)
+         CHUNK=13, NWORDS=14, PERM0=15, PERM1=16, MQ_OFS=17)
 LB = dict(ROW0=0, NROWS=1, NPART=2, NTASKS=3, TASK_OFS=4, DST_OFS=5, PP_OFS=6, STREAM_OFS=7, WORDS=8)
 
 
@@ -172,3 +172,72 @@ def test_plan_refuses_graphs_that_do_not_qualify():
     idx = (np.arange(Ub) % Ib).astype(np.int32)
     rp, cc, vv = norm_adj_csr(Ub, Ib, ptr, idx)
     assert build_plan(Ub, Ib, rp, cc, vv, 64)[0] is None
+
+
+def _multi_queues(words):
+    """The multi-phase launch's work-item queues (plan words at LP_MQ_OFS, csrc/spmm_lds.h)."""
+    o = int(words[H["MQ_OFS"]])
+    n_queues, n_groups, G = (int(v) for v in words[o: o + 3])
+    queues = []
+    for q in range(n_queues):
+        n_items, first = int(words[o + 4 + 2 * q]), int(words[o + 4 + 2 * q + 1])
+        queues.append(words[first * 4: first * 4 + 4 * n_items].reshape(-1, 4))
+    members = words[o + 4 + 2 * n_queues: o + 4 + 2 * n_queues + n_groups]
+    return n_queues, n_groups, G, queues, members
+
+
+@pytest.mark.parametrize("shape,dim,n_cu", [("tiny", 64, 64), ("tiny", 32, 64), ("tiny", 16, 64), ("tiny", 128, 256), ("tiny", 256, 256), ("ml1m", 64, 256)])
+def test_multi_phase_queues_cover_the_launch_and_cannot_deadlock(shape, dim, n_cu):
+    """spmm_lds_multi_kernel's contract with the plan: the queue lists hold every (half, slice, block) workgroup of the
+    single-phase table exactly once; a column group (the workgroups that exchange data between consecutive layers) never
+    straddles queues and its member count is what the arrival counter waits for; and -- simulated with FEWER resident
+    workgroups than the grid, in adversarial order -- handing a queue's items out in phase-major ticket order never leaves a
+    running workgroup waiting for an item nobody has taken."""
+    data = synth.make(shape)
+    U, I = data["n_users"], data["n_items"]
+    rowptr, col, val = norm_adj_csr(U, I, *data["train"])
+    words, info = build_plan(U, I, rowptr, col, val, dim, n_cu=n_cu)
+    assert words is not None
+    n_queues, n_groups, G, queues, members = _multi_queues(words)
+    S = {0: 1 << int(words[H["LSI"]]), 1: 1 << int(words[H["LSU"]])}
+    assert G == max(S.values()) and n_groups == dim // G and 1 <= n_queues <= 8 and n_groups <= 64
+    wg = words[int(words[H["WG_OFS"]]): int(words[H["WG_OFS"]]) + 4 * int(words[H["NWG"]])].reshape(-1, 4)
+    single = sorted((int(h), int(s_), int(rb)) for h, s_, rb, _ in wg)
+    multi = sorted((int(h), int(s_), int(rb)) for qv in queues for h, s_, rb, _ in qv)
+    assert single == multi
+    count = np.zeros(n_groups, dtype=np.int64)
+    for q, qv in enumerate(queues):
+        for h, s_, rb, g in qv:
+            assert int(g) == int(s_) * S[int(h)] // G and int(g) % n_queues == q      # the group of a slice; its home queue
+            count[int(g)] += 1
+    assert np.array_equal(count, members)
+    # ticket-order simulation: R < grid workgroups, each pulls from queue (b % 8) % n_queues; an item of phase p needs all
+    # members of its group to have FINISHED phase p - 1.  A workgroup that cannot start spins (keeps its slot).
+    n_phases, rng = 3, np.random.default_rng(dim)
+    for resident in (1, 3, max(2, int(words[H["NWG"]]) // 5)):
+        head = [0] * n_queues
+        arrived = np.zeros(n_groups, dtype=np.int64)
+        blocks = list(range(int(words[H["NWG"]])))
+        running = {}                                       # block -> (queue, ticket) it holds
+        waiting_blocks = blocks[::-1]
+        done_items = 0
+        total = sum(len(qv) for qv in queues) * n_phases
+        for _ in range(50 * total + 100):
+            while len(running) < resident and waiting_blocks:      # admit blocks in an arbitrary (reversed) order
+                b = waiting_blocks.pop()
+                q = (b % 8) % n_queues
+                running[b] = (q, head[q]); head[q] += 1
+            if not running:
+                break
+            b = list(running)[int(rng.integers(len(running)))]   # an arbitrary running block makes progress
+            q, t = running[b]
+            if t >= len(queues[q]) * n_phases:
+                del running[b]                                   # queue exhausted: the block exits
+                continue
+            phase, (h, s_, rb, g) = t // len(queues[q]), queues[q][t % len(queues[q])]
+            if phase > 0 and arrived[int(g)] < members[int(g)] * phase:
+                continue                                         # spins
+            arrived[int(g)] += 1
+            done_items += 1
+            running[b] = (q, head[q]); head[q] += 1
+        assert done_items == total and not running, (resident, done_items, total)
