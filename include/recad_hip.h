@@ -65,6 +65,11 @@ int rk_coo_to_csr(int32_t n_rows, int64_t nnz, const int64_t *coo_row, const int
 typedef struct rk_schedule *rk_schedule_t;
 int rk_csr_schedule_build(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim, void *stream,
                           rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words);
+/* the same from a HOST rowptr, no HIP call (ABI 8): what the CPU tests and the sanitizer builds drive; _words copies the
+ * n_words schedule words (what _upload sends to the device) into a host array */
+int rk_csr_schedule_build_host(int32_t n_rows, const int32_t *rowptr_host, int32_t class_split, int32_t dim,
+                               rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words);
+int rk_csr_schedule_words(rk_schedule_t sched, int32_t *host_out /*[n_words]*/);
 int rk_csr_schedule_upload(rk_schedule_t sched, int32_t *wave_desc, void *stream);
 int rk_csr_schedule_destroy(rk_schedule_t sched);
 

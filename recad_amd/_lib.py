@@ -108,6 +108,8 @@ _SIGNATURES = {
     "rk_device_info": [C.c_char_p, _I32, C.POINTER(_I32)],
     "rk_coo_to_csr": [_I32, _I64, _P, _P, _P, _P, _P, _P, _P],
     "rk_csr_schedule_build": [_I32, _P, _I32, _I32, _P, C.POINTER(_P), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)],
+    "rk_csr_schedule_build_host": [_I32, _P, _I32, _I32, C.POINTER(_P), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)],
+    "rk_csr_schedule_words": [_P, _P],
     "rk_csr_schedule_upload": [_P, _P, _P],
     "rk_csr_schedule_destroy": [_P],
     "rk_build_norm_adj": [_I32, _I32, _P, _P, _P, _P, _P, _P, _P],

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "host/layout.h"
 
 struct SpmmEpi {
     // v = acc (+ add[r])
@@ -112,28 +113,6 @@ __device__ __forceinline__ float drop_val(const DropCtx &c, int e, float v)
     const unsigned id = (unsigned)(c.tpos ? c.tpos[e] : e);
     return rk_drop_keep(c.seed_step, id, c.thresh24) ? v * c.inv_keep : 0.f;
 }
-
-static constexpr int kSpmmWavesMax = 16;
-// Waves per workgroup: chosen when the schedule is built and carried in the opaque `n_blocks` launch
-// parameter.  4-wave workgroups (7 per CU instead of 3 of 8 waves: finer-grained tail, more workgroups
-// resident) measured +4 % per train step on ml1m (0.94 M nonzeros) and +3 % on the yelp shape (3.3 M),
-// -2 % at 50 M nonzeros, where the longer rows split into more cross-workgroup pieces.
-// RK_SPMM_WAVES overrides for tuning.
-inline int spmm_waves_for(long long nnz)
-{
-    static const int w = getenv("RK_SPMM_WAVES") ? atoi(getenv("RK_SPMM_WAVES")) : 0;
-    if (w == 4 || w == 8 || w == 16) return w;
-    return nnz <= 8000000LL ? 4 : 8;
-}
-
-// bit 30 of the opaque `n_blocks` launch parameter: the schedule contains packed short-row waves;
-// bits 28-29: waves per workgroup (0 = 8, 1 = 4, 2 = 16); bit 27: long rows present
-static constexpr int kSchedPackedFlag = 1 << 30;
-static constexpr int kSchedLongFlag = 1 << 27;  // the schedule has long rows: SpmmArgs::scratch is required
-static constexpr int kSchedWavesShift = 28, kSchedWavesMask = 3 << 28;
-inline int sched_waves_code(int waves) { return (waves == 4 ? 1 : waves == 16 ? 2 : 0) << kSchedWavesShift; }
-inline int sched_waves(int n_blocks_param) { const int c = (n_blocks_param & kSchedWavesMask) >> kSchedWavesShift; return c == 1 ? 4 : c == 2 ? 16 : 8; }
-static constexpr int kSegNnz = 64;  // default nonzeros per schedule segment (RK_SEG_NNZ overrides, tuning only)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc)
 {

@@ -19,6 +19,7 @@
 // contiguous run.  E0 / m / v / light stay row-major (they are the caller's tensors).
 #pragma once
 #include "common.h"
+#include "host/layout.h"
 
 struct LdsDims {
     int U, I, d;
@@ -30,17 +31,6 @@ __host__ __device__ __forceinline__ size_t sl_off(const LdsDims &g, int r, int k
     if (r < g.U) return ((((size_t)(k >> g.lsu)) * (size_t)g.U + (size_t)r) << g.lsu) + (size_t)(k & ((1 << g.lsu) - 1));
     return (size_t)g.U * (size_t)g.d + ((((size_t)(k >> g.lsi)) * (size_t)g.I + (size_t)(r - g.U)) << g.lsi) + (size_t)(k & ((1 << g.lsi) - 1));
 }
-
-// plan buffer (device int32 words), header words
-enum {
-    LP_MAGIC = 0, LP_NWG, LP_U, LP_I, LP_D, LP_LSU, LP_LSI, LP_NBLK0, LP_NBLK1, LP_WG_OFS, LP_BLK_OFS, LP_DINV_OFS,
-    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_MQ_OFS, LP_HDR_WORDS = 32
-};
-static constexpr int kLdsMagic = 0x4c445331;  // "LDS1"
-// block descriptor words (one per (half, row block), shared by all slices)
-enum { LB_ROW0 = 0, LB_NROWS, LB_NPART, LB_NTASKS, LB_TASK_OFS, LB_DST_OFS, LB_PP_OFS, LB_STREAM_OFS, LB_WORDS = 8 };
-static constexpr int kLdsThreads = 1024;
-static constexpr int kLdsMaxBytes = 160 * 1024;
 
 struct LdsEpi {
     // v = dinv[r] * acc (+ add[r])          add: sliced
