@@ -18,7 +18,7 @@ struct rk_lds_plan {
     rk_lds_info info;
 };
 
-namespace {
+namespace rk_plan_detail {
 
 struct Chunk {
     int32_t padded, len, e_begin, pidx;
@@ -184,7 +184,8 @@ static bool choose_half(const int32_t *rp, int row_lo, int row_hi, int n_src, in
     return false;
 }
 
-}  // namespace
+}  // namespace rk_plan_detail
+using namespace rk_plan_detail;
 
 // Host-only builder (no HIP call): every array is host memory.  *n_words == 0 on return: the graph does not qualify
 // (not bipartite / not the normalised binary adjacency / a class table does not fit a CU's LDS) -- use spmm.h's kernel.
