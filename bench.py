@@ -72,6 +72,8 @@ def parse(argv=None):
                     help="labelled extra mode (SURVEY 8d config 3): time train(clean) + inject 50 fake users + train(poisoned) + 2 x "
                          "evaluation through workflow.execute(), with the graph / schedule rebuild of the retrain loop itemised")
     ap.add_argument("--rec-epoch", type=int, default=2, help="--workflow: training epochs per (re)train")
+    ap.add_argument("--no-also", action="store_true", help="N = 1 default run: skip the short yelp-shaped measurement (`also`)")
+    ap.add_argument("--also-config4", action="store_true", help="N = 1: add the config-4-shaped measurement (1M x 500K x 100M edges) to `also` (~60 s)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
     a = ap.parse_args(argv)
@@ -237,6 +239,85 @@ def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
             "eval_users_per_s": r["eval_users_per_s"],
             "eval_sample": f"{r['eval_users']} users through the reference's per-user loop (computer() = {layers} sparse mm per user, "
                            f"pair scores of the unseen items, sort, top-100), same {r['threads']} threads, {r['eval_seconds']:.1f} s"}
+
+
+def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0):
+    """A short measurement of ANOTHER BASELINE.json config next to the headline one, so that the driver's record carries it:
+    ms/step through the same reserve() -> epoch-call path, the SpMM's per-launch time and roofline (with the no-reuse gather
+    figure as `effective`), and one full evaluation.  Config 3 = yelp-shaped d = 128; config 4 = 1M x 500K x 100M edges d = 64."""
+    import torch
+    from recad_amd import _lib, dataset, model, synth
+    from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
+
+    t_all = time.perf_counter()
+    big = workload in ("c4s", "config4")
+    if big:
+        dd = synth.make_device(workload, dev)
+        d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+        del dd
+    else:
+        d = synth.make(workload)
+    ds = dataset.from_config("implicit", workload, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], need_graph=True,
+                             device=dev, graph_source="train", pairwise_batch_size=B, seed=1234)
+    torch.manual_seed(2023)
+    v = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=layers).I(dataset=ds).to(dev)
+    g = ds.graph_csr()
+    N, nnz = g.n_rows, g.nnz
+    ep = ds.generate_epoch()
+    trip = tuple(ep[k][: (steps + warmup) * B].contiguous() for k in ("users", "positive_items", "negative_items"))
+    v.reserve(max(steps, warmup) * B, B)
+    run_steps(v, trip, B, 0, warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    part = run_steps(v, trip, B, warmup, steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert np.isfinite(float(part[-1].sum().item()))
+    h = v._ensure_handle()
+    reps = 30 if nnz < 20_000_000 else 4
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+    e0.record()
+    for _ in range(reps):
+        _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+    e1.record()
+    torch.cuda.synchronize()
+    lds = v._ws.get("lds") is not None
+    spmm_ms = e0.elapsed_time(e1) / (reps * layers)
+    alg = 8 * nnz + 4 * (N + 1) + 8 * N * dim
+    gather = 8 * nnz + 4 * nnz * dim + 4 * N * dim
+    ptr, idx = ds.train_csr_sorted()
+    users = eligible_users(ptr, idx, np.array([0], dtype=np.int32))
+    if eval_users:
+        users = users[:eval_users]
+    ud = torch.as_tensor(users, dtype=torch.int32, device=dev)
+    pd_, id_ = torch.as_tensor(ptr, dtype=torch.int32, device=dev), torch.as_tensor(idx, dtype=torch.int32, device=dev)
+    tg = torch.as_tensor(np.array([0], dtype=np.int32), device=dev)
+    chunk = max(256, min(8192, (1 << 31) // max(ds.n_items, 1)))
+    full_catalog_topk(v, ud, pd_, id_, tg, K=100, chunk=chunk, to_host=False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    res = full_catalog_topk(v, ud, pd_, id_, tg, K=100, chunk=chunk, to_host=False)
+    hits = hit_counts(res["target_rank"], (10, 20, 50, 100))
+    torch.cuda.synchronize()
+    ev = time.perf_counter() - t1
+    return {"workload": f"LightGCN victim, {workload}-shaped synthetic {ds.n_users}x{ds.n_items}, {ds.traindataSize} train edges (nnz {nnz}), "
+                        f"dim={dim}, layers={layers}, batch={B}",
+            "value": steps * B / el, "unit": "interactions/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+            "roofline": {"bound": "hbm", "kernel": "spmm_lds_kernel" if lds else f"spmm_csr_kernel<{dim}>", "avg_launch_us": spmm_ms * 1e3,
+                         "bytes_per_launch": alg, "achieved": alg / spmm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / spmm_ms / 1e6 / HBM_PEAK_GBS,
+                         "gather_bytes_per_launch": gather, "effective_gbs": gather / spmm_ms / 1e6,
+                         "effective_frac": gather / spmm_ms / 1e6 / HBM_PEAK_GBS,
+                         "note": "per-launch time = propagate (L launches, HIP events) / L.  `frac` prices SURVEY 8d's COMPULSORY bytes "
+                                 "(A, X, Y once); `effective_frac` the no-reuse gather figure (one X row per nonzero): on i.i.d. synthetic "
+                                 "graphs there is no row reuse to harvest beyond the caches, so the kernel moves the gather bytes at about "
+                                 "the fabric rate while `frac` stays low (DESIGN 4.1)"},
+            "topk": {"eligible_users": int(len(users)), "seconds": ev, "value": len(users) / ev, "unit": "users/s",
+                     "hr@50": float(hits[0, 2].item()) / max(len(users), 1),
+                     "gemm_tflops_e2e": 2.0 * len(users) * ds.n_items * dim / ev / 1e12},
+            "seconds_total": time.perf_counter() - t_all}
 
 
 # ------------------------------------------------------------------------------------------------ worker
@@ -430,17 +511,18 @@ def worker(args):
         spmm_ms = ev0.elapsed_time(ev1) / (reps * per_call)
         spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_src = None
         tkey = f"{args.workload}_{args.graph}_d{args.dim}" + ("_lds" if lds is not None else "")
         for tname in ("r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath)).get(tkey)
+                    traffic_src = f"profiles/{tname} (rocprofv3 PMC passes on a builder-run box, not measured in this run)" if traffic is not None else None
                 except Exception:
                     traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
                     "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
                     "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
@@ -492,6 +574,11 @@ def worker(args):
     mfma = None
     if rank == 0 and world == 1 and not args.no_topk and not big and not args.force_collectives:
         mfma = mfma_gemm_probe(dev)
+    also = None
+    if rank == 0 and world == 1 and sharded is None and args.workload == "ml1m" and not args.no_also:
+        also = {"config3_yelp": also_measure(dev, "yelp", 128, args.layers, B)}
+        if args.also_config4:
+            also["config4"] = also_measure(dev, "config4", 64, args.layers, B, steps=10, warmup=3, eval_users=65536)
     cpu = cpu_aten = parity = None
     if want_parity:
         # the oracle on the timed run's own triplets from the victim's own initial tables: parity of the timed path AND the
@@ -548,7 +635,7 @@ def worker(args):
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
-            "cpu_baseline_port": cpu, "parity": parity, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
+            "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
         }
         if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
             same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]

@@ -26,6 +26,8 @@ extern thread_local char rk_err_buf[512];
 
 #define RK_CHECK_LAUNCH() RK_HIP(hipGetLastError())
 
+#include "host/layout.h"   // RK_TUNE_INT, plan / schedule layouts (pure C++, shared with the host-only builders)
+
 static constexpr int kWave = 64;
 
 // "Done once per DEVICE" flag for hipFuncSetAttribute (the attribute is applied to the current device's code object; a

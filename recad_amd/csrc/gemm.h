@@ -781,7 +781,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
 {
     static RkPerDeviceOnce attr_once;
-    static const int variant = getenv("RK_GEMM_VARIANT") ? atoi(getenv("RK_GEMM_VARIANT")) : 0;
+    static const int variant = RK_TUNE_INT("RK_GEMM_VARIANT", 0);
     int attr_dev;
     if (attr_once.need(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<128, 2, 2>),
@@ -797,15 +797,15 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         // whole 64 x 128 chunks of aligned operands: the 128-deep chunk loop (even a single chunk gains from the half tiles,
         // the b128 LDS stores and the pipelined operand reads: 1024 x 512 x 256 14.1 -> 8.4 us, 1024 x 256 x 128 9.2 -> 5.8 us)
         const int chunks = (g.K + kGK - 1) / kGK, per = (chunks + splits - 1) / splits;
-        static const int no_deep = getenv("RK_GEMM_NO_DEEP") ? atoi(getenv("RK_GEMM_NO_DEEP")) : 0;   // A/B only
-        static const int deep_min_k = getenv("RK_GEMM_DEEP_MINK") ? atoi(getenv("RK_GEMM_DEEP_MINK")) : 128;   // tuning only
+        static const int no_deep = RK_TUNE_INT("RK_GEMM_NO_DEEP", 0);   // A/B only
+        static const int deep_min_k = RK_TUNE_INT("RK_GEMM_DEEP_MINK", 128);   // tuning only
         const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
         // (A row-contiguous with B k-contiguous has no caller: forward / dX / dW are <1,1>, <1,2>, <2,2>)
         const bool deep = !no_deep && variant != 4 && fa && fb && !(fa == 2 && fb == 1) && g.M % 64 == 0 && g.N % 64 == 0 && g.K % kDK == 0 && per % 4 == 0 &&
                           per * kGK >= deep_min_k;
         if (variant == 4) hipLaunchKernelGGL((gemm_f32_kernel<64, 1, 4>), dim3(nwg, splits), dim3(256), gemm_lds_bytes<64>(1), s, g2, 1);
         else if (deep) {
-            static const int no_half = getenv("RK_GEMM_NO_HALF") ? atoi(getenv("RK_GEMM_NO_HALF")) : 0;   // A/B only
+            static const int no_half = RK_TUNE_INT("RK_GEMM_NO_HALF", 0);   // A/B only
             const bool half = nwg * splits < 256 && !no_half;   // fewer workgroups than CUs: 32-row tiles
             const void *fn[6] = {reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 1, 64>), reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<1, 2, 64>),
                                  reinterpret_cast<const void *>(gemm_f32_skinny_deep_kernel<2, 2, 64>),
@@ -835,10 +835,10 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         // many 128-tiles, aligned operands, A k-contiguous (scoring, tower forward, dX), K a multiple of 64: the wide kernel.
         // A k-contiguous B takes a partial last tile (clamped row loads); a row-contiguous B (dX) needs whole column tiles
         // and leaves the edge strip to this function again (fewer than 128 columns: it never comes back here).
-        static const int no_wide = getenv("RK_GEMM_NO_WIDE") ? atoi(getenv("RK_GEMM_NO_WIDE")) : 0;   // A/B only
-        static const int wide_min_k = getenv("RK_GEMM_WIDE_MINK") ? atoi(getenv("RK_GEMM_WIDE_MINK")) : kWK;   // tuning only
-        static const int strips = getenv("RK_GEMM_WIDE_STRIPS") ? atoi(getenv("RK_GEMM_WIDE_STRIPS")) : 0;   // A/B only
-        static const int wide_wgs = getenv("RK_GEMM_WIDE_WGS") ? atoi(getenv("RK_GEMM_WIDE_WGS")) : 512;   // tuning only: 2 per CU
+        static const int no_wide = RK_TUNE_INT("RK_GEMM_NO_WIDE", 0);   // A/B only
+        static const int wide_min_k = RK_TUNE_INT("RK_GEMM_WIDE_MINK", kWK);   // tuning only
+        static const int strips = RK_TUNE_INT("RK_GEMM_WIDE_STRIPS", 0);   // A/B only
+        static const int wide_wgs = RK_TUNE_INT("RK_GEMM_WIDE_WGS", 512);   // tuning only: 2 per CU
         const int fa = deep_form(g.A, g.a_rs, g.a_cs), fb = deep_form(g.B, g.b_rs, g.b_cs);
         const int Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
         if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
@@ -872,7 +872,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
     }
     // short-K problems are epilogue-bound: run several tiles per workgroup so stores drain under MFMAs
     int tpb = (g.K <= 64) ? nwg128 / 1024 : 1;
-    static const int tpb_env = getenv("RK_GEMM_TPB") ? atoi(getenv("RK_GEMM_TPB")) : 0;   // tuning only
+    static const int tpb_env = RK_TUNE_INT("RK_GEMM_TPB", 0);   // tuning only
     if (tpb_env > 0) tpb = tpb_env;
     tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
     const dim3 grid((nwg128 + tpb - 1) / tpb);

@@ -473,10 +473,10 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     if ((a.n_blocks & kSchedLongFlag) && !a.scratch) return hipErrorInvalidValue;  // long rows need their scratch block
     a.n_blocks &= ~(kSchedPackedFlag | kSchedWavesMask | kSchedLongFlag);
     const dim3 grid(a.n_blocks), block(W * 64);
-    static const int variant = getenv("RK_SPMM_VARIANT") ? atoi(getenv("RK_SPMM_VARIANT")) : 0;
-    static const int dbg = getenv("RK_SPMM_DEBUG") ? atoi(getenv("RK_SPMM_DEBUG")) : 0;
+    static const int variant = RK_TUNE_INT("RK_SPMM_VARIANT", 0);
+    static const int dbg = RK_TUNE_INT("RK_SPMM_DEBUG", 0);
     a.dbg = dbg;
-    static const int no_filt = getenv("RK_SPMM_NO_FRONTIER") ? atoi(getenv("RK_SPMM_NO_FRONTIER")) : 0;   // A/B only
+    static const int no_filt = RK_TUNE_INT("RK_SPMM_NO_FRONTIER", 0);   // A/B only
     if (no_filt || a.drop_thresh24 || !(a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) a.src_filter = nullptr;
     const bool filt = a.src_filter != nullptr;
 #define RK_SPMM_CASE(D, UN, WV, MW)                                                              \

@@ -378,7 +378,7 @@ enum { LS_HEAD = 0 /* 8 queue heads, one per 128-byte line */, LS_ARRIVE = 8 * 3
 // plan words at LP_MQ_OFS: {n_queues, n_groups, G, 0}, then n_queues x {n_items, first int4 of its list (in int4 units from
 // the plan's start)}, then n_groups x members; the lists hold int4 {half, slice, block, group}
 static constexpr int kLdsMaxPhases = 4;
-static constexpr unsigned kLdsSpinLimit = 1u << 26;   // polls before a waiter gives up (sets LS_ERR; ~ seconds)
+static constexpr unsigned kLdsSpinLimit = 1u << 21;   // polls before a waiter gives up and sets LS_ERR (a poll is a ~1.5 us round trip: ~3 s)
 
 struct LdsPhase {
     const float *x;
