@@ -142,7 +142,8 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
     float4 *part = tab + n4 + 16;
     int2 *ltask = reinterpret_cast<int2 *>(part + bd[LB_NPART] * LP);
     int *qhead = reinterpret_cast<int *>(ltask + n_tasks);
-    if (tid == 0) *qhead = 0;
+    if (HAND) { if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) *qhead = 0; }   // (wave-uniform branch: see spmm_lds_multi_kernel)
+    else if (tid == 0) *qhead = 0;
     for (int t = tid; t < n_tasks; t += kLdsThreads) ltask[t] = tasks[t];
     auto row_ops = [&](int i) {
         LdsRowOps o;
@@ -411,34 +412,54 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
     volatile int *bc = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_dyn) + a.bc_ofs);
     int *head = a.sync + LS_HEAD + q * 32;
     const int total = n_items * a.n_phases;
+#ifdef RK_LDS_DEBUG   // progress markers behind the sync words (debug builds; the probe over-allocates): {stage, ticket, iterations, spins}
+#define LDS_MARK(k, v) do { if (tid == 0) __hip_atomic_store(a.sync + 2560 + blockIdx.x * 4 + (k), (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define LDS_MARK(k, v) do { } while (0)
+#endif
+    // Everything one "leader" does around the workgroup barriers is done by the WHOLE first wave under a wave-uniform
+    // (scalar) branch, never by `if (tid == 0)`: with a single-lane branch at the bottom AND the top of this loop the
+    // compiler rotated the loop so that lane 0 left it alone (arrival add, next ticket, LDS store) while lanes 1-63 of its
+    // wave went on to the barrier -- s_barrier counts waves, not lanes, so the workgroup read a stale ticket and never
+    // terminated (ROCm 7.2, gfx950).  Every lane of that wave adds 1, so the counters advance in units of 64 (the compiler
+    // folds a wave's equal adds into ONE atomic of 64 whose first lane receives the old value -- no per-lane scan).
+    const bool w0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    int iters = 0;
     for (;;) {
-        if (tid == 0) bc[0] = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LDS_MARK(0, 1); LDS_MARK(2, iters); ++iters;
+        if (w0) bc[0] = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6;
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(bc[0]);   // uniform: the phase's arguments below are scalar loads
+        LDS_MARK(0, 2); LDS_MARK(1, t);
         if (t >= total) break;
         const int phase = t / n_items;
         const int4 wg = list[t - phase * n_items];   // {half, slice, block, group}
         int *arrive = a.sync + LS_ARRIVE + wg.w * 32;
-        if (phase > 0 && tid == 0) {
+        if (phase > 0 && w0) {
             // every member of the group has finished the previous phase (its stores drained before its add)
-            const int need = members[wg.w] * phase;
+            const int need = members[wg.w] * phase * 64;
             unsigned spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
                 __builtin_amdgcn_s_sleep(1);
+                LDS_MARK(3, spins);
                 if (++spins > kLdsSpinLimit) { __hip_atomic_store(a.sync + LS_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
         }
         __syncthreads();   // after the poll, before EVERY load of handed-off bytes; also: bc has been read by everybody
+        LDS_MARK(0, 3);
         const LdsPhase &ph = a.ph[phase];   // (kernel-argument memory: uniform loads at a uniform offset, no copy)
         if (wg.x == 0) lds_body<LPA, true>(ph.x, ph.e, plan, 0, wg.y, wg.z, lds_dyn);
         else lds_body<LPB, true>(ph.x, ph.e, plan, 1, wg.y, wg.z, lds_dyn);
+        LDS_MARK(0, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
-        __syncthreads();                                    // ... before the ONE lane that signals for all of them
-        if (tid == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                    // ... before the ONE wave that signals for all of them
+        LDS_MARK(0, 5);
+        if (w0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    LDS_MARK(0, 6);
     // leave the sync words zero for the next launch: the last workgroup out (nobody reads or adds after its own done-add)
-    if (tid == 0) bc[1] = __hip_atomic_fetch_add(a.sync + LS_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w0) bc[1] = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(a.sync + LS_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6;
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(bc[1]) == (int)gridDim.x - 1) {
         if (tid < 8) __hip_atomic_store(a.sync + LS_HEAD + tid * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

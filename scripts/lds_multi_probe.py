@@ -18,6 +18,8 @@ def main():
     name = args[0] if args else "lightgcn_dev_d64"
     L = int(args[1]) if len(args) > 1 else 2
     dev = torch.device("cuda:0")
+    if "--watch" in sys.argv:
+        _lib.RK_LDS_SYNC_WORDS = 2560 + 4 * 256 + 64   # room for the debug build's per-workgroup markers
     g = G.load(name)
     outs = {}
     for fuse in (False, True):
@@ -29,6 +31,36 @@ def main():
         m.embedding_item.weight.data.copy_(torch.from_numpy(i0))
         m = m.to(dev)
         t0 = time.perf_counter()
+        if fuse and "--watch" in sys.argv:
+            # debug build (-DRK_LDS_DEBUG through RECAD_HIP_LIB): launch on a side stream, watch it from the host, dump the markers if it hangs
+            m._ensure_handle()
+            big = m._ws["lds_sync"]
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                lu, li = m._propagate()
+            for k in range(40):
+                time.sleep(0.5)
+                if side.query():
+                    print("  completed in < %.1f s" % (0.5 * (k + 1)), flush=True)
+                    break
+            else:
+                copy = torch.cuda.Stream()
+                host = torch.empty(big.numel(), dtype=torch.int32).pin_memory()
+                with torch.cuda.stream(copy):
+                    host.copy_(big, non_blocking=True)
+                for k in range(20):
+                    time.sleep(0.5)
+                    if copy.query():
+                        break
+                s = host.numpy()
+                print("HUNG after 20 s.  heads", s[0:256:32].tolist(), "arrive", s[256:256 + 16 * 32:32].tolist(), "done", int(s[2304]), "err", int(s[2336]), flush=True)
+                mk = s[2560:2560 + 4 * 256].reshape(256, 4)
+                import collections
+                print("stage histogram", dict(collections.Counter(mk[:, 0].tolist())), flush=True)
+                for b in range(0, 256, 8):
+                    print("  wg", b, mk[b].tolist(), flush=True)
+                import os
+                os._exit(3)
         lu, li = m.computer()
         torch.cuda.synchronize()
         print(f"fuse={fuse}: first propagate {time.perf_counter() - t0:.3f} s", flush=True)
