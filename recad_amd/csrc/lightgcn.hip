@@ -531,6 +531,8 @@ static int launch_lds_multi(const rk_lightgcn_desc &d, const LdsInfo &li, const 
         LdsMultiArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.plan = d.lds_plan; ma.sync = d.lds_sync; ma.n_phases = m;
+        // tuning builds: RK_LDS_MSTAMPS=1 puts per-item wall-clock stamps behind the sync words (the probe over-allocates them)
+        if (RK_TUNE_INT("RK_LDS_MSTAMPS", 0) && d.lds_sync) ma.stamps = reinterpret_cast<unsigned long long *>(d.lds_sync + RK_LDS_SYNC_WORDS);
         for (int k = 0; k < m; ++k) {
             ma.ph[k].x = ph[p0 + k].x;
             ma.ph[k].e = ph[p0 + k].e;

@@ -106,7 +106,8 @@ struct LdsRowOps {
 // HAND: a phase of the multi-phase launch -- x / add / sum_in may have been written by OTHER workgroups of this launch (sc1
 // loads only), y / sliced sum_out are published write-through when e.publish is set.
 template <int LP, bool HAND = false>
-__device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds)
+__device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds,
+                                         unsigned long long *hst = nullptr /* HAND, diagnostic: {staged, gathered} wall-clock stamps */)
 {
     constexpr int SL = 64 / LP, S = 4 * LP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -187,6 +188,7 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
     if (tid < 16) tab[n4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding entries' rows
     __syncthreads();
     if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 1] = wall_clock64();
+    if (HAND && hst && __builtin_amdgcn_readfirstlane(tid >> 6) == 0) hst[0] = wall_clock64();
     // ---- phase 2: tasks, longest first, popped from an LDS counter; the next task's descriptor, destination and
     // first stream block are requested while the current one is walked
     auto pop = [&]() {
@@ -279,6 +281,7 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
     }
     __syncthreads();
     if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    if (HAND && hst && __builtin_amdgcn_readfirstlane(tid >> 6) == 0) hst[1] = wall_clock64();
     // ---- phase 3: per output row, chunk partials in CSR order, dinv of the row, fused epilogue
     for (int i = tid; i < n_rows * LP; i += kLdsThreads) {
         const int j = i % LP;
@@ -389,6 +392,7 @@ struct LdsMultiArgs {
     const int *plan;
     int *sync;
     int n_phases, bc_ofs;   // bc_ofs: byte offset of a 16-byte broadcast slot behind the body's LDS layout
+    unsigned long long *stamps;   // diagnostic, nullable: 8 wall-clock stamps per (workgroup, item): ticket known, wait over, staged, gathered, rows done, drained
     LdsPhase ph[kLdsMaxPhases];
 };
 
@@ -425,9 +429,11 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
     // folds a wave's equal adds into ONE atomic of 64 whose first lane receives the old value -- no per-lane scan).
     const bool w0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     int iters = 0;
+    int t_next = 0;   // (first wave) the NEXT ticket, drawn while this item's stores drain
+    if (w0) t_next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         LDS_MARK(0, 1); LDS_MARK(2, iters); ++iters;
-        if (w0) bc[0] = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6;
+        if (w0) bc[0] = __builtin_amdgcn_readfirstlane(t_next) >> 6;
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(bc[0]);   // uniform: the phase's arguments below are scalar loads
         LDS_MARK(0, 2); LDS_MARK(1, t);
@@ -440,20 +446,32 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
             const int need = members[wg.w] * phase * 64;
             unsigned spins = 0;
             while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-                __builtin_amdgcn_s_sleep(1);
                 LDS_MARK(3, spins);
                 if (++spins > kLdsSpinLimit) { __hip_atomic_store(a.sync + LS_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
         }
+#ifdef RK_TUNING   // per-item wall-clock stamps (tuning builds only; written by the whole first wave: no single-lane branch, see above)
+        unsigned long long *st = a.stamps ? a.stamps + ((size_t)blockIdx.x * kLdsMaxPhases + (size_t)(iters - 1)) * 8 : nullptr;
+#define LDS_STAMP(k) do { if (st && w0) st[k] = wall_clock64(); } while (0)
+        if (st && w0) st[6] = (unsigned long long)t;
+#else
+        unsigned long long *const st = nullptr;
+#define LDS_STAMP(k) do { } while (0)
+#endif
+        LDS_STAMP(0);
         __syncthreads();   // after the poll, before EVERY load of handed-off bytes; also: bc has been read by everybody
+        LDS_STAMP(1);
         LDS_MARK(0, 3);
         const LdsPhase &ph = a.ph[phase];   // (kernel-argument memory: uniform loads at a uniform offset, no copy)
-        if (wg.x == 0) lds_body<LPA, true>(ph.x, ph.e, plan, 0, wg.y, wg.z, lds_dyn);
-        else lds_body<LPB, true>(ph.x, ph.e, plan, 1, wg.y, wg.z, lds_dyn);
+        if (wg.x == 0) lds_body<LPA, true>(ph.x, ph.e, plan, 0, wg.y, wg.z, lds_dyn, st ? st + 2 : nullptr);
+        else lds_body<LPB, true>(ph.x, ph.e, plan, 1, wg.y, wg.z, lds_dyn, st ? st + 2 : nullptr);
+        LDS_STAMP(4);
         LDS_MARK(0, 4);
+        if (w0) t_next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the drain
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
         __syncthreads();                                    // ... before the ONE wave that signals for all of them
+        LDS_STAMP(5);
         LDS_MARK(0, 5);
         if (w0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -565,7 +565,11 @@ def _ncf_fp64_gate_arbiter(m, g, emb, W, b, pw, pb, names, pick):
     for nme, gr in zip(names, m._ws["grad"]):
         ref = g["grad1_" + nme]
         t64 = pick(nme, g_true[nme].numpy())   # (the golden holds a strided sample of every tensor: scale by the whole tensor's largest entry)
-        assert np.abs(ref.reshape(t64.shape) - t64).max() <= 2e-6 * float(g_true[nme].abs().max()), ("golden vs fp64", nme)
+        # L <= 3: ATen's blocked sums decide every gate like fp64 does (measured 4e-7).  L = 5 (8192-wide first layer, 8 M gates):
+        # the reference sits on ambiguous gates of its own -- its golden is 1.3e-2 of the largest entry away from fp64 autograd on
+        # the first layer's weights -- so only the GPU side, whose gates are known here, can be pinned tightly at that depth
+        ref_tol = 2e-6 if L <= 3 else 3e-2
+        assert np.abs(ref.reshape(t64.shape) - t64).max() <= ref_tol * float(g_true[nme].abs().max()), ("golden vs fp64", nme)
         got, want = gr.cpu().numpy().astype(np.float64), g_gpu_gates[nme].numpy().reshape(tuple(gr.shape))
         assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max(), ("gpu vs fp64 with the gpu's gates", nme, np.abs(got - want).max() / np.abs(want).max())
     return n_amb
