@@ -66,9 +66,11 @@ class LightGCN(BaseVictim):
         # when it is the faster kernel -- staging the slice tables costs ~2 us per launch whatever the graph holds, so sparse
         # graphs (the reference's as-is test-edge graphs: 10 nonzeros per row, 7.3 vs 6.6 us per launch) stay on the row gather
         self.use_lds = "auto"
-        # LDS path: the L layers of a forward / backward pass as ONE launch whose workgroups hand the layers over to each other
-        # per column group (csrc/spmm_lds.h, spmm_lds_multi_kernel) instead of L launches; False = one launch per layer
-        self.fuse_layers = True
+        # LDS path, opt-in: the L layers of a forward / backward pass as ONE launch whose workgroups hand the layers over to each
+        # other per column group (csrc/spmm_lds.h, spmm_lds_multi_kernel) instead of L launches.  Same bits; measured SLOWER on
+        # MI355X (ml1m: 90.2 vs 72.7 us per step -- an in-launch hand-off costs 2.5-3 us per seam against 1.9 us for the kernel
+        # boundary it removes), so the default is one launch per layer
+        self.fuse_layers = False
         # ordered (bit-reproducible) gradient scatter instead of float atomics: one more launch per step and a sort of
         # the epoch's triplets (rk_lightgcn_set_deterministic); not a reference option (its CUDA path is atomic too)
         self.deterministic = bool(config.get("deterministic", False))
@@ -159,7 +161,7 @@ class LightGCN(BaseVictim):
         ws["spmm_scratch"] = None if lds else g.new_scratch(d)  # this handle's own long-row counters / partial slots
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
-        fuse = bool(lds) and bool(self.fuse_layers) and self.n_layers >= 2 and not os.environ.get("RK_LDS_NO_FUSE")
+        fuse = bool(lds) and (bool(self.fuse_layers) or bool(os.environ.get("RK_LDS_FUSE"))) and self.n_layers >= 2   # (RK_LDS_FUSE=1: A/B runs of bench.py)
         ws["lds_sync"] = torch.zeros(_lib.RK_LDS_SYNC_WORDS, device=dev, dtype=torch.int32) if fuse else None   # this handle's own hand-off counters
         for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
             ws[k] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None

@@ -18,7 +18,7 @@ def main():
                              device=dev, graph_source="train", seed=3)
     torch.manual_seed(1)
     m = model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=3).I(dataset=ds).to(dev)
-    m.use_lds = True
+    m.use_lds, m.fuse_layers = True, True
     h = m._ensure_handle()
     for _ in range(20):
         _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")

@@ -1737,7 +1737,7 @@ def test_lightgcn_fused_layers_under_contention(gpu_device):
     for seed in (1, 2, 3):
         torch.manual_seed(seed)
         m = model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=3).I(dataset=ds).to(gpu_device)
-        m.use_lds = True
+        m.use_lds, m.fuse_layers = True, True
         ms.append(m)
     refs = []
     for m in ms:
