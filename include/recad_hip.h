@@ -131,7 +131,8 @@ typedef struct rk_lds_info {
     int32_t n_wg, lds_bytes, lpa, lpb;        /* launch shape: workgroups, dynamic LDS bytes, lanes per entry of the two halves */
     int32_t n_users, n_items, dim, lsu, lsi;  /* sliced-layout parameters */
     int32_t chunk;                            /* chunk caps (half 0 | half 1 << 16), informational */
-    int32_t reserved[6];
+    int32_t wgx_ofs, dinv_ofs, perm0_ofs, perm1_ofs, mq_ofs;   /* word offsets of the plan's sections: the launches pass them as kernel arguments (ABI 8) */
+    int32_t reserved;
 } rk_lds_info;
 typedef struct rk_lds_plan *rk_lds_plan_t;
 int rk_lds_plan_build(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val /*nullable*/,

@@ -32,7 +32,8 @@ class LdsInfo(C.Structure):
     _fields_ = [
         ("n_wg", C.c_int32), ("lds_bytes", C.c_int32), ("lpa", C.c_int32), ("lpb", C.c_int32),
         ("n_users", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("lsu", C.c_int32), ("lsi", C.c_int32),
-        ("chunk", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("chunk", C.c_int32), ("wgx_ofs", C.c_int32), ("dinv_ofs", C.c_int32), ("perm0_ofs", C.c_int32), ("perm1_ofs", C.c_int32),
+        ("mq_ofs", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

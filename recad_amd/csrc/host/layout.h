@@ -15,11 +15,14 @@
 // ---- LDS-resident SpMM plan (device int32 words), header words
 enum {
     LP_MAGIC = 0, LP_NWG, LP_U, LP_I, LP_D, LP_LSU, LP_LSI, LP_NBLK0, LP_NBLK1, LP_WG_OFS, LP_BLK_OFS, LP_DINV_OFS,
-    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_MQ_OFS, LP_HDR_WORDS = 32
+    LP_LDS_BYTES, LP_CHUNK, LP_NWORDS, LP_PERM0, LP_PERM1, LP_MQ_OFS, LP_WGX_OFS, LP_HDR_WORDS = 32
 };
 static constexpr int kLdsMagic = 0x4c445331;  // "LDS1"
 // block descriptor words (one per (half, row block), shared by all slices)
 enum { LB_ROW0 = 0, LB_NROWS, LB_NPART, LB_NTASKS, LB_TASK_OFS, LB_DST_OFS, LB_PP_OFS, LB_STREAM_OFS, LB_WORDS = 8 };
+// workgroup records (LP_WGX_OFS, 16 words = 64 bytes each, entry b = what blockIdx b runs): {half, slice, block, group} + the
+// block descriptor's 8 words + 4 spare -- ONE load gives a workgroup everything the header / table / descriptor chain held
+enum { LW_HALF = 0, LW_SLICE, LW_BLOCK, LW_GROUP, LW_BD = 4, LW_WORDS = 16 };
 static constexpr int kLdsThreads = 1024;
 static constexpr int kLdsMaxBytes = 160 * 1024;
 

@@ -288,7 +288,12 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
                     for (int h = 0; h < 2; ++h) {
                         if (k >= hp[h].n_blk) continue;
                         for (int sl = g * G / hp[h].S; sl < (g + 1) * G / hp[h].S; ++sl) {
-                            w.insert(w.end(), {h, sl, k, g});
+                            int rec = -1;   // the launch-order record of this (half, slice, block)
+                            for (int b = 0; b < n_wg && rec < 0; ++b) {
+                                const int32_t *e = &w[(size_t)w[LP_WG_OFS] + (size_t)b * 4];
+                                if (e[0] == h && e[1] == sl && e[2] == k) rec = b;
+                            }
+                            w.insert(w.end(), {rec, 0, 0, g});   // {record index (LP_WGX_OFS), -, -, group}
                             ++n_items;
                         }
                     }
@@ -532,12 +537,31 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         stream_ofs16[bi] = stream.size() / 8;
         stream.insert(stream.end(), o.stream.begin(), o.stream.end());
     }
+    // ---- one 64-byte record per workgroup (LW_*): table entry + its block descriptor, in launch order
+    {
+        while (w.size() & 15) w.push_back(0);
+        w[LP_WGX_OFS] = (int32_t)w.size();
+        const int G = std::max(hp[0].S, hp[1].S);
+        for (int b = 0; b < n_wg; ++b) {
+            const int32_t *e = &w[(size_t)w[LP_WG_OFS] + (size_t)b * 4];
+            const int h = e[0], sl = e[1], rb = e[2];
+            const int32_t *bd = &w[(size_t)w[LP_BLK_OFS] + ((size_t)(h ? hp[0].n_blk : 0) + (size_t)rb) * LB_WORDS];
+            int32_t rec[LW_WORDS] = {h, sl, rb, sl * hp[h].S / G, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < LB_WORDS; ++k) rec[LW_BD + k] = bd[k];
+            w.insert(w.end(), rec, rec + LW_WORDS);
+        }
+    }
     w[LP_DINV_OFS] = (int32_t)w.size();
     w.resize(w.size() + (size_t)N);
     memcpy(&w[(size_t)w[LP_DINV_OFS]], dinv.data(), sizeof(float) * (size_t)N);
     while (w.size() & 3) w.push_back(0);   // the stream is read with 16-byte loads
     const size_t stream_base16 = w.size() / 4;
     for (size_t bi = 0; bi < n_blocks_total; ++bi) w[(size_t)w[LP_BLK_OFS] + bi * LB_WORDS + LB_STREAM_OFS] = (int32_t)(stream_base16 + stream_ofs16[bi]);
+    for (int b = 0; b < n_wg; ++b) {   // (the records were written before the stream had its place)
+        int32_t *rec = &w[(size_t)w[LP_WGX_OFS] + (size_t)b * LW_WORDS];
+        const size_t bi = (size_t)(rec[LW_HALF] ? hp[0].n_blk : 0) + (size_t)rec[LW_BLOCK];
+        rec[LW_BD + LB_STREAM_OFS] = w[(size_t)w[LP_BLK_OFS] + bi * LB_WORDS + LB_STREAM_OFS];
+    }
     w.resize(w.size() + stream.size() / 2);
     memcpy(&w[stream_base16 * 4], stream.data(), stream.size() * sizeof(uint16_t));
     w[LP_NWORDS] = (int32_t)w.size();
@@ -545,6 +569,7 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
     memset(&fi, 0, sizeof(fi));
     fi.n_wg = n_wg; fi.lds_bytes = w[LP_LDS_BYTES]; fi.lpa = hp[0].lp; fi.lpb = hp[1].lp;
     fi.n_users = U; fi.n_items = I; fi.dim = dim; fi.lsu = lsu; fi.lsi = lsi; fi.chunk = w[LP_CHUNK];
+    fi.wgx_ofs = w[LP_WGX_OFS]; fi.dinv_ofs = w[LP_DINV_OFS]; fi.perm0_ofs = w[LP_PERM0]; fi.perm1_ofs = w[LP_PERM1]; fi.mq_ofs = w[LP_MQ_OFS];
     *info = fi;
     *n_words = (int64_t)w.size();
     *out = pl;

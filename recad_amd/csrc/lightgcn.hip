@@ -420,7 +420,8 @@ static int check_desc(const rk_lightgcn_desc &d)
         RK_FAIL(RK_EINVAL, "lightgcn: graph dropout needs 0 < keep_prob <= 1 and the transpose index tpos");
     if (d.lds_plan) {
         if (!d.lsum || !d.e0s || !d.ms || !d.vs) RK_FAIL(RK_EINVAL, "lightgcn: lds_plan needs the lsum, e0s, ms and vs work buffers");
-        if (d.lds_info.n_users != d.n_users || d.lds_info.n_items != d.n_items || d.lds_info.dim != d.dim || d.lds_info.n_wg <= 0)
+        if (d.lds_info.n_users != d.n_users || d.lds_info.n_items != d.n_items || d.lds_info.dim != d.dim || d.lds_info.n_wg <= 0 ||
+            d.lds_info.wgx_ofs <= 0 || d.lds_info.dinv_ofs <= 0)
             RK_FAIL(RK_EINVAL, "lightgcn: lds_info does not describe this graph / dim");
         if (reinterpret_cast<uintptr_t>(d.lds_plan) & 15) RK_FAIL(RK_EINVAL, "lightgcn: lds_plan must be 16-byte aligned");
         if (d.lds_sync && (reinterpret_cast<uintptr_t>(d.lds_sync) & 127)) RK_FAIL(RK_EINVAL, "lightgcn: lds_sync must be 128-byte aligned");
@@ -494,6 +495,8 @@ static LdsInfo lds_info(const rk_lightgcn_desc &d)
     LdsInfo li;
     li.n_wg = d.lds_info.n_wg; li.lds_bytes = d.lds_info.lds_bytes; li.lpa = d.lds_info.lpa; li.lpb = d.lds_info.lpb;
     li.U = d.n_users; li.I = d.n_items; li.d = d.dim; li.lsu = d.lds_info.lsu; li.lsi = d.lds_info.lsi;
+    li.wgx_ofs = d.lds_info.wgx_ofs; li.dinv_ofs = d.lds_info.dinv_ofs; li.perm0 = d.lds_info.perm0_ofs; li.perm1 = d.lds_info.perm1_ofs;
+    li.mq_ofs = d.lds_info.mq_ofs;
     return li;
 }
 
@@ -530,7 +533,7 @@ static int launch_lds_multi(const rk_lightgcn_desc &d, const LdsInfo &li, const 
         if (m == 1) { RK_HIP(spmm_lds_launch(li, ph[p0], s)); continue; }
         LdsMultiArgs ma;
         memset(&ma, 0, sizeof(ma));
-        ma.plan = d.lds_plan; ma.sync = d.lds_sync; ma.n_phases = m;
+        ma.plan = d.lds_plan; ma.sync = d.lds_sync; ma.n_phases = m; ma.h = li.hdr();
         // tuning builds: RK_LDS_MSTAMPS=1 puts per-item wall-clock stamps behind the sync words (the probe over-allocates them)
         if (RK_TUNE_INT("RK_LDS_MSTAMPS", 0) && d.lds_sync) ma.stamps = reinterpret_cast<unsigned long long *>(d.lds_sync + RK_LDS_SYNC_WORDS);
         for (int k = 0; k < m; ++k) {
@@ -555,7 +558,7 @@ static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s, bool tra
     for (int l = 1; l <= L; ++l) {
         LdsArgs &a = ph[(size_t)l - 1];
         memset(&a, 0, sizeof(a));
-        a.plan = d.lds_plan;
+        a.plan = d.lds_plan; a.h = li.hdr();
         a.x = (l == 1) ? d.e0s : bufs[l & 1];
         a.e.y = (l < L) ? bufs[(l + 1) & 1] : nullptr;
         a.e.sum_in = (l == 1) ? d.e0s : d.lsum;
@@ -578,7 +581,7 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
     for (int j = 1; j <= L; ++j) {
         LdsArgs &a = ph[(size_t)j - 1];
         memset(&a, 0, sizeof(a));
-        a.plan = d.lds_plan;
+        a.plan = d.lds_plan; a.h = li.hdr();
         a.x = (j == 1) ? d.gprop : bufs[j & 1];
         const bool last = (j == L);
         a.e.add = (last && !counted) ? d.gego : d.gprop;

@@ -59,9 +59,33 @@ struct LdsEpi {
     int publish;
 };
 
+// what the plan's header words say, as KERNEL ARGUMENTS (the host knows them: rk_lds_info): a workgroup's only dependent load
+// before its staging loads is then its own 64-byte record (LW_*) -- the header -> table -> block descriptor chain of dependent
+// loads cost every launch ~1 us before the first staging load was issued
+struct LdsHdr {
+    int U, I, d, lsu, lsi, wgx_ofs, dinv_ofs, perm0, perm1, mq_ofs;
+};
+struct LdsRec {   // a workgroup's record, in SGPRs
+    int half, slice, rb, grp, row0, n_rows, n_part, n_tasks, task_ofs, dst_ofs, pp_ofs, stream_ofs;
+};
+__device__ __forceinline__ LdsRec lds_load_rec(const int *__restrict__ plan, int wgx_ofs, int b)
+{
+    const int4 *p = reinterpret_cast<const int4 *>(plan + wgx_ofs) + (size_t)b * (LW_WORDS / 4);
+    const int4 a = p[0], c = p[1], g = p[2];
+    LdsRec r;
+    r.half = __builtin_amdgcn_readfirstlane(a.x); r.slice = __builtin_amdgcn_readfirstlane(a.y);
+    r.rb = __builtin_amdgcn_readfirstlane(a.z); r.grp = __builtin_amdgcn_readfirstlane(a.w);
+    r.row0 = __builtin_amdgcn_readfirstlane(c.x); r.n_rows = __builtin_amdgcn_readfirstlane(c.y);
+    r.n_part = __builtin_amdgcn_readfirstlane(c.z); r.n_tasks = __builtin_amdgcn_readfirstlane(c.w);
+    r.task_ofs = __builtin_amdgcn_readfirstlane(g.x); r.dst_ofs = __builtin_amdgcn_readfirstlane(g.y);
+    r.pp_ofs = __builtin_amdgcn_readfirstlane(g.z); r.stream_ofs = __builtin_amdgcn_readfirstlane(g.w);
+    return r;
+}
+
 struct LdsArgs {
     const int *plan;
     const float *x;  // sliced [N, d]
+    LdsHdr h;
     LdsEpi e;
 };
 
@@ -94,6 +118,16 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, size_t float_
     __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)(unsigned)(float_off * 4), 0, 16);
 }
 
+// Workgroup barrier between two phases that only exchange data through LDS: release / acquire fences on the LOCAL address space
+// only, so global loads already requested (epilogue operands, the next stream blocks) stay in flight across it -- __syncthreads()
+// drains vmcnt.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // epilogue operands of one (row, 4-column piece), requested before the gather so that they are in registers when
 // the row's sum is ready
 struct LdsRowOps {
@@ -106,34 +140,34 @@ struct LdsRowOps {
 // HAND: a phase of the multi-phase launch -- x / add / sum_in may have been written by OTHER workgroups of this launch (sc1
 // loads only), y / sliced sum_out are published write-through when e.publish is set.
 template <int LP, bool HAND = false>
-__device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const int *__restrict__ plan, int half, int slice, int rb, float4 *lds,
+__device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const int *__restrict__ plan, const LdsHdr &hd, const LdsRec &rec, float4 *lds,
                                          unsigned long long *hst = nullptr /* HAND, diagnostic: {staged, gathered} wall-clock stamps */)
 {
     constexpr int SL = 64 / LP, S = 4 * LP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane / LP, pj = lane % LP;
-    const int U = plan[LP_U], I = plan[LP_I], d = plan[LP_D];
+    const int half = rec.half, slice = rec.slice;
+    const int U = hd.U, I = hd.I, d = hd.d;
     const int n_src = half ? U : I, n_dst = half ? I : U;
-    const int *bd = plan + plan[LP_BLK_OFS] + ((half ? plan[LP_NBLK0] : 0) + rb) * LB_WORDS;
-    const float *dinv = reinterpret_cast<const float *>(plan + plan[LP_DINV_OFS]);
+    const float *dinv = reinterpret_cast<const float *>(plan + hd.dinv_ofs);
     const float *dsrc = dinv + (half ? 0 : U), *ddst = dinv + (half ? U : 0);
     // the source class's slice table: n_src * S contiguous floats
     const float4 *s4 = reinterpret_cast<const float4 *>(ax + (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S);
     const int n4 = n_src * LP;
     // LDS row of source row c: sources sorted by degree are dealt round-robin over the 16 / LP bank classes, so the hot
     // columns (an item half the users rated) do not pile up in one class of every lane group
-    const int *perm = plan + plan[half ? LP_PERM1 : LP_PERM0];
-    const int n_tasks = bd[LB_NTASKS];
-    const int2 *tasks = reinterpret_cast<const int2 *>(plan + bd[LB_TASK_OFS]);
-    const int *dstv = plan + bd[LB_DST_OFS];
-    const uint4 *stream = reinterpret_cast<const uint4 *>(plan) + bd[LB_STREAM_OFS];
-    const int n_rows = bd[LB_NROWS], row0 = bd[LB_ROW0];
-    const int *pp = plan + bd[LB_PP_OFS];
+    const int *perm = plan + (half ? hd.perm1 : hd.perm0);
+    const int n_tasks = rec.n_tasks;
+    const int2 *tasks = reinterpret_cast<const int2 *>(plan + rec.task_ofs);
+    const int *dstv = plan + rec.dst_ofs;
+    const uint4 *stream = reinterpret_cast<const uint4 *>(plan) + rec.stream_ofs;
+    const int n_rows = rec.n_rows, row0 = rec.row0;
+    const int *pp = plan + rec.pp_ofs;
     const size_t nd = (size_t)(U + I) * (size_t)d;
     const __amdgpu_buffer_rsrc_t rs_x = lds_rsrc(HAND ? ax : nullptr, nd), rs_add = lds_rsrc(HAND ? e.add : nullptr, nd),
                                  rs_sum = lds_rsrc(HAND && e.sum_out ? e.sum_in : nullptr, nd);
     const size_t x_off = (half ? (size_t)0 : (size_t)U * d) + (size_t)slice * n_src * S;   // first float of the slice table
-    const int lso = half ? plan[LP_LSI] : plan[LP_LSU];  // slice width (log2) of the OUTPUT class's block
+    const int lso = half ? hd.lsi : hd.lsu;  // slice width (log2) of the OUTPUT class's block
     const size_t cls_base = half ? (size_t)U * d : 0;
     const int node0 = half ? U : 0;
     if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 0] = wall_clock64();
@@ -141,11 +175,10 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
     // (the table sits at LDS address 0, so an entry's address is its stream word shifted)
     float4 *tab = lds;
     float4 *part = tab + n4 + 16;
-    int2 *ltask = reinterpret_cast<int2 *>(part + bd[LB_NPART] * LP);
+    int2 *ltask = reinterpret_cast<int2 *>(part + rec.n_part * LP);
     int *qhead = reinterpret_cast<int *>(ltask + n_tasks);
     if (HAND) { if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) *qhead = 0; }   // (wave-uniform branch: see spmm_lds_multi_kernel)
     else if (tid == 0) *qhead = 0;
-    for (int t = tid; t < n_tasks; t += kLdsThreads) ltask[t] = tasks[t];
     auto row_ops = [&](int i) {
         LdsRowOps o;
         const int lr = i / LP, j = i % LP;
@@ -165,9 +198,6 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         }
         return o;
     };
-    // this thread's first epilogue row: its operand loads fly under the staging and the gather
-    LdsRowOps ops0{};
-    if (tid < n_rows * LP) ops0 = row_ops(tid);
     // ---- phase 1: stage the slice table, pre-scaled by dinv of the source rows
     constexpr int UN = 8;
     for (int i0 = tid; i0 < n4; i0 += kLdsThreads * UN) {
@@ -186,7 +216,12 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         }
     }
     if (tid < 16) tab[n4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding entries' rows
-    __syncthreads();
+    for (int t = tid; t < n_tasks; t += kLdsThreads) ltask[t] = tasks[t];   // (after the staging loads: a load that feeds an LDS write is waited for)
+    // this thread's first epilogue row: its operand loads fly under the barrier and the gather.  (Requested AFTER the staging
+    // loads: in front of them the compiler drained them -- s_waitcnt vmcnt(0) -- before the first staging load was issued.)
+    LdsRowOps ops0{};
+    if (tid < n_rows * LP) ops0 = row_ops(tid);
+    lds_barrier();   // (LDS-only fences: the operand loads above stay in flight across it)
     if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 1] = wall_clock64();
     if (HAND && hst && __builtin_amdgcn_readfirstlane(tid >> 6) == 0) hst[0] = wall_clock64();
     // ---- phase 2: tasks, longest first, popped from an LDS counter; the next task's descriptor, destination and
@@ -279,7 +314,7 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         if (my_dst >= 0) part[my_dst * LP + pj] = acc;
         t = tn; tk = tkn; st = stn; my_dst = dstn; c0 = n0; c1 = n1;
     }
-    __syncthreads();
+    lds_barrier();
     if (!HAND && e.stamps && tid == 0) e.stamps[blockIdx.x * 4 + 2] = wall_clock64();
     if (HAND && hst && __builtin_amdgcn_readfirstlane(tid >> 6) == 0) hst[1] = wall_clock64();
     // ---- phase 3: per output row, chunk partials in CSR order, dinv of the row, fused epilogue
@@ -356,9 +391,9 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_kernel(const LdsArgs a)
         a.e.state[ST_STEP_BASE] += a.e.bump;
         a.e.state[ST_ADAM_T] += a.e.bump;
     }
-    const int4 wg = reinterpret_cast<const int4 *>(plan + plan[LP_WG_OFS])[blockIdx.x];  // {half, slice, row block, 0}
-    if (wg.x == 0) lds_body<LPA>(a.x, a.e, plan, 0, wg.y, wg.z, lds_dyn);
-    else lds_body<LPB>(a.x, a.e, plan, 1, wg.y, wg.z, lds_dyn);
+    const LdsRec rec = lds_load_rec(plan, a.h.wgx_ofs, blockIdx.x);
+    if (rec.half == 0) lds_body<LPA>(a.x, a.e, plan, a.h, rec, lds_dyn);
+    else lds_body<LPB>(a.x, a.e, plan, a.h, rec, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -391,6 +426,7 @@ struct LdsPhase {
 struct LdsMultiArgs {
     const int *plan;
     int *sync;
+    LdsHdr h;
     int n_phases, bc_ofs;   // bc_ofs: byte offset of a 16-byte broadcast slot behind the body's LDS layout
     unsigned long long *stamps;   // diagnostic, nullable: 8 wall-clock stamps per (workgroup, item): ticket known, wait over, staged, gathered, rows done, drained
     LdsPhase ph[kLdsMaxPhases];
@@ -407,7 +443,7 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
         el.state[ST_STEP_BASE] += el.bump;
         el.state[ST_ADAM_T] += el.bump;
     }
-    const int *mq = plan + plan[LP_MQ_OFS];
+    const int *mq = plan + a.h.mq_ofs;
     const int n_queues = mq[0], n_groups = mq[1];
     const int q = (int)(blockIdx.x & 7) % n_queues;
     const int n_items = mq[4 + 2 * q];
@@ -439,7 +475,8 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
         LDS_MARK(0, 2); LDS_MARK(1, t);
         if (t >= total) break;
         const int phase = t / n_items;
-        const int4 wg = list[t - phase * n_items];   // {half, slice, block, group}
+        const int4 wg = list[t - phase * n_items];   // {record index, -, -, group}
+        const LdsRec rec = lds_load_rec(plan, a.h.wgx_ofs, __builtin_amdgcn_readfirstlane(wg.x));   // (in flight under the poll)
         int *arrive = a.sync + LS_ARRIVE + wg.w * 32;
         if (phase > 0 && w0) {
             // every member of the group has finished the previous phase (its stores drained before its add)
@@ -464,8 +501,8 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
         LDS_STAMP(1);
         LDS_MARK(0, 3);
         const LdsPhase &ph = a.ph[phase];   // (kernel-argument memory: uniform loads at a uniform offset, no copy)
-        if (wg.x == 0) lds_body<LPA, true>(ph.x, ph.e, plan, 0, wg.y, wg.z, lds_dyn, st ? st + 2 : nullptr);
-        else lds_body<LPB, true>(ph.x, ph.e, plan, 1, wg.y, wg.z, lds_dyn, st ? st + 2 : nullptr);
+        if (rec.half == 0) lds_body<LPA, true>(ph.x, ph.e, plan, a.h, rec, lds_dyn, st ? st + 2 : nullptr);
+        else lds_body<LPB, true>(ph.x, ph.e, plan, a.h, rec, lds_dyn, st ? st + 2 : nullptr);
         LDS_STAMP(4);
         LDS_MARK(0, 4);
         if (w0) t_next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the drain
@@ -518,6 +555,8 @@ static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
 // Host-side description of an uploaded plan (what the launch needs without reading the device buffer)
 struct LdsInfo {
     int n_wg, lds_bytes, lpa, lpb, U, I, d, lsu, lsi;
+    int wgx_ofs, dinv_ofs, perm0, perm1, mq_ofs;
+    LdsHdr hdr() const { return LdsHdr{U, I, d, lsu, lsi, wgx_ofs, dinv_ofs, perm0, perm1, mq_ofs}; }
 };
 
 inline hipError_t spmm_lds_launch(const LdsInfo &info, const LdsArgs &a, hipStream_t s)

@@ -68,6 +68,8 @@ static int lds_info_of(const rk_lds_info *fi, LdsInfo *o, const char *who)
     if (!fi || fi->n_wg <= 0 || fi->lds_bytes <= 0 || fi->lds_bytes > kLdsMaxBytes - 64 || fi->dim <= 0) RK_FAIL(RK_EINVAL, "%s: bad plan info", who);
     o->n_wg = fi->n_wg; o->lds_bytes = fi->lds_bytes; o->lpa = fi->lpa; o->lpb = fi->lpb;
     o->U = fi->n_users; o->I = fi->n_items; o->d = fi->dim; o->lsu = fi->lsu; o->lsi = fi->lsi;
+    o->wgx_ofs = fi->wgx_ofs; o->dinv_ofs = fi->dinv_ofs; o->perm0 = fi->perm0_ofs; o->perm1 = fi->perm1_ofs; o->mq_ofs = fi->mq_ofs;
+    if (fi->wgx_ofs <= 0 || fi->dinv_ofs <= 0) RK_FAIL(RK_EINVAL, "%s: plan info without section offsets (built by an older library?)", who);
     return RK_OK;
 }
 
@@ -111,7 +113,7 @@ RK_EXPORT int rk_spmm_lds(const rk_lds_info *info, const int32_t *plan, const fl
     hipStream_t s = (hipStream_t)stream;
     LdsArgs a;
     memset(&a, 0, sizeof(a));
-    a.plan = plan; a.x = x;
+    a.plan = plan; a.x = x; a.h = li.hdr();
     a.e.add = epi->add; a.e.y = epi->y; a.e.y_rm = epi->y_row_major; a.e.sum_in = epi->sum_in; a.e.sum_out = epi->sum_out;
     a.e.sum_rm = epi->sum_out_row_major; a.e.sum_scale = epi->sum_scale; a.e.zero1 = epi->zero1; a.e.zero2 = epi->zero2;
     a.e.stamps = reinterpret_cast<unsigned long long *>(epi->stamps);

@@ -10,7 +10,7 @@ import pytest
 from recad_amd import _lib, synth
 
 H = dict(MAGIC=0, NWG=1, U=2, I=3, D=4, LSU=5, LSI=6, NBLK0=7, NBLK1=8, WG_OFS=9, BLK_OFS=10, DINV_OFS=11, LDS_BYTES=12,
-         CHUNK=13, NWORDS=14, PERM0=15, PERM1=16, MQ_OFS=17)
+         CHUNK=13, NWORDS=14, PERM0=15, PERM1=16, MQ_OFS=17, WGX_OFS=18)
 LB = dict(ROW0=0, NROWS=1, NPART=2, NTASKS=3, TASK_OFS=4, DST_OFS=5, PP_OFS=6, STREAM_OFS=7, WORDS=8)
 
 
@@ -202,13 +202,18 @@ def test_multi_phase_queues_cover_the_launch_and_cannot_deadlock(shape, dim, n_c
     S = {0: 1 << int(words[H["LSI"]]), 1: 1 << int(words[H["LSU"]])}
     assert G == max(S.values()) and n_groups == dim // G and 1 <= n_queues <= 8 and n_groups <= 64
     wg = words[int(words[H["WG_OFS"]]): int(words[H["WG_OFS"]]) + 4 * int(words[H["NWG"]])].reshape(-1, 4)
-    single = sorted((int(h), int(s_), int(rb)) for h, s_, rb, _ in wg)
-    multi = sorted((int(h), int(s_), int(rb)) for qv in queues for h, s_, rb, _ in qv)
-    assert single == multi
+    # the 64-byte workgroup records: table entry + its block descriptor (what the kernels read instead of the header chain)
+    rec = words[int(words[H["WGX_OFS"]]): int(words[H["WGX_OFS"]]) + 16 * int(words[H["NWG"]])].reshape(-1, 16)
+    assert np.array_equal(rec[:, :3], wg[:, :3])
+    for b, (h, s_, rb, _) in enumerate(wg):
+        bd = words[int(words[H["BLK_OFS"]]) + ((int(words[H["NBLK0"]]) if h else 0) + int(rb)) * LB["WORDS"]:][: LB["WORDS"]]
+        assert np.array_equal(rec[b, 4:12], bd) and int(rec[b, 3]) == int(s_) * S[int(h)] // G
+    multi = sorted(int(b) for qv in queues for b, _, _, _ in qv)
+    assert multi == list(range(int(words[H["NWG"]])))          # every record exactly once
     count = np.zeros(n_groups, dtype=np.int64)
     for q, qv in enumerate(queues):
-        for h, s_, rb, g in qv:
-            assert int(g) == int(s_) * S[int(h)] // G and int(g) % n_queues == q      # the group of a slice; its home queue
+        for b, _, _, g in qv:
+            assert int(g) == int(rec[int(b), 3]) and int(g) % n_queues == q      # the group of its slice; its home queue
             count[int(g)] += 1
     assert np.array_equal(count, members)
     # ticket-order simulation: R < grid workgroups, each pulls from queue (b % 8) % n_queues; an item of phase p needs all
@@ -234,7 +239,7 @@ def test_multi_phase_queues_cover_the_launch_and_cannot_deadlock(shape, dim, n_c
             if t >= len(queues[q]) * n_phases:
                 del running[b]                                   # queue exhausted: the block exits
                 continue
-            phase, (h, s_, rb, g) = t // len(queues[q]), queues[q][t % len(queues[q])]
+            phase, (_, _, _, g) = t // len(queues[q]), queues[q][t % len(queues[q])]
             if phase > 0 and arrived[int(g)] < members[int(g)] * phase:
                 continue                                         # spins
             arrived[int(g)] += 1
