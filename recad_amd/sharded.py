@@ -194,6 +194,12 @@ class HipOps:
         _lib.check(_lib.lib().rk_adam_coef_advance(_lib.ptr(coef), _lib.ptr(counter), float(lr), float(b1), float(b2), _lib.stream_ptr()),
                    "rk_adam_coef_advance")
 
+    def adam(self, p, g, m, v, t, lr, b1, b2, eps):
+        """dense torch.optim.Adam step t (1-based) on a contiguous block (the 2-D trainer's owned rows: its gradient only exists
+        after a reduce-scatter, so it cannot ride in an SpMM epilogue)"""
+        _lib.check(_lib.lib().rk_adam_step(p.numel(), _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), int(t), float(lr), float(b1),
+                                           float(b2), float(eps), _lib.stream_ptr()), "rk_adam_step")
+
     def new_row_bits(self, n_rows, device):
         return torch.zeros((n_rows + 31) // 32, dtype=torch.int32, device=device)
 

@@ -1,0 +1,311 @@
+"""2-D (Pr x Pc) tiling of the row-sharded LightGCN trainer (north_star: "all-gather ... before scoring and reduce-scatter on
+the item gradients"): `--parallel rows2d`.
+
+The 1-D partition (recad_amd/sharded.py) makes every rank receive the whole gathered table per layer -- (W-1)/W of N*d*4 bytes:
+336 MB at config 4 with W = 8 -- and walk all of it with the gathers of its slab.  Here the W = Pr * Pc ranks form a grid; node
+row r belongs to block b = r % W (round-robin: balances a power-law graph), block b sits at grid position (i, j) = (b // Pc,
+b % Pc), and rank (i, j)
+
+  * owns block (i, j) of every vector (E0, Adam's moments, the layer outputs): N / W rows;
+  * holds the TILE A[R_i, C_j] of the normalised adjacency: rows R_i = the Pc blocks of grid row i, columns C_j = the Pr blocks
+    of grid column j (A is symmetric, so the same tile serves the backward pass).
+
+One propagation layer  y = A x :
+    all-gather of x within the COLUMN group (the Pr ranks (., j)): every member then holds x[C_j]   -- receives (Pr-1) blocks
+    local SpMM  partial = A[R_i, C_j] . x[C_j]                                                        -- N/Pr rows, nnz/W entries
+    reduce-scatter of the partials within the ROW group (the Pc ranks (i, .)): sum over j, rank (i, j) keeps block (i, j)
+                                                                                                      -- receives (Pc-1) blocks
+=> (Pr - 1 + Pc - 1) blocks of (N/W)*d*4 bytes received per rank and layer: 2 x 4 at config 4 = 4 x 48 MB = 192 MB instead of 336,
+and the tile's gathers touch a column part of N/Pc rows (96 MB) instead of the whole table.  The price: a second collective on
+every layer's critical path, and a summation order that depends on the grid (`reduce="ordered"` fixes it: an all-to-all of the
+partial blocks and a sum in group-rank order -- same bytes as a direct reduce-scatter).
+
+BPR runs replicated like in the 1-D trainer (B is tiny next to the graph): the minibatch's light rows AND ego rows travel in ONE
+[6B, d] all-reduce (every rank contributes the rows it owns, exact zeros elsewhere), the gradient rows are scattered into
+replicated, grid-column-major gprop / gego buffers, so the first backward layer's x[C_j] is a local view (no gather).
+
+Per step: L all-gathers + L reduce-scatters (forward), L reduce-scatters + (L-1) all-gathers (backward), one [6B, d] all-reduce.
+Evaluation is user-sharded exactly like the 1-D trainer's (inherited).  The step is launched eagerly (no capture yet)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .sharded import HipOps, ShardedLightGCN
+
+
+def grid_shape(world, pr=None):
+    """(Pr, Pc) with Pr * Pc == world: Pr = 2 from 4 ranks on (2 x 4 at W = 8: 192 MB per rank and layer at config 4 against
+    224 for 1 x 8 / 4 x 2 and 336 for the 1-D partition), else 1."""
+    if pr is None:
+        pr = 2 if (world >= 4 and world % 2 == 0) else 1
+    if pr < 1 or world % pr:
+        raise ValueError(f"grid rows {pr} do not divide the world size {world}")
+    return pr, world // pr
+
+
+class GridLayout:
+    """Blocks of Mb = ceil(N / W) rows; block b = r % W holds node rows r = q * W + b at local row q."""
+
+    def __init__(self, n_rows, world, pr=None):
+        self.N, self.W = int(n_rows), int(world)
+        self.Pr, self.Pc = grid_shape(self.W, pr)
+        self.Mb = (self.N + self.W - 1) // self.W
+        self.M, self.C, self.Mc = self.Mb, 1, self.Mb     # (what the inherited evaluation reads: rows per rank, one chunk)
+
+    def coords(self, b):
+        return b // self.Pc, b % self.Pc
+
+    def pos(self, r):
+        """world-gathered position (rank order): what tables() / evaluate() index an all-gather over ALL ranks with"""
+        return (r % self.W) * self.Mb + r // self.W
+
+    def col_pos(self, r):
+        """position of node r inside x[C_j] (the column group's gathered blocks, group-rank order i = 0..Pr-1)"""
+        return ((r % self.W) // self.Pc) * self.Mb + r // self.W
+
+    def row_pos(self, r):
+        """position of node r inside a partial y[R_i] (the row group's blocks, group-rank order j = 0..Pc-1)"""
+        return ((r % self.W) % self.Pc) * self.Mb + r // self.W
+
+    def full_pos(self, r):
+        """position in the replicated, grid-column-major [W * Mb, d] buffers (gprop / gego / e0_full): C_j is rows
+        [j * Pr * Mb, (j + 1) * Pr * Mb)"""
+        b = r % self.W
+        return ((b % self.Pc) * self.Pr + b // self.Pc) * self.Mb + r // self.W
+
+
+def build_tile(rowptr, col, val, rank, layout):
+    """CSR (rowptr int32[Pc*Mb + 1], col int32, val fp32) of the tile A[R_i, C_j] of `rank` = (i, j): rows in row_pos order,
+    columns relabelled to col_pos, entry order inside a row unchanged.  Vectorised on the inputs' device."""
+    rp = torch.as_tensor(rowptr).long()
+    cl = torch.as_tensor(col).long()
+    vl = torch.as_tensor(val)
+    dev = rp.device
+    L = layout
+    i, j = L.coords(rank)
+    q = torch.arange(L.Mb, device=dev)
+    rows = (q.unsqueeze(0) * L.W + (i * L.Pc + torch.arange(L.Pc, device=dev)).unsqueeze(1)).reshape(-1)   # row_pos order
+    valid = rows < L.N
+    rsafe = torch.where(valid, rows, torch.zeros_like(rows))
+    deg = torch.where(valid, rp[rsafe + 1] - rp[rsafe], torch.zeros_like(rows))
+    n_rows = rows.numel()
+    row_of = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
+    first = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
+    first[1:] = torch.cumsum(deg, 0)
+    src = rp[rsafe][row_of] + (torch.arange(int(first[-1].item()), device=dev) - first[row_of])
+    c = cl[src]
+    keep = ((c % L.W) % L.Pc) == j
+    row_k, c_k, v_k = row_of[keep], c[keep], vl[src][keep]
+    cnt = torch.bincount(row_k, minlength=n_rows)
+    out_rp = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
+    out_rp[1:] = torch.cumsum(cnt, 0)
+    return out_rp.to(torch.int32).contiguous(), L.col_pos(c_k).to(torch.int32).contiguous(), v_k.to(torch.float32).contiguous()
+
+
+class Grid2DLightGCN(ShardedLightGCN):
+    """Same interface as ShardedLightGCN (train_epoch / tables / evaluate / describe), 2-D tiled propagation."""
+
+    def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False):
+        on = dist.is_available() and dist.is_initialized()
+        self.group = None
+        self.rank = dist.get_rank() if on else 0
+        self.world = dist.get_world_size() if on else 1
+        self.ops = ops or HipOps()
+        self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(dim), int(n_layers)
+        if self.L < 1:
+            raise ValueError("Grid2DLightGCN needs n_layers >= 1")
+        if reduce not in ("collective", "ordered"):
+            raise ValueError("reduce must be 'collective' (reduce_scatter_tensor) or 'ordered' (all-to-all + sum in group-rank order)")
+        self.lam, self.lr, self.betas, self.eps = lam, lr, betas, eps
+        self.N = self.U + self.I
+        self.layout = lay = GridLayout(self.N, self.world, grid_rows)
+        self.reduce_mode = "ordered" if deterministic else reduce
+        self.deterministic = bool(deterministic)
+        self.force_collectives = False
+        self.gather_mode = "collective"
+        self.device = torch.device(device) if device is not None else user_emb.device
+        self.gi, self.gj = lay.coords(self.rank)
+        # EVERY rank creates EVERY group, in the same order (torch.distributed requires it); keep the two this rank is in
+        self.col_group = self.row_group = None
+        if on and self.world > 1:
+            for j in range(lay.Pc):
+                g_ = dist.new_group([i * lay.Pc + j for i in range(lay.Pr)])
+                if j == self.gj:
+                    self.col_group = g_
+            for i in range(lay.Pr):
+                g_ = dist.new_group([i * lay.Pc + j for j in range(lay.Pc)])
+                if i == self.gi:
+                    self.row_group = g_
+        rowptr, col, val = (csr.rowptr, csr.col, csr.val) if hasattr(csr, "rowptr") else csr
+        self.tile = self.ops.make_slab(*build_tile(rowptr, col, val, self.rank, lay), self.device)
+        dev, Mb, W, d = self.device, lay.Mb, self.world, self.d
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self.e0, self.m, self.v = z(Mb, d), z(Mb, d), z(Mb, d)
+        self.s = z(Mb, d)
+        self.ybuf = [z(Mb, d), z(Mb, d)]
+        self.xcol = z(lay.Pr * Mb, d)            # x[C_j] gathered within the column group
+        self.partial = z(lay.Pc * Mb, d)         # A[R_i, C_j] . x[C_j]
+        self.recv = z(lay.Pc * Mb, d) if self.reduce_mode == "ordered" else None
+        self.gprop, self.gego, self.e0_full = z(W * Mb, d), z(W * Mb, d), z(W * Mb, d)   # replicated, grid-column-major
+        own0 = (self.gj * lay.Pr + self.gi) * Mb
+        self.own_full = slice(own0, own0 + Mb)                                           # this rank's block inside them
+        self.col_full = slice(self.gj * lay.Pr * Mb, (self.gj + 1) * lay.Pr * Mb)        # C_j inside them
+        self.t = 0
+        self._plan = None
+        self._graph = None
+        self.capture = False
+        self.load_tables(user_emb, item_emb)
+
+    def describe(self):
+        L = self.layout
+        blk = L.Mb * self.d * 4 / 1e6
+        return (f"node rows in {self.world} round-robin blocks on a {L.Pr} x {L.Pc} grid ({L.Mb} rows/rank); per layer an all-gather within "
+                f"the column group ({L.Pr - 1} x {blk:.1f} MB received) + a local tile SpMM + a reduce-scatter ({self.reduce_mode}) within "
+                f"the row group ({L.Pc - 1} x {blk:.1f} MB received); per step {2 * self.L - 1} all-gathers, {2 * self.L} reduce-scatters, "
+                f"one [6B,d] all-reduce; BPR replicated")
+
+    # ------------------------------------------------------------------ collectives
+    def _host(self):
+        return self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "gloo"
+
+    def _all_reduce(self, t):
+        if self.world == 1:
+            return
+        if self._host():
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+
+    def _gather_full(self, local, out_full):
+        """all-gather over ALL ranks in rank order (tables / evaluation): out_full[b * Mb + q] = row q of rank b"""
+        if self.world == 1:
+            out_full.copy_(local)
+        elif self._host():
+            h = torch.empty(out_full.shape, dtype=out_full.dtype)
+            dist.all_gather_into_tensor(h, local.cpu().contiguous())
+            out_full.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out_full, local.contiguous())
+        return out_full
+
+    def _gather_col(self, x_own):
+        """x[C_j] from the column group's blocks"""
+        if self.layout.Pr == 1:
+            return x_own
+        if self._host():
+            h = torch.empty(self.xcol.shape, dtype=self.xcol.dtype)
+            dist.all_gather_into_tensor(h, x_own.cpu().contiguous(), group=self.col_group)
+            self.xcol.copy_(h)
+        else:
+            dist.all_gather_into_tensor(self.xcol, x_own, group=self.col_group)
+        return self.xcol
+
+    def _reduce_rows(self, partial, out):
+        """out = sum over the row group of the members' partial blocks destined to this rank"""
+        lay = self.layout
+        if lay.Pc == 1:
+            out.copy_(partial)
+            return out
+        if self.reduce_mode == "ordered":
+            # direct reduce-scatter with a FIXED summation order: block k of every member goes to member k, which adds the Pc
+            # blocks it receives in group-rank order (its own among them)
+            if self._host():
+                h = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+                dist.all_to_all_single(h, partial.cpu().contiguous(), group=self.row_group)
+                self.recv.copy_(h)
+            else:
+                dist.all_to_all_single(self.recv, partial, group=self.row_group)
+            r = self.recv.view(lay.Pc, lay.Mb, self.d)
+            out.copy_(r[0])
+            for k in range(1, lay.Pc):
+                out.add_(r[k])
+            return out
+        if self._host():
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.reduce_scatter_tensor(h, partial.cpu().contiguous(), group=self.row_group)
+            out.copy_(h)
+        else:
+            dist.reduce_scatter_tensor(out, partial, group=self.row_group)
+        return out
+
+    def _layer(self, x_col, out):
+        """out (own block) = (A x)[block]: tile SpMM on x[C_j] + reduce-scatter within the row group"""
+        self.ops.spmm(self.tile, x_col, y=self.partial)
+        return self._reduce_rows(self.partial, out)
+
+    # ------------------------------------------------------------------ propagation
+    def _forward(self):
+        """light rows of the owned block into self.s"""
+        L = self.L
+        inv = 1.0 / (L + 1)
+        x = self.e0
+        for l in range(1, L + 1):
+            y = self._layer(self._gather_col(x), self.ybuf[l & 1])
+            if l == 1:
+                torch.add(self.e0, y, out=self.s)
+            else:
+                self.s.add_(y)
+            x = y
+        self.s.mul_(inv)
+
+    # ------------------------------------------------------------------ training
+    def reserve(self, n_triplets, batch):
+        n_steps = (int(n_triplets) + batch - 1) // batch
+        if self._plan is None or self._plan["cap_steps"] < n_steps or self._plan["batch"] != batch:
+            self._plan = {"cap_steps": n_steps, "batch": batch,
+                          "loss": torch.zeros(n_steps, _lib.RK_LOSS_PARTIALS, device=self.device, dtype=torch.float32),
+                          "rows": torch.zeros(6 * batch, self.d, device=self.device, dtype=torch.float32)}
+        return self._plan
+
+    def _epoch_plan(self, users, pos, neg, batch):
+        lay, dev = self.layout, self.device
+        nodes = torch.stack([users.to(dev).long(), pos.to(dev).long() + self.U, neg.to(dev).long() + self.U])   # [3, n]
+        ep = {"full": lay.full_pos(nodes).contiguous(), "own": ((nodes % self.world) == self.rank).to(torch.float32),
+              "local": (nodes // self.world).contiguous()}
+        if self.deterministic:
+            n = nodes.shape[1]
+            if 3 * batch >= (1 << 20) or self.world * lay.Mb >= (1 << 24):
+                raise ValueError("deterministic scatter: batches of < 349525 triplets and fewer than 2^24 gathered rows")
+            ep["b_in"] = torch.arange(n, device=dev) % batch
+        return ep
+
+    def step(self, plan, ep, s0, nb, k):
+        ops, L = self.ops, self.L
+        lp = plan["loss"][k]
+        self.t += 1
+        sl = slice(s0, s0 + nb)
+        cat3 = lambda t: t[:, sl].reshape(-1).contiguous()          # role-major [3 * nb]
+        local3, own3, full3 = cat3(ep["local"]), cat3(ep["own"]), cat3(ep["full"])
+        self._forward()
+        rows = plan["rows"]
+        light_rows, ego_rows = rows[: 3 * nb], rows[3 * nb: 6 * nb]
+        mask = own3 if self.world > 1 else None
+        ops.gather_rows(self.s, local3, mask, light_rows)
+        ops.gather_rows(self.e0, local3, mask, ego_rows)
+        self._all_reduce(rows[: 6 * nb])
+        self.e0_full.index_copy_(0, full3, ego_rows)               # the minibatch's rows of E0 (reg term); duplicates carry equal values
+        keys = None
+        if self.deterministic:
+            kk = (full3.view(3, nb) << 20) | (3 * ep["b_in"][sl].unsqueeze(0) + torch.arange(3, device=self.device).unsqueeze(1))
+            keys = torch.sort(kk.reshape(-1)).values.contiguous()
+        ru, rp, rn = full3[:nb], full3[nb:2 * nb], full3[2 * nb:]
+        ops.bpr(self.d, L, self.lam, light_rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp, keys=keys)
+        # backward: t_1 = g + A g, ..., grad = gego + A t_{L-1}; the first layer's x[C_j] is a view of the replicated gprop
+        x_col = self.gprop[self.col_full]
+        for j in range(1, L + 1):
+            last = j == L
+            y = self._layer(x_col, self.ybuf[j & 1])
+            y.add_((self.gego if last else self.gprop)[self.own_full])
+            if last:
+                ops.adam(self.e0, y, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+            else:
+                x_col = self._gather_col(y)
+        ops.zero_rows(self.gprop, self.gego, full3)
+        return lp
+
+    def _capture_ok(self):
+        return False

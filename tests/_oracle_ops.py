@@ -36,6 +36,12 @@ class OracleOps:
             for k, arr in (("p", p), ("m", m), ("v", vv)):
                 adam[k].copy_(torch.from_numpy(arr))
 
+    def adam(self, p, g, m, v, t, lr, b1, b2, eps):
+        pn, mn, vn = (np.ascontiguousarray(a.numpy()) for a in (p, m, v))
+        orc.adam(pn, np.ascontiguousarray(g.numpy()), mn, vn, t, lr, b1, b2, eps)
+        for dst, arr in ((p, pn), (m, mn), (v, vn)):
+            dst.copy_(torch.from_numpy(arr))
+
     def gather_rows(self, src, idx, mask, out):
         rows = src[idx]
         out.copy_(rows if mask is None else rows * mask.view(-1, 1))
