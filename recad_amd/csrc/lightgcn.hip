@@ -768,13 +768,7 @@ static int launch_epilogue(const rk_lightgcn_desc &d, int apply_update, hipStrea
     return RK_OK;
 }
 
-// hipGraph of n_steps train steps.  whole: kExecChunk = the steps only; kExecWhole = a complete epoch call, prologue and
-// epilogue included; kExecHead / kExecTail = the two halves of a complete call -- prologue + its first kHeadSteps steps, the
-// remaining steps + epilogue.  The runtime writes a graph's packets before the GPU sees the first of them (measured: the
-// driver-style 20-step call, 143 kernels, spent 171 us of wall time outside its 1415 us of kernels), so a call starts with a
-// short graph and the long one is enqueued while that runs.
-enum { kExecChunk = 0, kExecWhole = 1, kExecHead = 2, kExecTail = 3 };
-static constexpr int kHeadSteps = 2, kSplitMinSteps = 8;
+// hipGraph of n_steps train steps (whole: a complete epoch call, prologue and epilogue included)
 static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update, int batch, hipStream_t upload_stream, hipGraphExec_t *out)
 {
     const rk_lightgcn_desc &d = h->d;
@@ -799,10 +793,10 @@ static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update,
     hipGraph_t g = nullptr;
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = RK_OK;
-    if (whole == kExecWhole || whole == kExecHead) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
+    if (whole) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
     for (int k = 0; k < n_steps && rc == RK_OK; ++k)
         rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, ord);
-    if ((whole == kExecWhole || whole == kExecTail) && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
+    if (whole && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
     hipError_t err = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     RK_HIP(err);
@@ -878,11 +872,7 @@ RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, int64_t n, int32_t batch, int
     if (!s) { if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)); up = h->cap_stream; } else up = s;
     const int n_steps = (int)std::min<long long>((n + batch - 1) / batch, 1LL << 30);
     hipGraphExec_t ex = nullptr;
-    if (whole_call(n_steps, graph_steps)) {
-        if (n_steps < kSplitMinSteps) return ensure_exec(h, n_steps, kExecWhole, apply_update, batch, up, &ex);
-        int rc = ensure_exec(h, kHeadSteps, kExecHead, apply_update, batch, up, &ex);
-        return rc ? rc : ensure_exec(h, n_steps - kHeadSteps, kExecTail, apply_update, batch, up, &ex);
-    }
+    if (whole_call(n_steps, graph_steps)) return ensure_exec(h, n_steps, 1, apply_update, batch, up, &ex);
     int rc = ensure_exec(h, graph_steps, 0, apply_update, batch, up, &ex);
     if (rc) return rc;
     const int rem = n_steps % graph_steps;
@@ -922,20 +912,11 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
         if (rc) return rc;
     }
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
-    if (whole_call(n_steps, graph_steps)) {   // the whole call is one replay -- or two: a short head, then the rest
-        hipGraphExec_t ex = nullptr, ex2 = nullptr;
-        if (n_steps < kSplitMinSteps) {
-            int rc = ensure_exec(h, n_steps, kExecWhole, apply_update, batch, nullptr, &ex);
-            if (rc) return rc;
-            RK_HIP(hipGraphLaunch(ex, s));
-            return RK_OK;
-        }
-        int rc = ensure_exec(h, kHeadSteps, kExecHead, apply_update, batch, nullptr, &ex);
-        if (rc) return rc;
-        rc = ensure_exec(h, n_steps - kHeadSteps, kExecTail, apply_update, batch, nullptr, &ex2);
+    if (whole_call(n_steps, graph_steps)) {   // the whole call is one replay
+        hipGraphExec_t ex = nullptr;
+        int rc = ensure_exec(h, n_steps, 1, apply_update, batch, nullptr, &ex);
         if (rc) return rc;
         RK_HIP(hipGraphLaunch(ex, s));
-        RK_HIP(hipGraphLaunch(ex2, s));
         return RK_OK;
     }
     int rc = launch_prologue(d, apply_update, s, h->deterministic != 0);
