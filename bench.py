@@ -58,9 +58,13 @@ def parse(argv=None):
     ap.add_argument("--deterministic", action="store_true",
                     help="ordered (bit-reproducible) gradient scatter instead of float atomics (fused and row-sharded paths; labelled in config)")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
-    ap.add_argument("--parallel", default=None, choices=["rows", "replicas"],
-                    help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default) or one "
-                         "independent victim replica per GPU (weak scaling, no data-path collective)")
+    ap.add_argument("--parallel", default=None, choices=["rows", "rows2d", "replicas"],
+                    help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default); rows2d: the 2-D "
+                         "(Pr x Pc) tiling -- all-gather within column groups, reduce-scatter within row groups (recad_amd/sharded2d.py); "
+                         "replicas: one independent victim replica per GPU (weak scaling, no data-path collective)")
+    ap.add_argument("--grid-rows", type=int, default=0, help="rows2d: Pr of the Pr x Pc grid (0 = 2 from 4 ranks on, else 1)")
+    ap.add_argument("--reduce", default="collective", choices=["collective", "ordered"],
+                    help="rows2d: reduce_scatter_tensor (RCCL picks the algorithm) or all-to-all + sum in group-rank order (fixed order)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the workers")
     ap.add_argument("--gather", default="collective", choices=["collective", "direct"],
                     help="rows mode: all_gather_into_tensor (RCCL picks the algorithm) or one batched group of W-1 sends / receives "
@@ -352,7 +356,7 @@ def worker(args):
     from recad_amd import _lib, dataset, model, synth
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 
-    rows_mode = (world > 1 or args.force_collectives) and args.parallel == "rows"
+    rows_mode = (world > 1 or args.force_collectives) and args.parallel in ("rows", "rows2d")
     B = args.batch
 
     # ---------------- workload: synthetic interactions of the named shape, resident on the GPU
@@ -401,10 +405,16 @@ def worker(args):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not bool(torch.equal(lo, hi)):
             raise SystemExit("bench.py: the ranks generated different graphs (synthetic workload not reproducible across ranks)")
-        sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
-                                  victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
-                                  gather=args.gather, force_collectives=args.force_collectives,
-                                  deterministic=bool(args.deterministic))
+        if args.parallel == "rows2d":
+            from recad_amd.sharded2d import Grid2DLightGCN
+            sharded = Grid2DLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g, victim.embedding_user.weight,
+                                     victim.embedding_item.weight, device=dev, grid_rows=args.grid_rows or None, reduce=args.reduce,
+                                     deterministic=bool(args.deterministic))
+        else:
+            sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
+                                      victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
+                                      gather=args.gather, force_collectives=args.force_collectives,
+                                      deterministic=bool(args.deterministic))
         sharded.reserve(max(args.steps, args.warmup) * B, B)
     else:
         victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
@@ -446,7 +456,7 @@ def worker(args):
     work_ranks = 1 if sharded is not None else world  # rows: all ranks work on ONE training job
 
     # ---------------- rows mode: like-for-like single-GPU reference on rank 0 (others wait), then evaluation
-    same_1gpu = None
+    same_1gpu = replicas_same = None
     sharded_eval = None
     if sharded is not None:
         if not args.no_topk:
@@ -464,6 +474,22 @@ def worker(args):
             same_1gpu = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
                          "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait"}
         barrier()
+        # the SAME workload as N independent replicas (one retrain job per GPU, no data-path collective): what the node delivers
+        # when the perturb-retrain loop is parallelised over jobs instead of inside one -- the comparison north_star's 6x on the
+        # yelp shape has to be read against (the rows modes are communication-bound there: DESIGN 6)
+        if world > 1:
+            if rank != 0:
+                victim.reserve(max(args.steps, args.warmup) * B, B)
+            sr = min(args.steps, 10)
+            victim._run_epoch(users[: 3 * B], pos[: 3 * B], neg[: 3 * B], B)
+            barrier()
+            t1 = time.perf_counter()
+            victim._run_epoch(users[: sr * B], pos[: sr * B], neg[: sr * B], B)
+            barrier()
+            tr_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            replicas_same = {"value": world * sr * B / float(tr_.item()), "unit": "interactions/s", "ms_per_step": float(tr_.item()) / sr * 1e3,
+                             "steps": sr, "note": f"{world} independent victims (one per GPU, fused single-GPU path) on this workload, all at once"}
 
     # ---------------- secondary: one whole train_step() epoch, the build's device sampler included
     epoch_obj = None
@@ -613,6 +639,21 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         cpu_aten = cpu_baseline_aten(d, args.graph, args.dim, args.layers, B, host_triplets)
 
+    comm_model = None
+    if sharded is not None and rank == 0:
+        # the arithmetic the rows modes live under: bytes a rank must RECEIVE per propagation layer over its xGMI links
+        # (7 links x ~77 GB/s one direction on MI355X) against the local SpMM time a layer needs
+        blk = (N + world - 1) // world * args.dim * 4
+        if args.parallel == "rows2d":
+            pr_, pc_ = sharded.layout.Pr, sharded.layout.Pc
+            recv = (pr_ - 1 + pc_ - 1) * blk
+        else:
+            recv = (world - 1) * blk
+        comm_model = {"bytes_received_per_rank_and_layer": recv, "xgmi_in_GBps_assumed": 7 * 76.5,
+                      "receive_floor_us_per_layer": recv / (7 * 76.5e3) if world > 1 else 0.0,
+                      "layers_with_exchange_per_step": 2 * args.layers - 1,
+                      "note": "a layer cannot finish before its inputs have arrived: when receive_floor_us_per_layer exceeds the local SpMM "
+                              "time (same_workload_1gpu's step / (2 L) / N), the mode is communication-bound at this N"}
     if rank == 0:
         if sharded is not None:
             par = sharded.describe()
@@ -635,7 +676,8 @@ def worker(args):
                        "backend": args.backend if (world > 1 or sharded is not None) else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
-            "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu, "last_step_loss": last_loss,
+            "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu,
+            "same_workload_replicas": replicas_same, "rows_comm_model": comm_model, "last_step_loss": last_loss,
         }
         if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
             same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]

@@ -72,6 +72,30 @@ for W in (1, 2, 4, 8):
           f"  ({nnz_local} nnz, {lay.M} rows, {len(slabs)} chunk(s)); all-gather receives {(W - 1) * lay.M * dim * 4 / 1e6:.1f} MB per layer", flush=True)
     del slabs, x, ys
     torch.cuda.empty_cache()
+# the 2-D tiling (recad_amd/sharded2d.py): rank 0's tile A[R_0, C_0] over x[C_0] (Pr * Mb rows), partial of Pc * Mb rows
+from recad_amd.sharded2d import GridLayout, build_tile  # noqa: E402
+out["grid2d_per_layer_ms"] = {}
+for W, pr in ((4, 2), (8, 2), (8, 4), (8, 1)):
+    lay = GridLayout(N, W, pr)
+    tile = ops.make_slab(*build_tile(g.rowptr, g.col, g.val, 0, lay), dev)
+    x = torch.randn(lay.Pr * lay.Mb, dim, device=dev) * 0.1
+    y = torch.empty(lay.Pc * lay.Mb, dim, device=dev)
+    ops.spmm(tile, x, y=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.spmm(tile, x, y=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    blk = lay.Mb * dim * 4
+    out["grid2d_per_layer_ms"][f"{W}:{lay.Pr}x{lay.Pc}"] = {"ms": ms, "tile_nnz": int(tile["col"].numel()), "x_rows": lay.Pr * lay.Mb, "partial_rows": lay.Pc * lay.Mb,
+                                                          "bytes_received_per_rank": (lay.Pr - 1 + lay.Pc - 1) * blk}
+    print(f"W={W} grid {lay.Pr} x {lay.Pc}: rank-0 tile SpMM per layer {ms:.3f} ms ({int(tile['col'].numel())} nnz, x {lay.Pr * lay.Mb} rows, partial {lay.Pc * lay.Mb} rows); "
+          f"receives {(lay.Pr - 1 + lay.Pc - 1) * blk / 1e6:.1f} MB per layer (all-gather {(lay.Pr - 1) * blk / 1e6:.1f} + reduce-scatter {(lay.Pc - 1) * blk / 1e6:.1f})", flush=True)
+    del tile, x, y
+    torch.cuda.empty_cache()
 base = out["per_layer_ms"]["1"]["ms"]
 for W, v in out["per_layer_ms"].items():
     v["compute_speedup"] = base / v["ms"]

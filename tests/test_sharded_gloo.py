@@ -26,19 +26,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, out_path, chunks, gather):
+def _worker(rank, world, port, name, out_path, chunks, gather, grid=None):
+    """grid: None = the 1-D row partition (ShardedLightGCN); (grid rows, reduce mode) = the 2-D tiling (Grid2DLightGCN)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recad_amd.sharded import ShardedLightGCN
+    from recad_amd.sharded2d import Grid2DLightGCN
     from tests._oracle_ops import OracleOps
     g = G.load(name)
     U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u0, i0 = G.lightgcn_init(g)
-    tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"),
-                         chunks=chunks, gather=gather)
-    assert tr.layout.C == chunks
+    if grid is None:
+        tr = ShardedLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"),
+                             chunks=chunks, gather=gather)
+        assert tr.layout.C == chunks
+    else:
+        tr = Grid2DLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"),
+                            grid_rows=grid[0], reduce=grid[1])
+        assert tr.layout.Pr * tr.layout.Pc == world and (grid[0] is None or tr.layout.Pr == grid[0])
     losses = []
     for s in range(min(4, len(g["batch_len"]))):
         n = int(g["batch_len"][s])
@@ -58,16 +65,22 @@ def _worker(rank, world, port, name, out_path, chunks, gather):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,gather", [(1, 1, "collective"), (2, 1, "collective"), (2, 3, "collective"),
-                                                 (3, 2, "collective"), (3, 2, "direct"), (2, 4, "direct")])
-def test_sharded_matches_oracle(tmp_path, world, chunks, gather):
+# world 8 = the target machine's only world size: the 1-D partition (collective and one-shot gathers) and the 2-D tiling on its
+# 2 x 4 default grid, 4 x 2, and the degenerate 1 x W / W x 1 grids; N % W != 0 throughout
+@pytest.mark.parametrize("world,chunks,gather,grid", [
+    (1, 1, "collective", None), (2, 1, "collective", None), (2, 3, "collective", None), (3, 2, "collective", None), (3, 2, "direct", None),
+    (2, 4, "direct", None), (8, 2, "collective", None), (8, 1, "direct", None),
+    (1, 1, "collective", (None, "collective")), (2, 1, "collective", (1, "collective")), (2, 1, "collective", (2, "ordered")),
+    (4, 1, "collective", (None, "collective")), (6, 1, "collective", (3, "ordered")),
+    (8, 1, "collective", (None, "collective")), (8, 1, "collective", (None, "ordered")), (8, 1, "collective", (4, "collective"))])
+def test_sharded_matches_oracle(tmp_path, world, chunks, gather, grid):
     name = "lightgcn_game_d64_tg"
     out = str(tmp_path / f"w{world}.npz")
-    mp.spawn(_worker, args=(world, _free_port(), name, out, chunks, gather), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, out, chunks, gather, grid), nprocs=world, join=True)
     res = np.load(out)
     g = G.load(name)
     U, I, L = int(g["n_users"]), int(g["n_items"]), int(g["layers"])
-    assert (U + I) % world != 0 or world == 1   # the ragged case (N % W != 0) is the one exercised
+    assert (U + I) % world != 0 or world in (1, 4)   # the ragged case (N % W != 0) is the one exercised
     csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
     u, i = G.lightgcn_init(g)
     st = orc.AdamState(u.shape, i.shape)
@@ -143,3 +156,43 @@ def test_bench_self_launch_dry_run():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env2)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_grid_tiles_cover_graph():
+    """Grid2D layout: every stored entry of A lands in exactly one rank's tile, at the row / column positions the layer's
+    all-gather (column group) and reduce-scatter (row group) use; the replicated buffers' column parts are contiguous."""
+    from recad_amd.sharded2d import GridLayout, build_tile
+    rng = np.random.default_rng(1)
+    n = 103
+    deg = rng.integers(0, 9, n)
+    rowptr = np.zeros(n + 1, dtype=np.int32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n, rowptr[-1]).astype(np.int32)
+    val = rng.random(rowptr[-1]).astype(np.float32)
+    dense = np.zeros((n, n), dtype=np.float64)
+    np.add.at(dense, (np.repeat(np.arange(n), deg), col), val)
+    for W, pr in ((1, None), (2, 1), (2, 2), (4, None), (8, None), (8, 4), (6, 3)):
+        lay = GridLayout(n, W, pr)
+        nodes = np.arange(n, dtype=np.int64)
+        assert len(set(lay.full_pos(nodes).tolist())) == n and len(set(lay.pos(nodes).tolist())) == n
+        rebuilt = np.zeros_like(dense)
+        for rank in range(W):
+            i, j = lay.coords(rank)
+            rp, cc, vv = (t.numpy() for t in build_tile(rowptr, col, val, rank, lay))
+            assert len(rp) == lay.Pc * lay.Mb + 1
+            rows_i = [r for r in range(n) if (r % W) // lay.Pc == i]
+            cols_j = [c for c in range(n) if (c % W) % lay.Pc == j]
+            inv_row = {int(lay.row_pos(np.int64(r))): r for r in rows_i}
+            inv_col = {int(lay.col_pos(np.int64(c))): c for c in cols_j}
+            assert len(inv_row) == len(rows_i) and len(inv_col) == len(cols_j)
+            fp = lay.full_pos(np.asarray(cols_j, dtype=np.int64)) if cols_j else np.zeros(0, dtype=np.int64)
+            assert all(j * lay.Pr * lay.Mb <= p < (j + 1) * lay.Pr * lay.Mb for p in fp)          # C_j is one contiguous run
+            assert all(int(lay.full_pos(np.int64(c))) - j * lay.Pr * lay.Mb == int(lay.col_pos(np.int64(c))) for c in cols_j)
+            for k in range(lay.Pc * lay.Mb):
+                a, b = rp[k], rp[k + 1]
+                if k not in inv_row:
+                    assert a == b
+                    continue
+                r = inv_row[k]
+                for e in range(a, b):
+                    rebuilt[r, inv_col[int(cc[e])]] += vv[e]
+        assert np.allclose(rebuilt, dense, rtol=0, atol=1e-12)
