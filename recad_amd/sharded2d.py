@@ -16,9 +16,11 @@ One propagation layer  y = A x :
     reduce-scatter of the partials within the ROW group (the Pc ranks (i, .)): sum over j, rank (i, j) keeps block (i, j)
                                                                                                       -- receives (Pc-1) blocks
 => (Pr - 1 + Pc - 1) blocks of (N/W)*d*4 bytes received per rank and layer: 2 x 4 at config 4 = 4 x 48 MB = 192 MB instead of 336,
-and the tile's gathers touch a column part of N/Pc rows (96 MB) instead of the whole table.  The price: a second collective on
-every layer's critical path, and a summation order that depends on the grid (`reduce="ordered"` fixes it: an all-to-all of the
-partial blocks and a sum in group-rank order -- same bytes as a direct reduce-scatter).
+and the tile's gathers touch a column part of N/Pc rows instead of the whole table.  The price: a second collective on every
+layer's critical path (none for Pr = 1, the default: see grid_shape), and a summation order that depends on the grid
+(`reduce="ordered"` fixes it: an all-to-all of the partial blocks and a sum in group-rank order -- same bytes as a direct
+reduce-scatter).  The blocks' rows are cut into C chunks; the reduce-scatter of chunk c is issued asynchronously and runs under
+the tile SpMM of chunk c+1 (producer-side overlap), so a layer exposes about 1/C of its communication.
 
 BPR runs replicated like in the 1-D trainer (B is tiny next to the graph): the minibatch's light rows AND ego rows travel in ONE
 [6B, d] all-reduce (every rank contributes the rows it owns, exact zeros elsewhere), the gradient rows are scattered into
@@ -35,10 +37,15 @@ from .sharded import HipOps, ShardedLightGCN
 
 
 def grid_shape(world, pr=None):
-    """(Pr, Pc) with Pr * Pc == world: Pr = 2 from 4 ranks on (2 x 4 at W = 8: 192 MB per rank and layer at config 4 against
-    224 for 1 x 8 / 4 x 2 and 336 for the 1-D partition), else 1."""
+    """(Pr, Pc) with Pr * Pc == world.  Default Pr = 1: COLUMN slabs -- rank j holds A[:, C_j] with C_j = its own block, so a
+    layer needs no all-gather at all (x[C_j] is local), its gathers touch N/W rows (48 MB at config 4: cache-resident) and
+    the one collective is a reduce-scatter whose W-1 blocks arrive over W-1 different xGMI links at once.  On the fully
+    connected mesh that beats the 2 x 4 grid in TIME although 2 x 4 receives fewer BYTES (192 vs 336 MB per layer at config
+    4): every block is N/W rows whatever the grid, a collective with k peers uses k links, and 2 x 4 puts TWO collectives
+    (1 link, then 3 links) on every layer's critical path -- measured tile SpMM 0.764 ms (1 x 8) / 0.745 (2 x 4) / 1.09 (the
+    1-D row partition) per layer at config 4 (profiles/r04_shard_probe_config4.txt), each collective >= 0.63 ms."""
     if pr is None:
-        pr = 2 if (world >= 4 and world % 2 == 0) else 1
+        pr = 1
     if pr < 1 or world % pr:
         raise ValueError(f"grid rows {pr} do not divide the world size {world}")
     return pr, world // pr
@@ -47,11 +54,14 @@ def grid_shape(world, pr=None):
 class GridLayout:
     """Blocks of Mb = ceil(N / W) rows; block b = r % W holds node rows r = q * W + b at local row q."""
 
-    def __init__(self, n_rows, world, pr=None):
+    def __init__(self, n_rows, world, pr=None, chunks=1):
         self.N, self.W = int(n_rows), int(world)
         self.Pr, self.Pc = grid_shape(self.W, pr)
-        self.Mb = (self.N + self.W - 1) // self.W
-        self.M, self.C, self.Mc = self.Mb, 1, self.Mb     # (what the inherited evaluation reads: rows per rank, one chunk)
+        per = (self.N + self.W - 1) // self.W
+        self.C = max(1, min(int(chunks), per))            # row chunks of a block: the reduce-scatter of chunk c runs under the SpMM of c+1
+        self.Mc = (per + self.C - 1) // self.C
+        self.Mb = self.Mc * self.C                        # rows per block, padded
+        self.M = self.Mb                                  # (what the inherited evaluation reads: rows per rank)
 
     def coords(self, b):
         return b // self.Pc, b % self.Pc
@@ -65,8 +75,10 @@ class GridLayout:
         return ((r % self.W) // self.Pc) * self.Mb + r // self.W
 
     def row_pos(self, r):
-        """position of node r inside a partial y[R_i] (the row group's blocks, group-rank order j = 0..Pc-1)"""
-        return ((r % self.W) % self.Pc) * self.Mb + r // self.W
+        """position of node r inside a partial y[R_i]: chunk-major -- chunk c of every block of the row group (group-rank order
+        j = 0..Pc-1) is ONE contiguous run, what a reduce-scatter of that chunk takes"""
+        q = r // self.W
+        return (q // self.Mc) * (self.Pc * self.Mc) + ((r % self.W) % self.Pc) * self.Mc + q % self.Mc
 
     def full_pos(self, r):
         """position in the replicated, grid-column-major [W * Mb, d] buffers (gprop / gego / e0_full): C_j is rows
@@ -84,8 +96,9 @@ def build_tile(rowptr, col, val, rank, layout):
     dev = rp.device
     L = layout
     i, j = L.coords(rank)
-    q = torch.arange(L.Mb, device=dev)
-    rows = (q.unsqueeze(0) * L.W + (i * L.Pc + torch.arange(L.Pc, device=dev)).unsqueeze(1)).reshape(-1)   # row_pos order
+    # row_pos order: [chunk c][block j'][row o of the chunk]  ->  node id (c * Mc + o) * W + (i * Pc + j')
+    qq = (torch.arange(L.C, device=dev).view(-1, 1, 1) * L.Mc + torch.arange(L.Mc, device=dev).view(1, 1, -1))
+    rows = (qq * L.W + (i * L.Pc + torch.arange(L.Pc, device=dev)).view(1, -1, 1)).reshape(-1)
     valid = rows < L.N
     rsafe = torch.where(valid, rows, torch.zeros_like(rows))
     deg = torch.where(valid, rp[rsafe + 1] - rp[rsafe], torch.zeros_like(rows))
@@ -107,7 +120,7 @@ class Grid2DLightGCN(ShardedLightGCN):
     """Same interface as ShardedLightGCN (train_epoch / tables / evaluate / describe), 2-D tiled propagation."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False):
+                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None):
         on = dist.is_available() and dist.is_initialized()
         self.group = None
         self.rank = dist.get_rank() if on else 0
@@ -120,7 +133,11 @@ class Grid2DLightGCN(ShardedLightGCN):
             raise ValueError("reduce must be 'collective' (reduce_scatter_tensor) or 'ordered' (all-to-all + sum in group-rank order)")
         self.lam, self.lr, self.betas, self.eps = lam, lr, betas, eps
         self.N = self.U + self.I
-        self.layout = lay = GridLayout(self.N, self.world, grid_rows)
+        if chunks is None:
+            # (like the 1-D trainer: overlap only pays when there is a collective to hide and the blocks are big)
+            per_rank = self.N // self.world
+            chunks = 4 if (self.world > 1 and per_rank >= (1 << 17)) else 2 if (self.world > 1 and per_rank >= 4096) else 1
+        self.layout = lay = GridLayout(self.N, self.world, grid_rows, chunks)
         self.reduce_mode = "ordered" if deterministic else reduce
         self.deterministic = bool(deterministic)
         self.force_collectives = False
@@ -139,7 +156,12 @@ class Grid2DLightGCN(ShardedLightGCN):
                 if i == self.gi:
                     self.row_group = g_
         rowptr, col, val = (csr.rowptr, csr.col, csr.val) if hasattr(csr, "rowptr") else csr
-        self.tile = self.ops.make_slab(*build_tile(rowptr, col, val, self.rank, lay), self.device)
+        trp, tcl, tvl = build_tile(rowptr, col, val, self.rank, lay)
+        self.tiles = []                          # one slab per row chunk: rows [c * Pc * Mc, (c + 1) * Pc * Mc) of the tile
+        for c in range(lay.C):
+            r0, r1 = c * lay.Pc * lay.Mc, (c + 1) * lay.Pc * lay.Mc
+            a, b = int(trp[r0].item()), int(trp[r1].item())
+            self.tiles.append(self.ops.make_slab((trp[r0:r1 + 1] - a).contiguous(), tcl[a:b].contiguous(), tvl[a:b].contiguous(), self.device))
         dev, Mb, W, d = self.device, lay.Mb, self.world, self.d
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.e0, self.m, self.v = z(Mb, d), z(Mb, d), z(Mb, d)
@@ -161,7 +183,7 @@ class Grid2DLightGCN(ShardedLightGCN):
     def describe(self):
         L = self.layout
         blk = L.Mb * self.d * 4 / 1e6
-        return (f"node rows in {self.world} round-robin blocks on a {L.Pr} x {L.Pc} grid ({L.Mb} rows/rank); per layer an all-gather within "
+        return (f"node rows in {self.world} round-robin blocks on a {L.Pr} x {L.Pc} grid ({L.Mb} rows/rank in {L.C} chunk(s)); per layer an all-gather within "
                 f"the column group ({L.Pr - 1} x {blk:.1f} MB received) + a local tile SpMM + a reduce-scatter ({self.reduce_mode}) within "
                 f"the row group ({L.Pc - 1} x {blk:.1f} MB received); per step {2 * self.L - 1} all-gathers, {2 * self.L} reduce-scatters, "
                 f"one [6B,d] all-reduce; BPR replicated")
@@ -204,38 +226,51 @@ class Grid2DLightGCN(ShardedLightGCN):
             dist.all_gather_into_tensor(self.xcol, x_own, group=self.col_group)
         return self.xcol
 
-    def _reduce_rows(self, partial, out):
-        """out = sum over the row group of the members' partial blocks destined to this rank"""
+    def _reduce_rows(self, partial, out, async_op=False):
+        """out = sum over the row group of the members' partial blocks destined to this rank (partial: [Pc * rows, d], out:
+        [rows, d]).  async_op (RCCL / gloo collective form only): returns the work handle instead of waiting."""
         lay = self.layout
         if lay.Pc == 1:
             out.copy_(partial)
-            return out
+            return None
         if self.reduce_mode == "ordered":
             # direct reduce-scatter with a FIXED summation order: block k of every member goes to member k, which adds the Pc
             # blocks it receives in group-rank order (its own among them)
+            recv = self.recv[: partial.shape[0]]
             if self._host():
-                h = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+                h = torch.empty(recv.shape, dtype=recv.dtype)
                 dist.all_to_all_single(h, partial.cpu().contiguous(), group=self.row_group)
-                self.recv.copy_(h)
+                recv.copy_(h)
             else:
-                dist.all_to_all_single(self.recv, partial, group=self.row_group)
-            r = self.recv.view(lay.Pc, lay.Mb, self.d)
+                dist.all_to_all_single(recv, partial, group=self.row_group)
+            r = recv.view(lay.Pc, out.shape[0], self.d)
             out.copy_(r[0])
             for k in range(1, lay.Pc):
                 out.add_(r[k])
-            return out
+            return None
         if self._host():
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.reduce_scatter_tensor(h, partial.cpu().contiguous(), group=self.row_group)
             out.copy_(h)
-        else:
+            return None
+        return dist.reduce_scatter_tensor(out, partial, group=self.row_group, async_op=async_op) if async_op else \
             dist.reduce_scatter_tensor(out, partial, group=self.row_group)
-        return out
 
     def _layer(self, x_col, out):
-        """out (own block) = (A x)[block]: tile SpMM on x[C_j] + reduce-scatter within the row group"""
-        self.ops.spmm(self.tile, x_col, y=self.partial)
-        return self._reduce_rows(self.partial, out)
+        """out (own block) = (A x)[block]: per row chunk a tile SpMM on x[C_j], then that chunk's reduce-scatter within the row
+        group -- issued asynchronously (it runs on the collective's stream behind the SpMM that produced the chunk) while the
+        next chunk's SpMM runs; the layer returns when every chunk has landed."""
+        lay = self.layout
+        pending = []
+        for c in range(lay.C):
+            part = self.partial[c * lay.Pc * lay.Mc:(c + 1) * lay.Pc * lay.Mc]
+            self.ops.spmm(self.tiles[c], x_col, y=part)
+            w = self._reduce_rows(part, out[c * lay.Mc:(c + 1) * lay.Mc], async_op=lay.C > 1)
+            if w is not None:
+                pending.append(w)
+        for w in pending:
+            w.wait()      # nccl: the launch stream waits for the collective's stream; gloo: host wait
+        return out
 
     # ------------------------------------------------------------------ propagation
     def _forward(self):

@@ -44,8 +44,8 @@ def _worker(rank, world, port, name, out_path, chunks, gather, grid=None):
         assert tr.layout.C == chunks
     else:
         tr = Grid2DLightGCN(U, I, d, L, csr, torch.from_numpy(u0), torch.from_numpy(i0), ops=OracleOps(), device=torch.device("cpu"),
-                            grid_rows=grid[0], reduce=grid[1])
-        assert tr.layout.Pr * tr.layout.Pc == world and (grid[0] is None or tr.layout.Pr == grid[0])
+                            grid_rows=grid[0], reduce=grid[1], chunks=chunks)
+        assert tr.layout.Pr * tr.layout.Pc == world and (grid[0] is None or tr.layout.Pr == grid[0]) and tr.layout.C == chunks
     losses = []
     for s in range(min(4, len(g["batch_len"]))):
         n = int(g["batch_len"][s])
@@ -72,7 +72,8 @@ def _worker(rank, world, port, name, out_path, chunks, gather, grid=None):
     (2, 4, "direct", None), (8, 2, "collective", None), (8, 1, "direct", None),
     (1, 1, "collective", (None, "collective")), (2, 1, "collective", (1, "collective")), (2, 1, "collective", (2, "ordered")),
     (4, 1, "collective", (None, "collective")), (6, 1, "collective", (3, "ordered")),
-    (8, 1, "collective", (None, "collective")), (8, 1, "collective", (None, "ordered")), (8, 1, "collective", (4, "collective"))])
+    (8, 1, "collective", (None, "collective")), (8, 1, "collective", (2, "ordered")), (8, 1, "collective", (4, "collective")),
+    (8, 3, "collective", (2, "collective")), (8, 2, "collective", (1, "ordered")), (3, 2, "collective", (None, "collective"))])
 def test_sharded_matches_oracle(tmp_path, world, chunks, gather, grid):
     name = "lightgcn_game_d64_tg"
     out = str(tmp_path / f"w{world}.npz")
@@ -170,8 +171,8 @@ def test_grid_tiles_cover_graph():
     val = rng.random(rowptr[-1]).astype(np.float32)
     dense = np.zeros((n, n), dtype=np.float64)
     np.add.at(dense, (np.repeat(np.arange(n), deg), col), val)
-    for W, pr in ((1, None), (2, 1), (2, 2), (4, None), (8, None), (8, 4), (6, 3)):
-        lay = GridLayout(n, W, pr)
+    for W, pr, Cc in ((1, None, 1), (2, 1, 2), (2, 2, 1), (4, None, 3), (8, 2, 2), (8, 4, 1), (6, 3, 4), (8, 1, 3)):
+        lay = GridLayout(n, W, pr, Cc)
         nodes = np.arange(n, dtype=np.int64)
         assert len(set(lay.full_pos(nodes).tolist())) == n and len(set(lay.pos(nodes).tolist())) == n
         rebuilt = np.zeros_like(dense)
