@@ -316,20 +316,38 @@ int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v,
  * in); items in the user's seen list (CSR seen_ptr/seen_idx indexed by user_ids[b], ids sorted ascending)
  * are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K] sorted by (score desc, item id
  * asc), padded with -1/-inf; for each target t its score and rank among the unseen items (hit@k <=> rank < k).
- * Three paths, identical results: (1) GEMM into a [nb, n_items] matrix in `scratch` + a selection pass (catalogues of
- * < 16 384 items, small user blocks, or requests the other two do not take); (2) the register-resident PANEL form, recad_amd/csrc/score_panel.h:
- * a workgroup holds the scores of 16 / 32 users x 1920 items in its registers, selects from there and never writes a score
- * (K <= 256, n_targets <= 4, dim <= 256; scratch = a k-permuted copy of the item table, n_items * 16 * ceil(dim / 16) floats;
- * the default from 16 384 items on for blocks of >= 8192 users, >= 4096 at dim <= 64: it parallelises over the users only);
- * (3) the older fused sweep, recad_amd/csrc/score_select.h (K <= 256, n_targets <= 4,
- * dim <= 128; 1025 floats of scratch per user; RK_SEL_FORCE=1).  scratch: device float[rk_score_topk_scratch_floats(...)]
- * for the SAME nb, 16-byte aligned. */
-int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets);
+ * Two paths, identical results (ids, scores, target scores and ranks bit for bit):
+ *   RK_SCORE_GEMM  -- GEMM into a [nb, n_items] matrix in `scratch` + a selection pass: small user blocks, catalogues of < 16 384
+ *                     items, and everything the panel form does not take;
+ *   RK_SCORE_PANEL -- the register-resident panel form, recad_amd/csrc/score_panel.h: a workgroup holds the scores of 16 / 32
+ *                     users x 1920 items in its registers, selects from there and never writes a score (K <= 256, n_targets <= 4,
+ *                     dim <= 256; scratch = a k-permuted copy of the item table, n_items * 16 * ceil(dim / 16) floats).  It
+ *                     parallelises over the users only, so it is the default from 16 384 items on for blocks of >= 8192 users
+ *                     (>= 4096 at dim <= 64).
+ * The path is an ARGUMENT, not process state (ABI 8): rk_score_topk_plan() fills a plan for one (nb, n_items, dim, K, n_targets) --
+ * the library's choice when request is NULL / request->path == RK_SCORE_AUTO, the requested path and shape knobs otherwise
+ * (RK_EINVAL if that path does not support the request) -- with the scratch it needs, and rk_score_topk() runs exactly that plan:
+ * sizing and launch cannot disagree.  (Round 2's fused sweep, score_select.h, is gone: measured slower than both paths on every
+ * shape, its last default corner included -- profiles/r04_score_corner.txt.) */
+#define RK_SCORE_AUTO 0
+#define RK_SCORE_GEMM 1
+#define RK_SCORE_PANEL 2
+typedef struct rk_score_plan {
+    int32_t path;             /* RK_SCORE_GEMM / RK_SCORE_PANEL (RK_SCORE_AUTO only in a request) */
+    int32_t panel_rows;       /* PANEL: 16 or 32 user rows per workgroup (request: 0 = by shape) */
+    int32_t panel_ntw;        /* PANEL: 16-item tiles per wave and panel: 8 (1024-item panels) or 15 (1920) (request: 0 = by catalogue size) */
+    int32_t panel_safe;       /* PANEL: 1 = every panel through the exact safe form (tests) */
+    int32_t nb, n_items, dim, K, n_targets;   /* what the plan was made for: rk_score_topk refuses anything else */
+    int32_t reserved[3];
+    int64_t scratch_floats;   /* device float[scratch_floats], 16-byte aligned */
+} rk_score_plan;
+int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets, const rk_score_plan *request /*nullable*/,
+                       rk_score_plan *out);
 int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
                   int32_t n_items, const float *ubias, const float *ibias, float mean,
                   const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
                   float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
-                  int32_t *target_rank, float *scratch, void *stream);
+                  int32_t *target_rank, const rk_score_plan *plan, float *scratch, void *stream);
 
 /* ---------------------------------------------------------------- MF --------------- */
 /* One epoch of MF.train_step, recad/model/victim/mf.py:49-69: logits (mf.py:40-47),

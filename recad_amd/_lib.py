@@ -71,6 +71,19 @@ class LightGCNDesc(C.Structure):
     ]
 
 
+class ScorePlan(C.Structure):
+    """rk_score_plan (include/recad_hip.h): the scoring path and its shape knobs as an ARGUMENT of rk_score_topk"""
+
+    _fields_ = [
+        ("path", C.c_int32), ("panel_rows", C.c_int32), ("panel_ntw", C.c_int32), ("panel_safe", C.c_int32),
+        ("nb", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("K", C.c_int32), ("n_targets", C.c_int32),
+        ("reserved", C.c_int32 * 3), ("scratch_floats", C.c_int64),
+    ]
+
+
+RK_SCORE_AUTO, RK_SCORE_GEMM, RK_SCORE_PANEL = 0, 1, 2
+
+
 class SpmmEpilogue(C.Structure):
     """rk_spmm_epilogue (include/recad_hip.h)."""
 
@@ -141,8 +154,8 @@ _SIGNATURES = {
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _F, C.c_uint64, _P],
     "rk_score_matrix": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _F, C.c_uint64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
-    "rk_score_topk_scratch_floats": [_I32, _I32, _I32, _I32, _I32],
-    "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rk_score_topk_plan": [_I32, _I32, _I32, _I32, _I32, C.POINTER(ScorePlan), C.POINTER(ScorePlan)],
+    "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, C.POINTER(ScorePlan), _P, _P],
     "rk_bpr_sample": [_I32, _I32, _P, _P, _I64, C.c_uint64, _P, _P, _P, _P, _P],
     "rk_pointwise_sample": [_I32, _I32, _P, _P, _I64, _I32, C.c_uint64, _P, _P, _P, _P],
     "rk_topk_rows": [_P, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P],
@@ -155,7 +168,7 @@ _SIGNATURES = {
     "rk_mf_train_epoch": [_I32, _I32, _I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F,
                           _F, _P, _I32, _F, C.c_uint64, _P],
 }
-_RESTYPES = {"rk_last_error": C.c_char_p, "rk_score_topk_scratch_floats": C.c_int64}
+_RESTYPES = {"rk_last_error": C.c_char_p}
 EXPORTS = tuple(_SIGNATURES)
 
 

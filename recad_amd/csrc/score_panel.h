@@ -28,14 +28,75 @@
 #pragma once
 #include <float.h>
 
-#include "score_select.h"
+#include <algorithm>
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float sel_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned score_key(float s)
+{
+    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf).  -0.0 is
+    // folded onto +0.0 so that key equality is float equality (the oracle compares floats).
+    if (s == -INFINITY) return 0u;
+    unsigned u = __float_as_uint(s);
+    if (u == 0x80000000u) u = 0u;
+    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return k == 0u ? 1u : k;
+}
+
+__device__ __forceinline__ float key_score(unsigned k)
+{
+    // inverse of score_key for every finite score and +inf (-0.0 comes back as +0.0)
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// Threshold search over the (distinct) composites held 8 per lane (unused slots 0), n_valid >= K.  Bit-wise binary
+// search from the top: T grows while at least K composites stay >= T.  After `min_bits` bits it stops as soon as at
+// most `limit` composites are >= T (a COARSE threshold: cheap, and any T with count >= K is a valid pruning bound);
+// with limit == K it runs to the exact K-th composite (early exit once the count is exactly K).  Key bits are
+// searched on the high words alone (32-bit compares); the id bits above id_bits are ones in every entry.
+// Returns T; *cnt_out = #(composite >= T).
+__device__ __forceinline__ unsigned long long wave_threshold(const unsigned long long (&c)[8], int n, int K, int limit, int min_bits,
+                                                             int id_bits, int *cnt_out)
+{
+    unsigned hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hi[j] = (unsigned)(c[j] >> 32);
+    unsigned Tk = 0u;
+    int cntT = n, done_bits = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        if (done_bits >= min_bits && cntT <= limit) { *cnt_out = cntT; return (unsigned long long)Tk << 32; }
+        const unsigned trial = Tk | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(hi[j] >= trial));
+        if (cnt >= K) { Tk = trial; cntT = cnt; }
+        ++done_bits;
+    }
+    unsigned long long T = (unsigned long long)Tk << 32;
+    if (cntT <= limit) { *cnt_out = cntT; return T; }
+    // more than `limit` entries share the K-th key: resolve the tie on the (inverted) item ids
+    if (id_bits < 32) T |= (0xffffffffULL >> id_bits) << id_bits;
+    for (int bit = (id_bits < 32 ? id_bits : 32) - 1; bit >= 0; --bit) {
+        const unsigned long long trial = T | (1ULL << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(c[j] >= trial));
+        if (cnt >= K) { T = trial; cntT = cnt; }
+        if (cntT <= limit) break;
+    }
+    *cnt_out = cntT;
+    return T;
+}
 
 static constexpr int kPanMaxRows = 32;       // user rows per workgroup: 16 or 32
 static constexpr int kPanWaves = 8;
 static constexpr int kPanNT = kPanWaves * 64;
 static constexpr int kPanCap = 384;          // candidate slots per row: K (<= 256) + one safe round (128)
 static constexpr int kPanMaxT = 4;
-static constexpr int kPanDefaultMinItems = 16384;   // rk_score_topk takes this form by default from this catalogue size on (RK_PAN_FORCE=1: always)
+static constexpr int kPanDefaultMinItems = 16384;   // rk_score_topk_plan takes this form by default from this catalogue size on
 
 struct PanArgs {
     int nb, n_items, d, K;
@@ -792,15 +853,14 @@ inline bool pan_supported(int n_items, int d, int K, int n_targets)
 inline long long pan_scratch_floats(int n_items, int d) { return (long long)n_items * 16 * pan_dc(d) + 4; }
 // user rows per workgroup: 32 (one workgroup per CU, every item operand feeds 8 MFMAs) pays from 8192 users on when the sweep is
 // operand-bound -- dim > 64 or catalogues of >= 65 536 items; measured 8 192 x 34 474 x 128 1.05 vs 1.18 ms, 16 384 x 131 072 x 64
-// 4.43 vs 4.72, but 4 096 x 34 474 x 64 0.69 vs 0.47 and 8 192 x 34 474 x 64 0.73 vs 0.70 (RK_PAN_ROWS=16|32 for tuning / tests,
-// read per call)
+// 4.43 vs 4.72, but 4 096 x 34 474 x 64 0.69 vs 0.47 and 8 192 x 34 474 x 64 0.73 vs 0.70 (rk_score_plan.panel_rows overrides)
 inline int pan_rows(int nb, int n_items, int d)
 {
-    const char *fr = getenv("RK_PAN_ROWS");
-    const int force = fr ? atoi(fr) : 0;
-    if (force == 16 || force == 32) return force;
     return nb >= 8192 && (d > 64 || n_items >= 65536) ? 32 : 16;
 }
+// 16-item tiles per wave and panel: the narrow form (8: 1024-item panels) while the catalogue fits one or two narrow panels
+// (less padding), else 15 (1920 items)
+inline int pan_ntw(int n_items) { return n_items <= 1024 ? 8 : 15; }
 
 template <int NTW, int DC, int NTG, int RB>
 inline hipError_t pan_launch_one(const PanArgs &a, hipStream_t s)
@@ -837,16 +897,15 @@ inline hipError_t pan_launch_dc(const PanArgs &a, hipStream_t s)
 #endif
 }
 
-// scratch: pan_scratch_floats(n_items, d) floats, 16-byte aligned
-inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s)
+// scratch: pan_scratch_floats(n_items, d) floats, 16-byte aligned; rows / ntw / safe: the plan's shape knobs (rk_score_plan)
+inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s, int rows, int ntw, int safe)
 {
     int bits = 1;
     while (bits < 32 && (1LL << bits) < (long long)a.n_items) ++bits;
     a.id_bits = bits;
-    const char *fs = getenv("RK_PAN_SAFE");   // tests: the safe form for every panel (read per call)
-    a.force_safe = fs ? atoi(fs) : 0;
-    const char *fst = getenv("RK_PAN_STAMPS");   // diagnostic: the stamps go behind the scratch (the caller over-allocates it by 36 * 8 bytes per workgroup + 64)
-    a.stamps = (fst && atoi(fst)) ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + pan_scratch_floats(a.n_items, a.d)) + 63) & ~(uintptr_t)63) : nullptr;
+    a.force_safe = safe;
+    // tuning builds, RK_PAN_STAMPS=1: the stamps go behind the scratch (the probe over-allocates it by 36 * 8 bytes per workgroup + 64)
+    a.stamps = RK_TUNE_INT("RK_PAN_STAMPS", 0) ? reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + pan_scratch_floats(a.n_items, a.d)) + 63) & ~(uintptr_t)63) : nullptr;
     const int dc = pan_dc(a.d);
     const long long n4 = (long long)a.n_items * dc * 4;
     hipLaunchKernelGGL(pan_permute_kernel, dim3((unsigned)std::min<long long>(2048, (n4 + 255) / 256)), dim3(256), 0, s, a.itab, a.n_items, a.d, dc,
@@ -854,10 +913,6 @@ inline hipError_t score_panel_launch(PanArgs a, float *scratch, hipStream_t s)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     a.itabp = scratch;
-    // panel width: the narrow form while the catalogue fits one or two narrow panels (less padding), else 1920 items
-    const char *fw = getenv("RK_PAN_NTW");
-    const int force = fw ? atoi(fw) : 0;
-    const bool narrow = force ? force == 8 : a.n_items <= 1024;
-    if (narrow) return pan_launch_dc<8, 1>(a, s);   // (small catalogues: 16-row workgroups only)
-    return pan_rows(a.nb, a.n_items, a.d) == 32 ? pan_launch_dc<15, 2>(a, s) : pan_launch_dc<15, 1>(a, s);
+    if (ntw == 8) return pan_launch_dc<8, 1>(a, s);   // (narrow panels: 16-row workgroups only)
+    return rows == 32 ? pan_launch_dc<15, 2>(a, s) : pan_launch_dc<15, 1>(a, s);
 }

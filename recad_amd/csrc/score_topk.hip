@@ -8,7 +8,6 @@
 #include <climits>
 
 #include "gemm.h"
-#include "score_select.h"
 #include "score_panel.h"
 
 // ---------------------------------------------------------------- pass 2
@@ -343,7 +342,7 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     // is 2.8x SLOWER than streaming it from L2 -- one 4-wave workgroup per CU); ml1m-size rows tie.
     // measured on 8192 rows: staging wins up to ~40 KB rows (6000 items: 90 vs 99 us, 9000: 132 vs 140), loses
     // beyond (14000 items, 56 KB: 285 vs 202 us -- two workgroups per CU)
-    static const size_t lds_row_max = getenv("RK_TOPK_LDS_KB") ? (size_t)atoi(getenv("RK_TOPK_LDS_KB")) * 1024 : 40 * 1024;
+    static const size_t lds_row_max = (size_t)RK_TUNE_INT("RK_TOPK_LDS_KB", 40) * 1024;
     if (row_bytes <= lds_row_max) {
         static RkPerDeviceOnce attr_once;
         int attr_dev;
@@ -363,62 +362,67 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
     return RK_OK;
 }
 
-// Which path rk_score_topk takes for a request, and the scratch it needs (floats).
-//   fused sweep (score_select.h): no score matrix, 1025 floats of candidate slots per user; needs K <= 256, at most 4
-//     targets, dim <= 128.  Measured on MI355X it is the SLOWER of the two wherever the score matrix fits comfortably
-//     (5893 x 3702 x 64: 198 vs 98 us; 54617 x 34474 x 128: 10.5 vs 7.7 ms -- DESIGN.md 4.3), so it is chosen by
-//     default only for catalogues of >= 2^18 items, where a block of users no longer fits a sensible score matrix;
-//   GEMM + selection over a materialised [nb, n_items] matrix otherwise.
-// RK_SEL_FORCE=1 forces the fused sweep wherever it is supported, RK_SEL_OFF=1 forbids it (tests run both; read per call).
-static bool use_fused(int n_items, int dim, int K, int n_targets)
-{
-    const char *off = getenv("RK_SEL_OFF"), *force = getenv("RK_SEL_FORCE");
-    if (off && atoi(off)) return false;
-    if (!sel_supported(n_items, dim, K, n_targets)) return false;
-    return (force && atoi(force)) || n_items >= (1 << 18);
-}
-
 // The register-resident panel form (score_panel.h): K <= 256, at most 4 targets, dim <= 256.  It parallelises over the USERS only
 // (16 or 32 per workgroup, the catalogue swept panel by panel), so it is the default for catalogues of >= 16 384 items AND enough
 // users to fill the chip: >= 8192, or >= 4096 at dim <= 64.  Measured on MI355X against GEMM + selection (ms): 16 384 x 34 474 x 64
 // 1.36 vs 1.91, 16 384 x 131 072 x 64 4.43 vs 6.76, 54 617 x 34 474 x 128 6.65 vs 7.77, 8 192 x 131 072 x 256 5.71 vs 6.49,
-// 4 096 x 34 474 x 64 0.47 vs 0.51, 4 096 x 500 000 x 64 5.56 vs 6.44; 16 384 x 500 000 x 64 15.4 vs 18.6 for the older fused
-// sweep; and where it is NOT taken: 5 893 x 3 702 x 64 0.105 vs 0.098, 2 048 x 131 072 x 64 1.55 vs 1.02, 4 096 x 34 474 x 128
-// 0.72 vs 0.64.  RK_PAN_FORCE=1 takes it wherever it is supported, RK_PAN_OFF=1 (or RK_SEL_OFF=1 / RK_SEL_FORCE=1, which name
-// the other two paths) forbids it; read per call.
-static bool use_panel(int nb, int n_items, int dim, int K, int n_targets)
+// 4 096 x 34 474 x 64 0.47 vs 0.51, 4 096 x 500 000 x 64 5.56 vs 6.44, 4 000 x 300 000 x 64 3.43 vs 3.89; and where it is NOT
+// taken: 5 893 x 3 702 x 64 0.105 vs 0.098, 2 048 x 131 072 x 64 1.55 vs 1.02, 2 048 x 300 000 x 64 3.39 vs 2.19, 4 096 x 34 474 x
+// 128 0.72 vs 0.64 (profiles/r04_score_corner.txt).
+static bool panel_by_default(int nb, int n_items, int dim, int K, int n_targets)
 {
-    const char *off = getenv("RK_PAN_OFF"), *force = getenv("RK_PAN_FORCE"), *soff = getenv("RK_SEL_OFF"), *sforce = getenv("RK_SEL_FORCE");
-    if ((off && atoi(off)) || (soff && atoi(soff)) || (sforce && atoi(sforce))) return false;
     if (!pan_supported(n_items, dim, K, n_targets)) return false;
-    if (force && atoi(force)) return true;
     return n_items >= kPanDefaultMinItems && (nb >= 8192 || (nb >= 4096 && dim <= 64));
 }
 
-RK_EXPORT int64_t rk_score_topk_scratch_floats(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets)
+RK_EXPORT int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets, const rk_score_plan *request,
+                                 rk_score_plan *out)
 {
-    if (nb <= 0 || n_items <= 0) return 0;
-    if (use_panel(nb, n_items, dim, K, n_targets)) return (int64_t)pan_scratch_floats(n_items, dim);              // the k-permuted item table
-    if (use_fused(n_items, dim, K, n_targets)) return (int64_t)sel_scratch_floats(nb, n_items, n_targets);   // candidate slots + counts (per item range)
-    return (int64_t)nb * n_items;
+    if (!out || nb <= 0 || n_items <= 0 || dim <= 0) RK_FAIL(RK_EINVAL, "rk_score_topk_plan: bad arguments");
+    if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
+    if (n_targets < 0 || n_targets > 256) RK_FAIL(RK_EINVAL, "top-K: bad targets");
+    rk_score_plan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.nb = nb; pl.n_items = n_items; pl.dim = dim; pl.K = K; pl.n_targets = n_targets;
+    const int want = request ? request->path : RK_SCORE_AUTO;
+    if (want != RK_SCORE_AUTO && want != RK_SCORE_GEMM && want != RK_SCORE_PANEL) RK_FAIL(RK_EINVAL, "rk_score_topk_plan: unknown path %d", want);
+    if (want == RK_SCORE_PANEL && !pan_supported(n_items, dim, K, n_targets))
+        RK_FAIL(RK_EINVAL, "rk_score_topk_plan: the panel form needs K <= 256, n_targets <= %d, dim <= 256", kPanMaxT);
+    pl.path = want != RK_SCORE_AUTO ? want : (panel_by_default(nb, n_items, dim, K, n_targets) ? RK_SCORE_PANEL : RK_SCORE_GEMM);
+    if (pl.path == RK_SCORE_PANEL) {
+        const int rows = request ? request->panel_rows : 0, ntw = request ? request->panel_ntw : 0;
+        if ((rows != 0 && rows != 16 && rows != 32) || (ntw != 0 && ntw != 8 && ntw != 15)) RK_FAIL(RK_EINVAL, "rk_score_topk_plan: panel_rows in {16, 32}, panel_ntw in {8, 15}");
+        pl.panel_ntw = ntw ? ntw : pan_ntw(n_items);
+        pl.panel_rows = pl.panel_ntw == 8 ? 16 : (rows ? rows : pan_rows(nb, n_items, dim));
+        pl.panel_safe = request && request->panel_safe ? 1 : 0;
+        pl.scratch_floats = (int64_t)pan_scratch_floats(n_items, dim);   // the k-permuted item table
+    } else {
+        pl.scratch_floats = (int64_t)nb * n_items;                      // the score matrix
+    }
+    *out = pl;
+    return RK_OK;
 }
 
 RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const int32_t *user_ids, const float *itab,
                             int32_t n_items, const float *ubias, const float *ibias, float mean,
                             const int32_t *seen_ptr, const int32_t *seen_idx, int32_t K, int32_t *top_ids,
                             float *top_scores, const int32_t *targets, int32_t n_targets, float *target_score,
-                            int32_t *target_rank, float *scratch, void *stream)
+                            int32_t *target_rank, const rk_score_plan *plan, float *scratch, void *stream)
 {
     if (nb <= 0) return RK_OK;
-    if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores)
+    if (dim <= 0 || n_items <= 0 || !utab || !itab || !user_ids || !seen_ptr || !seen_idx || !scratch || !top_ids || !top_scores || !plan)
         RK_FAIL(RK_EINVAL, "rk_score_topk: bad arguments");
     if ((ubias == nullptr) != (ibias == nullptr)) RK_FAIL(RK_EINVAL, "rk_score_topk: give both biases or neither");
     if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
+    // the plan sized `scratch`: it must be the plan of THIS request (a smaller block of the same plan is fine for the panel form,
+    // whose scratch does not depend on nb, and for the matrix, which only shrinks)
+    if (plan->n_items != n_items || plan->dim != dim || plan->K != K || plan->n_targets != n_targets || nb > plan->nb)
+        RK_FAIL(RK_EINVAL, "rk_score_topk: the plan was made for another request (rk_score_topk_plan)");
     hipStream_t s = (hipStream_t)stream;
-    if (use_panel(nb, n_items, dim, K, n_targets)) {
-        // (no silent fall-through: the caller sized `scratch` for THIS path)
+    if (plan->path == RK_SCORE_PANEL) {
+        if (!pan_supported(n_items, dim, K, n_targets)) RK_FAIL(RK_EINVAL, "rk_score_topk: the panel form does not take this request");
         if (reinterpret_cast<uintptr_t>(scratch) & 15) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 16-byte aligned (panel form)");
         PanArgs a;
         memset(&a, 0, sizeof(a));
@@ -426,29 +430,10 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
         a.utab = utab; a.user_ids = user_ids; a.itab = itab; a.ubias = ubias; a.ibias = ibias; a.mean = mean;
         a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
         a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
-        RK_HIP(score_panel_launch(a, scratch, s));
+        RK_HIP(score_panel_launch(a, scratch, s, plan->panel_rows, plan->panel_ntw, plan->panel_safe));
         return RK_OK;
     }
-    if (use_fused(n_items, dim, K, n_targets)) {
-        // (no silent fall-through to the GEMM path: the caller sized `scratch` for THIS path, 1025 floats per user)
-        if (reinterpret_cast<uintptr_t>(scratch) & 7) RK_FAIL(RK_EINVAL, "rk_score_topk: scratch must be 8-byte aligned (fused sweep)");
-        SelArgs a;
-        memset(&a, 0, sizeof(a));
-        a.nb = nb; a.n_items = n_items; a.d = dim; a.K = K;
-        a.utab = utab; a.user_ids = user_ids; a.itab = itab; a.ubias = ubias; a.ibias = ibias; a.mean = mean;
-        a.seen_ptr = seen_ptr; a.seen_idx = seen_idx; a.targets = targets; a.n_targets = n_targets;
-        a.top_ids = top_ids; a.top_scores = top_scores; a.target_score = target_score; a.target_rank = target_rank;
-        a.n_splits = sel_splits(nb, n_items);
-        a.cand = reinterpret_cast<unsigned long long *>(scratch);
-        a.cand_cnt = reinterpret_cast<int *>(scratch + (size_t)nb * a.n_splits * kSelC * 2);
-        a.rank_part = a.cand_cnt + (size_t)nb * a.n_splits;
-#ifdef RK_SEL_STAMPS
-        // diagnostic build: the stamps go behind the candidate scratch (the caller over-allocates it by 64 KiB)
-        a.stamps = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(scratch + sel_scratch_floats(nb, n_items, n_targets)) + 63) & ~(uintptr_t)63);
-#endif
-        RK_HIP(score_select_launch(a, s));
-        return RK_OK;
-    }
+    if (plan->path != RK_SCORE_GEMM) RK_FAIL(RK_EINVAL, "rk_score_topk: plan->path %d", plan->path);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = nb; g.N = n_items; g.K = dim;

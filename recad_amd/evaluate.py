@@ -4,13 +4,35 @@ Replaces the per-user Python loop + pandas sort of Normal.user_item_model_genera
 (recad/workflow/normal.py:57-93) with rk_score_topk: propagate ONCE, then for blocks of
 users one fp32-MFMA GEMM and one selection kernel.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
 from . import _lib
 
 
-def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096, to_host=True):
+def score_plan(nb, n_items, dim, K, n_targets, request=None):
+    """rk_score_topk_plan: the library's path choice for this request, or the requested one.  request: None / dict with any of
+    path ("gemm" | "panel" | "auto"), panel_rows (16 | 32), panel_ntw (8 | 15), panel_safe (bool) -- what the tests and the
+    probes force; the product passes None."""
+    req = _lib.ScorePlan()
+    if request:
+        req.path = {"auto": _lib.RK_SCORE_AUTO, "gemm": _lib.RK_SCORE_GEMM, "panel": _lib.RK_SCORE_PANEL}[request.get("path", "auto")]
+        req.panel_rows, req.panel_ntw = int(request.get("panel_rows", 0)), int(request.get("panel_ntw", 0))
+        req.panel_safe = 1 if request.get("panel_safe") else 0
+    out = _lib.ScorePlan()
+    _lib.check(_lib.lib().rk_score_topk_plan(int(nb), int(n_items), int(dim), int(K), int(n_targets), C.byref(req) if request else None,
+                                             C.byref(out)), "rk_score_topk_plan")
+    return out
+
+
+# what full_catalog_topk asks the library for when its caller does not say: None = the library's choice.  The GPU tests and the
+# probes set it (tests/conftest-style fixtures) -- the library itself reads no environment variable for this any more.
+SCORE_REQUEST = None
+
+
+def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chunk=4096, to_host=True, request=None, extra_scratch_floats=0):
     """For every user in user_ids (int array): top-K unseen items and the score/rank of each target.
 
     seen_ptr/seen_idx: CSR (indexed by user id) of the items to exclude (the train items), item ids ASCENDING
@@ -20,6 +42,8 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     arrays, or (to_host=False) device tensors left in HBM, no synchronisation.
     """
     _lib.require_gpu()
+    if request is None:
+        request = SCORE_REQUEST
     tabs = victim.scoring_tables() if hasattr(victim, "scoring_tables") else None
     dot = tabs is not None
     if dot:
@@ -50,12 +74,17 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     tscore = torch.empty(n, max(T, 1), dtype=torch.float32, device=dev)
     trank = torch.empty(n, max(T, 1), dtype=torch.int32, device=dev)
     chunk = max(1, min(chunk, n))
+    plan = None
     if dot:
-        # fused sweep (K <= 256, <= 4 targets): candidate slots only, so the whole user list goes in ONE call.  The scratch is
-        # sized for the block size actually passed (the library splits the catalogue into item ranges by that size)
-        if int(_lib.lib().rk_score_topk_scratch_floats(n, n_items, d, K, T)) < n * n_items:
+        # the scoring path is an argument of the call: a plan for the whole user list first -- if the library (or the request)
+        # takes the panel form, its scratch does not grow with the block, so everything goes in ONE call; the GEMM + selection
+        # path works through blocks of `chunk` users (its scratch is the block's score matrix)
+        plan = score_plan(n, n_items, d, K, T, request)
+        if plan.path != _lib.RK_SCORE_PANEL:
+            plan = score_plan(chunk, n_items, d, K, T, request)
+        else:
             chunk = n
-        scratch = torch.empty(int(_lib.lib().rk_score_topk_scratch_floats(chunk, n_items, d, K, T)), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(plan.scratch_floats) + extra_scratch_floats, dtype=torch.float32, device=dev)
     else:
         scratch = torch.empty(chunk * n_items, dtype=torch.float32, device=dev)
     for s in range(0, n, chunk):
@@ -71,7 +100,7 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
         _lib.check(_lib.lib().rk_score_topk(
             d, _lib.ptr(utab), e - s, _lib.ptr(ids), _lib.ptr(itab), n_items, _lib.ptr(ubias), _lib.ptr(ibias),
             float(mean), _lib.ptr(seen_ptr_t), _lib.ptr(seen_idx_t), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_scores[s:e]),
-            _lib.ptr(targets_t), T, _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), _lib.ptr(scratch), _lib.stream_ptr()),
+            _lib.ptr(targets_t), T, _lib.ptr(tscore[s:e]), _lib.ptr(trank[s:e]), C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()),
             "rk_score_topk")
     if not to_host:
         return {"top_ids": top_ids, "top_scores": top_scores, "target_score": tscore[:, :T], "target_rank": trank[:, :T]}

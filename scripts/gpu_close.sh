@@ -47,9 +47,9 @@ timeout 600 python scripts/bench_victims.py > /dev/null 2>&1; cp $o/bench_victim
 ( for shape in "5893 3702 64 20" "16384 34474 64 5" "54617 34474 128 3" "8192 34474 256 5" "16384 131072 64 3"; do
     PROBE_MODES=panel,unfused timeout 300 python3 scripts/score_probe.py $shape 2>/dev/null | grep -v amdgpu.ids
   done
-  PROBE_MODES=panel,fused,unfused timeout 600 python3 scripts/score_probe.py 16384 500000 64 2 2>/dev/null | grep -v amdgpu.ids
-  RK_PAN_ROWS=16 PROBE_MODES=panel timeout 300 python3 scripts/score_probe.py 54617 34474 128 3 2>/dev/null | grep "^panel" | sed 's/^panel /panel (16-row workgroups) /' ) > $o/${tag}_score_probe.txt; cat $o/${tag}_score_probe.txt
-( RK_PAN_ROWS=16 timeout 120 python3 scripts/pan_stamps.py 2>/dev/null | grep -v amdgpu.ids; timeout 200 python3 scripts/pan_stamps.py 54617 34474 128 2>/dev/null | grep -v amdgpu.ids ) > $o/${tag}_pan_stamps.txt
+  PROBE_MODES=panel,unfused timeout 600 python3 scripts/score_probe.py 16384 500000 64 2 2>/dev/null | grep -v amdgpu.ids
+  PROBE_ROWS=16 PROBE_MODES=panel timeout 300 python3 scripts/score_probe.py 54617 34474 128 3 2>/dev/null | grep "^panel" | sed 's/^panel /panel (16-row workgroups) /' ) > $o/${tag}_score_probe.txt; cat $o/${tag}_score_probe.txt
+( PROBE_ROWS=16 timeout 120 python3 scripts/pan_stamps.py 2>/dev/null | grep -v amdgpu.ids; timeout 200 python3 scripts/pan_stamps.py 54617 34474 128 2>/dev/null | grep -v amdgpu.ids ) > $o/${tag}_pan_stamps.txt
 timeout 900 bash scripts/pan_pmc.sh 16384 34474 64 > $o/${tag}_pan_sq_counters.txt 2>&1
 python3 - <<PY
 import json

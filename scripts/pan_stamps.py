@@ -1,5 +1,6 @@
 """Diagnostic: where a workgroup of the register-resident panel form (score_panel.h) spends its time (RK_PAN_STAMPS=1).
     python3 scripts/pan_stamps.py [n_users=5893] [n_items=3702] [dim=64]"""
+import ctypes as C
 import os
 import sys
 
@@ -7,9 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
-os.environ["RK_PAN_FORCE"] = "1"
 os.environ["RK_PAN_STAMPS"] = "1"
 from recad_amd import _lib
+from recad_amd.evaluate import score_plan
 
 nu, I, d = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((1, 5893), (2, 3702), (3, 64)))
 dev = torch.device('cuda:0')
@@ -29,13 +30,14 @@ top_ids = torch.empty(nu, K, dtype=torch.int32, device=dev)
 top_sc = torch.zeros(nu, K, device=dev)
 ts = torch.empty(nu, 1, device=dev)
 tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
-need = int(_lib.lib().rk_score_topk_scratch_floats(nu, I, d, K, 1))
-rows = int(os.environ.get("RK_PAN_ROWS", 32 if nu >= 4096 else 16))
+rows = int(os.environ.get("PROBE_ROWS", 32 if nu >= 4096 else 16))
+plan = score_plan(nu, I, d, K, 1, {"path": "panel", "panel_rows": rows})   # (stamps: tuning build + RK_PAN_STAMPS=1)
+need = int(plan.scratch_floats)
 n_wg = (nu + rows - 1) // rows
 scratch = torch.zeros(need + n_wg * 72 + 64, device=dev)
 for _ in range(3):
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), nu, _lib.ptr(ids), _lib.ptr(itab), I, None, None, 0.0, _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids),
-                                        _lib.ptr(top_sc), _lib.ptr(tg), 1, _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "x")
+                                        _lib.ptr(top_sc), _lib.ptr(tg), 1, _lib.ptr(ts), _lib.ptr(tr), C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "x")
 torch.cuda.synchronize()
 off = ((scratch.data_ptr() + need * 4 + 63) & ~63) - scratch.data_ptr()
 st = scratch.view(torch.uint8)[off: off + n_wg * 288].view(torch.int64).view(n_wg, 36).cpu().numpy().astype(np.float64)

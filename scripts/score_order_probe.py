@@ -1,6 +1,7 @@
 """Probe (tuning only): rk_score_topk when the scores are ORDERED by item id (an item bias that grows / falls / steps with the
 id on top of random embeddings) -- the case in which the panel form's bound from earlier panels is too low for a later one.
     python3 scripts/score_order_probe.py <random|descending|blocky|ascending> [n_users=16384] [n_items=34474] [dim=64]"""
+import ctypes as C
 import os
 import sys
 
@@ -8,6 +9,7 @@ import torch
 
 sys.path.insert(0, '.')
 from recad_amd import _lib
+from recad_amd.evaluate import score_plan
 
 kind = sys.argv[1]
 nu, I, d = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((2, 16384), (3, 34474), (4, 64)))
@@ -25,22 +27,20 @@ ids = torch.arange(nu, dtype=torch.int32, device=dev)
 tg = torch.tensor([0], dtype=torch.int32, device=dev)
 out = {}
 for mode in ("panel", "unfused"):
-    for k in ("RK_SEL_OFF", "RK_PAN_FORCE"):
-        os.environ.pop(k, None)
-    os.environ[{"unfused": "RK_SEL_OFF", "panel": "RK_PAN_FORCE"}[mode]] = "1"
     chunk = nu if mode == "panel" else 8192
+    plan = score_plan(chunk, I, d, K, 1, {"path": "panel" if mode == "panel" else "gemm"})
     top_ids = torch.empty(nu, K, dtype=torch.int32, device=dev)
     top_sc = torch.empty(nu, K, device=dev)
     ts = torch.empty(nu, 1, device=dev)
     tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
-    scratch = torch.empty(int(_lib.lib().rk_score_topk_scratch_floats(chunk, I, d, K, 1)) + 64, device=dev)
+    scratch = torch.empty(int(plan.scratch_floats) + 64, device=dev)
 
     def once():
         for s in range(0, nu, chunk):
             e = min(nu, s + chunk)
             _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), e - s, _lib.ptr(ids[s:e]), _lib.ptr(itab), I, _lib.ptr(ub), _lib.ptr(ib), 0.0, _lib.ptr(ptr),
                                                 _lib.ptr(idx), K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_sc[s:e]), _lib.ptr(tg), 1, _lib.ptr(ts[s:e]),
-                                                _lib.ptr(tr[s:e]), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+                                                _lib.ptr(tr[s:e]), C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

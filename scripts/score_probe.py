@@ -1,5 +1,6 @@
-"""Probe (tuning only): rk_score_topk per-call time, panel form vs fused sweep vs GEMM + selection, on random tables (PROBE_MODES=panel,unfused ...).
+"""Probe (tuning only): rk_score_topk per-call time, panel form (PROBE_ROWS=16|32 forces its workgroup shape) vs GEMM + selection, on random tables (PROBE_MODES=panel,unfused).
     python3 scripts/score_probe.py <n_users> <n_items> <dim> [reps]"""
+import ctypes as C
 import os
 import sys
 
@@ -8,6 +9,7 @@ import torch
 
 sys.path.insert(0, '.')
 from recad_amd import _lib
+from recad_amd.evaluate import score_plan
 
 nu, I, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
@@ -29,21 +31,19 @@ top_sc = torch.empty(nu, K, device=dev)
 ts = torch.empty(nu, 1, device=dev)
 tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
 out = {}
-modes = os.environ.get("PROBE_MODES", "panel,fused,unfused").split(",")
+modes = os.environ.get("PROBE_MODES", "panel,unfused").split(",")
 for mode in modes:
-    for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_FORCE", "RK_PAN_OFF"):
-        os.environ.pop(k, None)
-    os.environ[{"unfused": "RK_SEL_OFF", "fused": "RK_SEL_FORCE", "panel": "RK_PAN_FORCE"}[mode]] = "1"
     chunk = nu if mode != "unfused" else max(256, min(8192, (1 << 31) // I))
-    need = int(_lib.lib().rk_score_topk_scratch_floats(min(chunk, nu), I, d, K, 1)) + 16384
-    scratch = torch.empty(need, device=dev)
+    req = {"path": "gemm"} if mode == "unfused" else dict({"path": "panel"}, **({"panel_rows": int(os.environ["PROBE_ROWS"])} if os.environ.get("PROBE_ROWS") else {}))
+    plan = score_plan(min(chunk, nu), I, d, K, 1, req)
+    scratch = torch.empty(int(plan.scratch_floats) + 16384, device=dev)
 
     def once():
         for s in range(0, nu, chunk):
             e = min(nu, s + chunk)
             _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), e - s, _lib.ptr(ids[s:e]), _lib.ptr(itab), I, None, None, 0.0, _lib.ptr(sp), _lib.ptr(si),
                                                 K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_sc[s:e]), _lib.ptr(tg), 1, _lib.ptr(ts[s:e]), _lib.ptr(tr[s:e]),
-                                                _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+                                                C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     once(); once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

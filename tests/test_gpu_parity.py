@@ -277,11 +277,11 @@ def _eval_against_golden(g, m, device):
     return res, users
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("panel", [False, True])
 @pytest.mark.parametrize("name", ["lightgcn_dev_d64", "lightgcn_game_d64_tg"])
-def test_lightgcn_eval_golden(gpu_device, name, fused, request):
-    if fused:
-        request.getfixturevalue("fused_scoring")
+def test_lightgcn_eval_golden(gpu_device, name, panel, request):
+    if panel:   # (the default at these catalogue sizes is GEMM + selection)
+        request.getfixturevalue("panel_scoring")
     g = G.load(name)
     m, ds = _make_lgn(g, gpu_device)
     # train over the recorded batches exactly as the golden run did (one train_step per batch)
@@ -291,53 +291,46 @@ def test_lightgcn_eval_golden(gpu_device, name, fused, request):
     _eval_against_golden(g, m, gpu_device)
 
 
+# Which path rk_score_topk takes is an ARGUMENT (rk_score_plan, ABI 8): the tests ask for one through the request that
+# recad_amd.evaluate.full_catalog_topk hands to rk_score_topk_plan (evaluate.SCORE_REQUEST), or build the plan themselves.
+PATH_REQUESTS = {
+    "gemm": {"path": "gemm"},
+    "panel": {"path": "panel", "panel_rows": 16}, "panel32": {"path": "panel", "panel_rows": 32},
+    "panel_safe": {"path": "panel", "panel_rows": 16, "panel_safe": True}, "panel32_safe": {"path": "panel", "panel_rows": 32, "panel_safe": True},
+    "panel_narrow": {"path": "panel", "panel_rows": 16, "panel_ntw": 8},
+}
+
+
+def _score_request(req):
+    from recad_amd import evaluate
+    evaluate.SCORE_REQUEST = req
+    try:
+        yield
+    finally:
+        evaluate.SCORE_REQUEST = None
+
+
 @pytest.fixture
 def unfused_scoring():
-    """RK_SEL_OFF=1: rk_score_topk takes the GEMM + selection path over a materialised score matrix."""
-    import os
-    os.environ["RK_SEL_OFF"] = "1"
-    yield
-    os.environ.pop("RK_SEL_OFF", None)
-
-
-@pytest.fixture
-def fused_scoring():
-    """RK_SEL_FORCE=1: rk_score_topk takes the fused sweep (no score matrix) wherever it is supported, also below
-    the catalogue size at which it becomes the default."""
-    import os
-    os.environ["RK_SEL_FORCE"] = "1"
-    yield
-    os.environ.pop("RK_SEL_FORCE", None)
+    """GEMM + selection over a materialised score matrix, whatever the shape."""
+    yield from _score_request({"path": "gemm"})
 
 
 @pytest.fixture
 def panel_scoring():
-    """RK_PAN_FORCE=1: rk_score_topk takes the register-resident panel form (score_panel.h) wherever it is supported."""
-    import os
-    os.environ["RK_PAN_FORCE"] = "1"
-    yield
-    os.environ.pop("RK_PAN_FORCE", None)
-    os.environ.pop("RK_PAN_SAFE", None)
-    os.environ.pop("RK_PAN_NTW", None)
-    os.environ.pop("RK_PAN_ROWS", None)
+    """The register-resident panel form (score_panel.h) wherever it is supported."""
+    yield from _score_request({"path": "panel"})
 
 
-@pytest.mark.parametrize("path", ["panel", "panel32", "panel_safe", "panel32_safe", "panel_narrow", "sweep", "gemm"])
+@pytest.mark.parametrize("path", ["panel", "panel32", "panel_safe", "panel32_safe", "panel_narrow", "gemm"])
 @pytest.mark.parametrize("d,with_bias", [(64, False), (64, True), (128, False), (50, True), (7, False), (256, False)])
-def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
+def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path):
     """Integer/index bar: scores from the fp32 MFMA equal the oracle's fmaf chain bit for bit,
     so the top-K id lists and ranks must be IDENTICAL (ties included: lower id first) -- on the register-resident panel
-    form (its fast and its safe form, both panel widths), on the fused sweep (no score matrix) and on the GEMM + selection path."""
-    import os
+    form (its fast and its safe form, both panel widths, both workgroup shapes) and on the GEMM + selection path."""
+    import ctypes as C
     from recad_amd import _lib
-    fused = path == "sweep"
-    request.getfixturevalue({"sweep": "fused_scoring", "gemm": "unfused_scoring"}.get(path, "panel_scoring"))
-    if path in ("panel_safe", "panel32_safe"):
-        os.environ["RK_PAN_SAFE"] = "1"
-    if path == "panel_narrow":
-        os.environ["RK_PAN_NTW"] = "8"
-    if path.startswith("panel"):
-        os.environ["RK_PAN_ROWS"] = "32" if path.startswith("panel32") else "16"
+    from recad_amd.evaluate import score_plan
     rng = np.random.default_rng(d)
     nu, nb, I, K = 220, 150, 1000 + d, 100
     utab = rng.standard_normal((nu, d), dtype=np.float32)
@@ -361,21 +354,24 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path, request):
     top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
     ts = torch.empty(nb, 3, dtype=torch.float32, device=dev)
     tr = torch.empty(nb, 3, dtype=torch.int32, device=dev)
-    need = int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, 3))
-    scratch = torch.empty(max(nb * I, need), dtype=torch.float32, device=dev)
+    plan = score_plan(nb, I, d, K, 3, PATH_REQUESTS[path])
+    assert plan.path == (_lib.RK_SCORE_PANEL if path.startswith("panel") else _lib.RK_SCORE_GEMM)
+    need = int(plan.scratch_floats)
+    scratch = torch.empty(need, dtype=torch.float32, device=dev)
     tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
     ids = t(user_ids, torch.int32)
     sp, si, tg = t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(targets, torch.int32)
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(ids), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.25 if with_bias else 0.0,
                                         _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 3,
-                                        _lib.ptr(ts), _lib.ptr(tr), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+                                        _lib.ptr(ts), _lib.ptr(tr), C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids] if with_bias else None, ib, 0.25 if with_bias else 0.0)
-    # fused: candidate slots + counts (+ per-range target counts), never the score matrix
-    if path.startswith("panel"):
-        assert need == I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4   # the k-permuted item table
+    if path.startswith("panel"):   # the k-permuted item table, never the score matrix
+        assert need == I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4
+        assert (plan.panel_rows, plan.panel_ntw, plan.panel_safe) == (16 if path == "panel_narrow" else 32 if path.startswith("panel32") else 16,
+                                                                      8 if path == "panel_narrow" else 15, 1 if path.endswith("safe") else 0)
     else:
-        assert (nb * 1025 <= need <= nb * 8 * 1028 + 2) if (fused and d <= 128) else need == nb * I
-    got_scores = None if ((fused and d <= 128) or path.startswith("panel")) else scratch[: nb * I].view(nb, I).cpu().numpy()
+        assert need == nb * I
+    got_scores = None if path.startswith("panel") else scratch[: nb * I].view(nb, I).cpu().numpy()
     top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         seen = seen_lists[int(user_ids[b])]
@@ -1927,9 +1923,11 @@ def test_device_eval_plumbing(gpu_device):
     assert abs(out[0] - ref) <= 1e-12 + 1e-12 * abs(ref) * a.size
 
 
-def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, targets):
+def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, targets, request=None):
     """rk_score_topk through the C-ABI on host arrays -> (top_ids, top_scores, target_score, target_rank)"""
+    import ctypes as C
     from recad_amd import _lib
+    from recad_amd.evaluate import score_plan
     nu, d = utab.shape
     I = itab.shape[0]
     nb, T = len(user_ids), len(targets)
@@ -1943,69 +1941,35 @@ def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, tar
     top_sc = torch.empty(nb, K, dtype=torch.float32, device=dev)
     ts = torch.empty(nb, max(T, 1), dtype=torch.float32, device=dev)
     tr = torch.empty(nb, max(T, 1), dtype=torch.int32, device=dev)
-    need = int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, T))
-    scratch = torch.empty(max(need, 2), dtype=torch.float32, device=dev)
+    plan = score_plan(nb, I, d, K, T, request)
+    scratch = torch.empty(max(int(plan.scratch_floats), 2), dtype=torch.float32, device=dev)
     tu, ti, tub, tib = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32)
     ids, sp, si, tg = t(user_ids, torch.int32), t(seen_ptr, torch.int32), t(seen_idx, torch.int32), t(np.asarray(targets, np.int32), torch.int32)
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(ids), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), float(mean),
                                         _lib.ptr(sp), _lib.ptr(si), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg) if T else None, T,
-                                        _lib.ptr(ts) if T else None, _lib.ptr(tr) if T else None, _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+                                        _lib.ptr(ts) if T else None, _lib.ptr(tr) if T else None, C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()),
+               "rk_score_topk")
     return top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy()[:, :T], tr.cpu().numpy()[:, :T]
 
 
-@pytest.mark.parametrize("splits", [2, 3, 8])
-def test_fused_sweep_item_ranges(gpu_device, splits, fused_scoring):
-    """The sweep over `splits` contiguous item ranges (one workgroup per (row block, range), per-range candidate lists and
-    target counts merged by the finalize kernel; RK_SEL_SPLITS) returns the same bits as the oracle's scan: the top-K of a
-    union is the top-K of the parts' top-Ks, ties included."""
-    import os
-    rng = np.random.default_rng(splits)
-    nu, I, d, K = 150, 3000, 32, 100
-    utab = rng.standard_normal((nu, d), dtype=np.float32)
-    itab = (rng.integers(-3, 4, (I, d)) / 4.0).astype(np.float32)      # quantised: plenty of exact ties across ranges
-    utab = (rng.integers(-3, 4, (nu, d)) / 4.0).astype(np.float32)
-    deg = rng.integers(0, 400, nu)
-    ptr = np.zeros(nu + 1, dtype=np.int32)
-    ptr[1:] = np.cumsum(deg)
-    idx = np.concatenate([np.sort(rng.choice(I, size=int(k), replace=False)) for k in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
-    targets = np.array([5, 1500, 2999], dtype=np.int32)
-    os.environ["RK_SEL_SPLITS"] = str(splits)
-    os.environ["RK_SEL_CONFIG"] = "2"
-    try:
-        seen_lists = [idx[ptr[u]:ptr[u + 1]] for u in range(nu)]
-        ids, sc, ts, tr = _score_topk_call(gpu_device, utab, itab, None, None, 0.0, np.arange(nu, dtype=np.int32), seen_lists, K, targets)
-    finally:
-        del os.environ["RK_SEL_SPLITS"], os.environ["RK_SEL_CONFIG"]
-    for u in range(nu):
-        s = orc.score_rows(utab[u:u + 1], itab)[0]
-        rid, rsc, rts, rtr = orc.topk_row(s, idx[ptr[u]:ptr[u + 1]], K, targets)
-        assert np.array_equal(ids[u], rid) and np.array_equal(sc[u], rsc), u
-        assert np.array_equal(ts[u], rts) and np.array_equal(tr[u], rtr), u
-
-
 @pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
-@pytest.mark.parametrize("path", ["panel", "sweep"])
+@pytest.mark.parametrize("path", ["panel", "gemm"])
 @pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 100, 1, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
-def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path, request):
-    """The register-resident panel form (score_panel.h; config 1: 32-row workgroups, config 2: the narrow panels) and the
-    fused scoring + selection sweep (score_select.h) on rows built to stress their threshold logic: constant
+def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path):
+    """The register-resident panel form (score_panel.h; config 1: 32-row workgroups, config 2: the narrow panels) and GEMM +
+    selection (config 0 only) on rows built to stress their threshold logic: constant
     and few-valued rows (every score ties), scores ascending with the item id (every item beats the running
     threshold: repeated compactions), descending, long runs of seen items inside one tile, rows with fewer than
     K unseen items -- bit-identical lists, scores and ranks to the oracle's scan (ties: lower id first).  For the panel form
     the ascending rows overflow a list in every panel (its bound refinement by counting), the constant and few-valued ones cannot
     be separated by any bound (its safe form).
     The scores are made of exact pieces (zero dot product + item bias) where the pattern matters."""
-    import os
     rng = np.random.default_rng(I + K)
     nu, d = 90, 16
-    request.getfixturevalue("panel_scoring" if path == "panel" else "fused_scoring")
-    if config and path == "sweep":
-        os.environ["RK_SEL_CONFIG"] = str(config)   # force the 16-row / 64-row workgroup shape
-    if path == "panel":
-        os.environ["RK_PAN_ROWS"] = "32" if config == 1 else "16"
-        if config == 2:
-            os.environ["RK_PAN_NTW"] = "8"
-    try:
+    if path == "gemm" and config:
+        pytest.skip("the workgroup-shape knobs belong to the panel form")
+    req = {"path": "gemm"} if path == "gemm" else dict({"path": "panel", "panel_rows": 32 if config == 1 else 16}, **({"panel_ntw": 8} if config == 2 else {}))
+    if True:
         utab = np.zeros((nu, d), np.float32)
         itab = np.zeros((I, d), np.float32)
         ub = np.zeros(nu, np.float32)
@@ -2037,7 +2001,7 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path, request):
             seen = [np.sort(rng.choice(I, size=int(rng.integers(0, min(I, 60))), replace=False)).astype(np.int32) for _ in range(nu)]
         user_ids = rng.permutation(nu)[:77].astype(np.int32)
         targets = np.array([3, I - 1, I // 2, 17][:T], dtype=np.int32)
-        ti, tsc, ts, tr = _score_topk_call(gpu_device, utab, itab, ub, ib, 0.5, user_ids, seen, K, targets)
+        ti, tsc, ts, tr = _score_topk_call(gpu_device, utab, itab, ub, ib, 0.5, user_ids, seen, K, targets, request=req)
         ref_scores = orc.score_rows(utab[user_ids], itab, ub[user_ids], ib, 0.5)
         for b in range(len(user_ids)):
             rid, rsc, rts, rtr = orc.topk_row(ref_scores[b], seen[int(user_ids[b])], K, targets)
@@ -2045,9 +2009,6 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path, request):
             assert np.array_equal(tsc[b], rsc), (kind, b)
             if T:
                 assert np.array_equal(ts[b], rts) and np.array_equal(tr[b], rtr), (kind, b)
-    finally:
-        os.environ.pop("RK_SEL_CONFIG", None)
-        os.environ.pop("RK_PAN_ROWS", None)
 
 
 def _spmm_rows_host(rp, c, v, x, rows):
@@ -2060,20 +2021,18 @@ def _spmm_rows_host(rp, c, v, x, rows):
     return out
 
 
-@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "fused"), ("c4s", 64, "panel"), ("config4", 64, "default"), ("config4", 64, "panel")])
+@pytest.mark.parametrize("shape,dim,mode", [("yelp", 128, "default"), ("c4s", 64, "default"), ("c4s", 64, "panel"), ("config4", 64, "default"), ("config4", 64, "panel")])
 def test_full_size_properties_large(gpu_device, shape, dim, mode, request):
     """BASELINE.json configs 3 and 4 on the GPU: yelp-shaped (54 632 x 34 474, 1.64 M train edges, d=128),
     config 4 / 4 (250 K x 125 K, 25 M edges, d=64: rows of > 100 K nonzeros, i.e. hundreds of cross-workgroup
     pieces, 32-bit gather offsets at 96 MB tables) and config 4 itself (1 M x 500 K x 100 M edges: 200 M nonzeros,
-    384 MB tables, a 500 K-item catalogue; the few sampled users score through GEMM + selection by default, 'fused' and
-    'panel' force the other two paths).  The oracle cannot replay these sizes in seconds, so:
+    384 MB tables, a 500 K-item catalogue; the few sampled users score through GEMM + selection by default, 'panel'
+    forces the other path).  The oracle cannot replay these sizes in seconds, so:
     size-independent properties (linearity, symmetry, spectral bound of the normalised adjacency, determinism),
     float64 host restatements of SAMPLED rows (the longest rows included), a train step that moves the loss, and
     bit-exact top-K lists / target ranks against the oracle on sampled users."""
     from recad_amd import dataset, model, synth
     from recad_amd.evaluate import eligible_users_device, full_catalog_topk
-    if mode == "fused":
-        request.getfixturevalue("fused_scoring")
     if mode == "panel":
         request.getfixturevalue("panel_scoring")
     if shape in ("c4s", "config4"):

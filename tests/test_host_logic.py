@@ -317,33 +317,46 @@ def test_ctypes_descriptors_match_the_header(tmp_path):
             assert getattr(cls, rename.get(f, f)).offset == int(out[f"{st}.{f}"]), (st, f)
 
 
-def test_score_topk_path_selection_by_scratch_size(monkeypatch):
-    """rk_score_topk_scratch_floats (host code of the C ABI, no GPU needed) names the path rk_score_topk will take for a
-    request: GEMM + selection (a [nb, n_items] matrix) below 16 384 items or for user blocks too small to fill the chip, the
-    register-resident panel form (a k-permuted copy of the item table) otherwise, the older fused sweep
-    (1025 floats per user) when forced, and GEMM + selection for requests neither fused form takes (more than 4 targets)."""
+def test_score_topk_plan_names_the_path():
+    """rk_score_topk_plan (host code of the C ABI, no GPU needed) names the path rk_score_topk will take and sizes its scratch:
+    GEMM + selection (a [nb, n_items] matrix) below 16 384 items or for user blocks too small to fill the chip, the
+    register-resident panel form (a k-permuted copy of the item table) otherwise; a request forces a path and the panel form's
+    shape knobs, and a path that cannot take the request is refused.  No environment variable is consulted."""
+    import os
     from recad_amd import _lib
-    for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_OFF", "RK_PAN_FORCE", "RK_PAN_ROWS", "RK_SEL_SPLITS"):
-        monkeypatch.delenv(k, raising=False)
-    f = lambda nb, I, d, K=100, T=1: int(_lib.lib().rk_score_topk_scratch_floats(nb, I, d, K, T))
-    panel = lambda I, d: I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4
-    assert f(5893, 3702, 64) == 5893 * 3702                      # ml1m: GEMM + selection
-    assert f(16384, 34474, 64) == panel(34474, 64)
-    assert f(54617, 34474, 128) == panel(34474, 128)
-    assert f(8192, 34474, 100) == panel(34474, 100)              # k padded to a multiple of 16
-    assert f(8192, 34474, 256) == panel(34474, 256)
-    assert f(4096, 34474, 64) == panel(34474, 64)                # 4096 users fill the chip at dim <= 64 ...
-    assert f(4096, 34474, 128) == 4096 * 34474                   # ... not beyond
-    assert f(2048, 131072, 64) == 2048 * 131072                  # few users: the GEMM parallelises over the items too
-    assert f(16384, 500000, 64) == panel(500000, 64)
-    assert f(8192, 500000, 64, 100, 5) == 8192 * 500000          # five targets: neither fused form
-    assert f(8192, 34474, 64, 300) == 8192 * 34474               # K > 256
-    monkeypatch.setenv("RK_PAN_OFF", "1")
-    assert f(16384, 34474, 64) == 16384 * 34474
-    assert 8192 * 1025 <= f(8192, 500000, 64) <= 8192 * 1028 + 2  # >= 2^18 items: the older sweep
-    monkeypatch.delenv("RK_PAN_OFF")
-    monkeypatch.setenv("RK_PAN_FORCE", "1")
-    assert f(5893, 3702, 64) == panel(3702, 64)
-    monkeypatch.delenv("RK_PAN_FORCE")
-    monkeypatch.setenv("RK_SEL_OFF", "1")
-    assert f(16384, 500000, 64) == 16384 * 500000
+    from recad_amd.evaluate import score_plan
+    for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_OFF", "RK_PAN_FORCE"):   # (the round-3 switches: must be inert now)
+        os.environ[k] = "1"
+    try:
+        def f(nb, I, d, K=100, T=1, req=None):
+            p = score_plan(nb, I, d, K, T, req)
+            assert (p.nb, p.n_items, p.dim, p.K, p.n_targets) == (nb, I, d, K, T)
+            return p.path, int(p.scratch_floats)
+        panel = lambda I, d: (_lib.RK_SCORE_PANEL, I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4)
+        gemm = lambda nb, I: (_lib.RK_SCORE_GEMM, nb * I)
+        assert f(5893, 3702, 64) == gemm(5893, 3702)                  # ml1m: GEMM + selection
+        assert f(16384, 34474, 64) == panel(34474, 64)
+        assert f(54617, 34474, 128) == panel(34474, 128)
+        assert f(8192, 34474, 100) == panel(34474, 100)               # k padded to a multiple of 16
+        assert f(8192, 34474, 256) == panel(34474, 256)
+        assert f(4096, 34474, 64) == panel(34474, 64)                 # 4096 users fill the chip at dim <= 64 ...
+        assert f(4096, 34474, 128) == gemm(4096, 34474)               # ... not beyond
+        assert f(2048, 131072, 64) == gemm(2048, 131072)              # few users: the GEMM parallelises over the items too
+        assert f(2048, 500000, 64) == gemm(2048, 500000)              # (round 3 sent this corner to the fused sweep: 3x slower)
+        assert f(16384, 500000, 64) == panel(500000, 64)
+        assert f(8192, 500000, 64, 100, 5) == gemm(8192, 500000)      # five targets: not the panel form
+        assert f(16384, 34474, 64, req={"path": "gemm"}) == gemm(16384, 34474)
+        assert f(5893, 3702, 64, req={"path": "panel"}) == panel(3702, 64)
+        p = score_plan(16384, 131072, 64, 100, 1, None)
+        assert (p.panel_rows, p.panel_ntw, p.panel_safe) == (32, 15, 0)                   # operand-bound sweep: 32-row workgroups
+        p = score_plan(16384, 34474, 64, 100, 1, {"path": "panel", "panel_rows": 32, "panel_safe": True})
+        assert (p.panel_rows, p.panel_ntw, p.panel_safe) == (32, 15, 1)
+        p = score_plan(100, 900, 64, 100, 1, {"path": "panel"})
+        assert (p.panel_rows, p.panel_ntw) == (16, 8)                                      # small catalogue: narrow panels
+        with pytest.raises(_lib.HipCallError):
+            score_plan(8192, 500000, 64, 100, 5, {"path": "panel"})                       # five targets
+        with pytest.raises(_lib.HipCallError):
+            score_plan(8192, 34474, 64, 300, 1, None)                                      # K > 256
+    finally:
+        for k in ("RK_SEL_OFF", "RK_SEL_FORCE", "RK_PAN_OFF", "RK_PAN_FORCE"):
+            os.environ.pop(k, None)

@@ -1,18 +1,14 @@
 """Randomised scoring-GEMM stress: rk_score_topk's score matrix must equal the oracle's k-ordered fmaf chain bit for bit
 (random block sizes, catalog sizes, dims, gathered user ids, with and without biases)."""
-import sys, numpy as np, torch
+import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from oracle import oracle as orc
 from recad_amd import _lib
+from recad_amd.evaluate import score_plan
 
 
 def run(seed=0, n_cases=100):
-    import os
-    os.environ["RK_SEL_OFF"] = "1"   # the score matrix is what this tool checks: GEMM + selection path
-    try:
-        _run(seed, n_cases)
-    finally:
-        os.environ.pop("RK_SEL_OFF", None)
+    _run(seed, n_cases)   # (the score matrix is what this tool checks: every call asks for the GEMM + selection path)
 
 
 def _run(seed, n_cases):
@@ -31,10 +27,11 @@ def _run(seed, n_cases):
         top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev); top_sc = torch.empty(nb, K, device=dev)
         ts_ = torch.empty(nb, 1, device=dev); tr = torch.empty(nb, 1, dtype=torch.int32, device=dev)
         scratch = torch.empty(nb * I, device=dev)
+        plan = score_plan(nb, I, d, K, 1, {"path": "gemm"})
         tu, ti, tub, tib, tid, tsp, tsi, tg = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32), t(ids, torch.int32), t(sp, torch.int32), t(si, torch.int32), t(np.zeros(1, dtype=np.int32), torch.int32)
         _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(tid), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.5 if bias else 0.0,
                                             _lib.ptr(tsp), _lib.ptr(tsi), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 1, _lib.ptr(ts_), _lib.ptr(tr),
-                                            _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
+                                            C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
         got = scratch.view(nb, I).cpu().numpy()
         ref = orc.score_rows(utab[ids], itab, ub[ids] if bias else None, ib, 0.5 if bias else 0.0)
         if not np.array_equal(got, ref):
