@@ -1954,8 +1954,9 @@ def _score_topk_call(dev, utab, itab, ub, ib, mean, user_ids, seen_lists, K, tar
 
 
 @pytest.mark.parametrize("kind", ["const", "two_values", "quantised", "ascending", "descending", "random", "mostly_seen", "dense_seen"])
-@pytest.mark.parametrize("path", ["panel", "gemm"])
-@pytest.mark.parametrize("I,K,T,config", [(5000, 100, 1, 0), (40000, 100, 3, 0), (1300, 256, 4, 1), (9000, 100, 1, 1), (9000, 1, 0, 2), (700, 100, 2, 2), (130, 50, 1, 0)])
+@pytest.mark.parametrize("path,I,K,T,config", [("panel", 5000, 100, 1, 0), ("panel", 40000, 100, 3, 0), ("panel", 1300, 256, 4, 1), ("panel", 9000, 100, 1, 1),
+                                               ("panel", 9000, 1, 0, 2), ("panel", 700, 100, 2, 2), ("panel", 130, 50, 1, 0),
+                                               ("gemm", 5000, 100, 1, 0), ("gemm", 40000, 100, 3, 0), ("gemm", 130, 50, 1, 0)])
 def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path):
     """The register-resident panel form (score_panel.h; config 1: 32-row workgroups, config 2: the narrow panels) and GEMM +
     selection (config 0 only) on rows built to stress their threshold logic: constant
@@ -1967,8 +1968,6 @@ def test_fused_sweep_stress(gpu_device, kind, I, K, T, config, path):
     The scores are made of exact pieces (zero dot product + item bias) where the pattern matters."""
     rng = np.random.default_rng(I + K)
     nu, d = 90, 16
-    if path == "gemm" and config:
-        pytest.skip("the workgroup-shape knobs belong to the panel form")
     req = {"path": "gemm"} if path == "gemm" else dict({"path": "panel", "panel_rows": 32 if config == 1 else 16}, **({"panel_ntw": 8} if config == 2 else {}))
     if True:
         utab = np.zeros((nu, d), np.float32)
