@@ -3,7 +3,7 @@
 # to the last kernel's end against the sum of the kernel durations, from rocprofv3's kernel trace.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/ct_$$
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-topk --steps 20 --warmup 5 "$@" > gpurun_out/ct_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-topk --no-also --no-parity --steps 20 --warmup 5 "$@" > gpurun_out/ct_bench.json 2>/dev/null
 f=$(ls $out/*/*kernel_trace.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -3,7 +3,7 @@
 # the multi-phase form (F bpr B).  Extra arguments go to bench.py; RK_LDS_NO_FUSE=1 in the environment selects the former.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/st_$$
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-parity --steps 64 --warmup 8 --graph-steps 0 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-parity --no-also --no-topk --steps 64 --warmup 8 --graph-steps 0 "$@" > /dev/null 2>&1
 f=$(ls $out/*/*kernel_trace.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
