@@ -409,7 +409,7 @@ def worker(args):
             from recad_amd.sharded2d import Grid2DLightGCN
             sharded = Grid2DLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g, victim.embedding_user.weight,
                                      victim.embedding_item.weight, device=dev, grid_rows=args.grid_rows or None, reduce=args.reduce,
-                                     deterministic=bool(args.deterministic))
+                                     deterministic=bool(args.deterministic), force_collectives=args.force_collectives)
         else:
             sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
                                       victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
@@ -539,7 +539,7 @@ def worker(args):
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
         traffic = traffic_src = None
         tkey = f"{args.workload}_{args.graph}_d{args.dim}" + ("_lds" if lds is not None else "")
-        for tname in ("r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+        for tname in ("r04_spmm_traffic.json", "r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 try:

@@ -120,7 +120,7 @@ class Grid2DLightGCN(ShardedLightGCN):
     """Same interface as ShardedLightGCN (train_epoch / tables / evaluate / describe), 2-D tiled propagation."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None):
+                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None, force_collectives=False):
         on = dist.is_available() and dist.is_initialized()
         self.group = None
         self.rank = dist.get_rank() if on else 0
@@ -136,17 +136,20 @@ class Grid2DLightGCN(ShardedLightGCN):
         if chunks is None:
             # (like the 1-D trainer: overlap only pays when there is a collective to hide and the blocks are big)
             per_rank = self.N // self.world
-            chunks = 4 if (self.world > 1 and per_rank >= (1 << 17)) else 2 if (self.world > 1 and per_rank >= 4096) else 1
+            coll = self.world > 1 or (bool(force_collectives) and on)
+            chunks = 4 if (coll and per_rank >= (1 << 17)) else 2 if (coll and per_rank >= 4096) else 1
         self.layout = lay = GridLayout(self.N, self.world, grid_rows, chunks)
         self.reduce_mode = "ordered" if deterministic else reduce
         self.deterministic = bool(deterministic)
-        self.force_collectives = False
+        # W == 1 (and groups of one rank) normally short-circuit every collective to a copy; force_collectives keeps them: a one-rank
+        # RCCL group on a single-GPU box then exercises the real reduce_scatter / all_gather / all_reduce calls and their async handles
+        self.force_collectives = bool(force_collectives) and on
         self.gather_mode = "collective"
         self.device = torch.device(device) if device is not None else user_emb.device
         self.gi, self.gj = lay.coords(self.rank)
         # EVERY rank creates EVERY group, in the same order (torch.distributed requires it); keep the two this rank is in
         self.col_group = self.row_group = None
-        if on and self.world > 1:
+        if on and (self.world > 1 or self.force_collectives):
             for j in range(lay.Pc):
                 g_ = dist.new_group([i * lay.Pc + j for i in range(lay.Pr)])
                 if j == self.gj:
@@ -193,7 +196,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         return self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "gloo"
 
     def _all_reduce(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         if self._host():
             h = t.cpu()
@@ -204,7 +207,7 @@ class Grid2DLightGCN(ShardedLightGCN):
 
     def _gather_full(self, local, out_full):
         """all-gather over ALL ranks in rank order (tables / evaluation): out_full[b * Mb + q] = row q of rank b"""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             out_full.copy_(local)
         elif self._host():
             h = torch.empty(out_full.shape, dtype=out_full.dtype)
@@ -216,7 +219,7 @@ class Grid2DLightGCN(ShardedLightGCN):
 
     def _gather_col(self, x_own):
         """x[C_j] from the column group's blocks"""
-        if self.layout.Pr == 1:
+        if self.layout.Pr == 1 and not self.force_collectives:
             return x_own
         if self._host():
             h = torch.empty(self.xcol.shape, dtype=self.xcol.dtype)
@@ -230,7 +233,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         """out = sum over the row group of the members' partial blocks destined to this rank (partial: [Pc * rows, d], out:
         [rows, d]).  async_op (RCCL / gloo collective form only): returns the work handle instead of waiting."""
         lay = self.layout
-        if lay.Pc == 1:
+        if lay.Pc == 1 and not self.force_collectives:
             out.copy_(partial)
             return None
         if self.reduce_mode == "ordered":
@@ -265,7 +268,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         for c in range(lay.C):
             part = self.partial[c * lay.Pc * lay.Mc:(c + 1) * lay.Pc * lay.Mc]
             self.ops.spmm(self.tiles[c], x_col, y=part)
-            w = self._reduce_rows(part, out[c * lay.Mc:(c + 1) * lay.Mc], async_op=lay.C > 1)
+            w = self._reduce_rows(part, out[c * lay.Mc:(c + 1) * lay.Mc], async_op=lay.C > 1 or self.force_collectives)
             if w is not None:
                 pending.append(w)
         for w in pending:
@@ -318,7 +321,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         self._forward()
         rows = plan["rows"]
         light_rows, ego_rows = rows[: 3 * nb], rows[3 * nb: 6 * nb]
-        mask = own3 if self.world > 1 else None
+        mask = own3 if (self.world > 1 or self.force_collectives) else None
         ops.gather_rows(self.s, local3, mask, light_rows)
         ops.gather_rows(self.e0, local3, mask, ego_rows)
         self._all_reduce(rows[: 6 * nb])
