@@ -435,7 +435,7 @@ def worker(args):
     if args.warmup > 0:
         wp = run(0, args.warmup)
         if want_parity:
-            warm_losses = wp.sum(dim=1).double().cpu().numpy()   # (the loss buffer is reused by the timed call)
+            warm_losses = wp.sum(dim=1).double()   # device-side copy now (the loss buffer is reused by the timed call), read back after the timing
     barrier()
     t0 = time.perf_counter()
     partials = run(args.warmup, args.steps)
@@ -444,7 +444,7 @@ def worker(args):
     run_losses = run_tables = None
     if want_parity:   # what the timed path produced, to be laid next to the oracle below (outside the timed region)
         tl = partials.sum(dim=1).double().cpu().numpy()
-        run_losses = tl if warm_losses is None else np.concatenate([warm_losses, tl])
+        run_losses = tl if warm_losses is None else np.concatenate([warm_losses.cpu().numpy(), tl])
         if args.warmup + args.steps == n_par:
             run_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (victim.embedding_user.weight, victim.embedding_item.weight))
     if world > 1:
