@@ -308,6 +308,9 @@ int rk_pair_scores(int32_t dim, const float *utab, const float *itab, const floa
 /* Dense torch.optim.Adam step on one tensor (recad/utils.py:181-183): t = 1-based step. */
 int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
                  float beta1, float beta2, float eps, void *stream);
+/* the same, coefficients {lr / (1 - beta1^t), sqrt(1 - beta2^t)} from device float[2] (rk_adam_coef_advance): for captured steps (ABI 8) */
+int rk_adam_step_dev(int64_t n, float *param, const float *grad, float *m, float *v, const float *coef, float beta1, float beta2, float eps,
+                     void *stream);
 
 /* Full-catalog scoring + top-K + target rank for a block of users: replaces the per-user
  * loop of Normal.user_item_model_generate, recad/workflow/normal.py:57-93.

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "rk_pair_scores": [_I32, _P, _P, _P, _P, _F, _P, _P, _I64, _P, _F, C.c_uint64, _P],
     "rk_score_matrix": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _F, C.c_uint64, _P, _P],
     "rk_adam_step": [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P],
+    "rk_adam_step_dev": [_I64, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "rk_score_topk_plan": [_I32, _I32, _I32, _I32, _I32, C.POINTER(ScorePlan), C.POINTER(ScorePlan)],
     "rk_score_topk": [_I32, _P, _I32, _P, _P, _I32, _P, _P, _F, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, C.POINTER(ScorePlan), _P, _P],
     "rk_bpr_sample": [_I32, _I32, _P, _P, _I64, C.c_uint64, _P, _P, _P, _P, _P],

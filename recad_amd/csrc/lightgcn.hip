@@ -386,6 +386,30 @@ __global__ void adam_l0_kernel(long long n, float *p, float *gego, float *gprop,
     }
 }
 
+// the same with the step's coefficients {lr / (1 - b1^t), sqrt(1 - b2^t)} read from device memory (rk_adam_coef_advance): a
+// captured step cannot take t from the host
+__global__ void adam_dev_kernel(long long n, float *p, const float *g, float *m, float *v, const float *coef, float b1, float b2, float eps)
+{
+    const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
+    const float step_size = coef[0], bc2s = coef[1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, mm, vv, g[i], w1, b2, w2, step_size, bc2s, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+RK_EXPORT int rk_adam_step_dev(int64_t n, float *param, const float *grad, float *m, float *v, const float *coef, float beta1, float beta2,
+                               float eps, void *stream)
+{
+    if (n <= 0) return RK_OK;
+    if (!param || !grad || !m || !v || !coef) RK_FAIL(RK_EINVAL, "rk_adam_step_dev: bad arguments");
+    const int grid = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long long)n, param, grad, m, v, coef, beta1, beta2, eps);
+    RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
 RK_EXPORT int rk_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, int32_t t, float lr,
                            float beta1, float beta2, float eps, void *stream)
 {

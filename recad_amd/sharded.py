@@ -194,9 +194,14 @@ class HipOps:
         _lib.check(_lib.lib().rk_adam_coef_advance(_lib.ptr(coef), _lib.ptr(counter), float(lr), float(b1), float(b2), _lib.stream_ptr()),
                    "rk_adam_coef_advance")
 
-    def adam(self, p, g, m, v, t, lr, b1, b2, eps):
+    def adam(self, p, g, m, v, t, lr, b1, b2, eps, coef=None):
         """dense torch.optim.Adam step t (1-based) on a contiguous block (the 2-D trainer's owned rows: its gradient only exists
-        after a reduce-scatter, so it cannot ride in an SpMM epilogue)"""
+        after a reduce-scatter, so it cannot ride in an SpMM epilogue); coef: device float[2] holding the step's coefficients
+        (adam_advance) instead of t -- what a captured step uses"""
+        if coef is not None:
+            _lib.check(_lib.lib().rk_adam_step_dev(p.numel(), _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(coef), float(b1),
+                                                   float(b2), float(eps), _lib.stream_ptr()), "rk_adam_step_dev")
+            return
         _lib.check(_lib.lib().rk_adam_step(p.numel(), _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), int(t), float(lr), float(b1),
                                            float(b2), float(eps), _lib.stream_ptr()), "rk_adam_step")
 
@@ -464,12 +469,16 @@ class ShardedLightGCN:
                           "rows": rows}
         return self._plan
 
+    def _bpr_pos(self, nodes):
+        """row of a node in the replicated gradient buffers the BPR kernel scatters into"""
+        return self.layout.pos(nodes)
+
     def _epoch_plan(self, users, pos, neg, batch):
         """Everything index-shaped a step needs, for the whole epoch at once (no per-step host arithmetic):
         gathered positions of the minibatch nodes, and which compact rows this rank owns."""
         lay, dev = self.layout, self.device
         nodes = torch.stack([users.to(dev).long(), pos.to(dev).long() + self.U, neg.to(dev).long() + self.U])  # [3, n]
-        posn = lay.pos(nodes).contiguous()                                                        # gathered positions
+        posn = self._bpr_pos(nodes).contiguous()                                                  # gathered positions
         own_f = ((nodes % self.world) == self.rank).to(torch.float32)
         local = (nodes // self.world)
         ep = {"pos": posn, "own_f": own_f, "local": local}

@@ -27,7 +27,8 @@ BPR runs replicated like in the 1-D trainer (B is tiny next to the graph): the m
 replicated, grid-column-major gprop / gego buffers, so the first backward layer's x[C_j] is a local view (no gather).
 
 Per step: L all-gathers + L reduce-scatters (forward), L reduce-scatters + (L-1) all-gathers (backward), one [6B, d] all-reduce.
-Evaluation is user-sharded exactly like the 1-D trainer's (inherited).  The step is launched eagerly (no capture yet)."""
+Evaluation is user-sharded exactly like the 1-D trainer's (inherited), and so is the step capture (a full-batch step with its
+collectives recorded once, replayed per step; eager fallback)."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -120,7 +121,7 @@ class Grid2DLightGCN(ShardedLightGCN):
     """Same interface as ShardedLightGCN (train_epoch / tables / evaluate / describe), 2-D tiled propagation."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None, force_collectives=False):
+                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None, force_collectives=False, capture=None):
         on = dist.is_available() and dist.is_initialized()
         self.group = None
         self.rank = dist.get_rank() if on else 0
@@ -180,7 +181,11 @@ class Grid2DLightGCN(ShardedLightGCN):
         self.t = 0
         self._plan = None
         self._graph = None
-        self.capture = False
+        self._graph_failed = False
+        self._ysel = 0
+        # step capture like the 1-D trainer's (kernels + collectives recorded once into a torch.cuda.CUDAGraph, replayed per step with
+        # staged indices and device-resident Adam coefficients); None = wherever it can work, eager fallback if the capture fails
+        self.capture = capture
         self.load_tables(user_emb, item_emb)
 
     def describe(self):
@@ -294,43 +299,31 @@ class Grid2DLightGCN(ShardedLightGCN):
     def reserve(self, n_triplets, batch):
         n_steps = (int(n_triplets) + batch - 1) // batch
         if self._plan is None or self._plan["cap_steps"] < n_steps or self._plan["batch"] != batch:
+            # `rows` is baked into the captured step graph: allocated once per batch size (see ShardedLightGCN.reserve)
+            rows = None if (self._plan is None or self._plan["batch"] != batch) else self._plan["rows"]
+            if rows is None:
+                rows = torch.zeros(6 * batch, self.d, device=self.device, dtype=torch.float32)   # light rows | ego rows of the minibatch
+                self._graph = None
             self._plan = {"cap_steps": n_steps, "batch": batch,
-                          "loss": torch.zeros(n_steps, _lib.RK_LOSS_PARTIALS, device=self.device, dtype=torch.float32),
-                          "rows": torch.zeros(6 * batch, self.d, device=self.device, dtype=torch.float32)}
+                          "loss": torch.zeros(n_steps, _lib.RK_LOSS_PARTIALS, device=self.device, dtype=torch.float32), "rows": rows}
         return self._plan
 
-    def _epoch_plan(self, users, pos, neg, batch):
-        lay, dev = self.layout, self.device
-        nodes = torch.stack([users.to(dev).long(), pos.to(dev).long() + self.U, neg.to(dev).long() + self.U])   # [3, n]
-        ep = {"full": lay.full_pos(nodes).contiguous(), "own": ((nodes % self.world) == self.rank).to(torch.float32),
-              "local": (nodes // self.world).contiguous()}
-        if self.deterministic:
-            n = nodes.shape[1]
-            if 3 * batch >= (1 << 20) or self.world * lay.Mb >= (1 << 24):
-                raise ValueError("deterministic scatter: batches of < 349525 triplets and fewer than 2^24 gathered rows")
-            ep["b_in"] = torch.arange(n, device=dev) % batch
-        return ep
+    def _bpr_pos(self, nodes):
+        return self.layout.full_pos(nodes)     # the replicated buffers are grid-column-major
 
-    def step(self, plan, ep, s0, nb, k):
+    def _step_core(self, nb, idx_local3, idx_own3, idx_pos3, lp, keys, adam):
+        """One train step given the minibatch's 3*nb role-major index rows (slices of the epoch plan when eager, the fixed staging
+        buffers when captured: the inherited step() / _replay() drive it exactly like the 1-D trainer's)."""
         ops, L = self.ops, self.L
-        lp = plan["loss"][k]
-        self.t += 1
-        sl = slice(s0, s0 + nb)
-        cat3 = lambda t: t[:, sl].reshape(-1).contiguous()          # role-major [3 * nb]
-        local3, own3, full3 = cat3(ep["local"]), cat3(ep["own"]), cat3(ep["full"])
         self._forward()
-        rows = plan["rows"]
+        rows = self._plan["rows"]
         light_rows, ego_rows = rows[: 3 * nb], rows[3 * nb: 6 * nb]
-        mask = own3 if (self.world > 1 or self.force_collectives) else None
-        ops.gather_rows(self.s, local3, mask, light_rows)
-        ops.gather_rows(self.e0, local3, mask, ego_rows)
+        mask = idx_own3 if (self.world > 1 or self.force_collectives) else None
+        ops.gather_rows(self.s, idx_local3, mask, light_rows)
+        ops.gather_rows(self.e0, idx_local3, mask, ego_rows)
         self._all_reduce(rows[: 6 * nb])
-        self.e0_full.index_copy_(0, full3, ego_rows)               # the minibatch's rows of E0 (reg term); duplicates carry equal values
-        keys = None
-        if self.deterministic:
-            kk = (full3.view(3, nb) << 20) | (3 * ep["b_in"][sl].unsqueeze(0) + torch.arange(3, device=self.device).unsqueeze(1))
-            keys = torch.sort(kk.reshape(-1)).values.contiguous()
-        ru, rp, rn = full3[:nb], full3[nb:2 * nb], full3[2 * nb:]
+        self.e0_full.index_copy_(0, idx_pos3, ego_rows)            # the minibatch's rows of E0 (reg term); duplicates carry equal values
+        ru, rp, rn = idx_pos3[:nb], idx_pos3[nb:2 * nb], idx_pos3[2 * nb:3 * nb]
         ops.bpr(self.d, L, self.lam, light_rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp, keys=keys)
         # backward: t_1 = g + A g, ..., grad = gego + A t_{L-1}; the first layer's x[C_j] is a view of the replicated gprop
         x_col = self.gprop[self.col_full]
@@ -339,11 +332,7 @@ class Grid2DLightGCN(ShardedLightGCN):
             y = self._layer(x_col, self.ybuf[j & 1])
             y.add_((self.gego if last else self.gprop)[self.own_full])
             if last:
-                ops.adam(self.e0, y, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+                ops.adam(self.e0, y, self.m, self.v, adam["t"], adam["lr"], adam["b1"], adam["b2"], adam["eps"], coef=adam.get("coef"))
             else:
                 x_col = self._gather_col(y)
-        ops.zero_rows(self.gprop, self.gego, full3)
-        return lp
-
-    def _capture_ok(self):
-        return False
+        ops.zero_rows(self.gprop, self.gego, idx_pos3)

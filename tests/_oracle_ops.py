@@ -36,7 +36,7 @@ class OracleOps:
             for k, arr in (("p", p), ("m", m), ("v", vv)):
                 adam[k].copy_(torch.from_numpy(arr))
 
-    def adam(self, p, g, m, v, t, lr, b1, b2, eps):
+    def adam(self, p, g, m, v, t, lr, b1, b2, eps, coef=None):
         pn, mn, vn = (np.ascontiguousarray(a.numpy()) for a in (p, m, v))
         orc.adam(pn, np.ascontiguousarray(g.numpy()), mn, vn, t, lr, b1, b2, eps)
         for dst, arr in ((p, pn), (m, mn), (v, vn)):

@@ -921,6 +921,32 @@ def test_grid2d_trainer_hip(gpu_device, tmp_path, world, grid_rows, reduce):
                         res["users"], res["items"])
 
 
+def test_grid2d_step_capture_matches_eager(gpu_device):
+    """The 2-D trainer's captured step (tile SpMMs, the [6B, d] all-reduce, reduce-scatter / all-gather calls and the dense Adam with
+    device-resident coefficients recorded once, replayed per step) against its eager step: ordered scatter and ordered reduce, so
+    losses and tables must agree bit for bit; a ragged last step and a second, longer epoch in between."""
+    from recad_amd.sharded2d import Grid2DLightGCN
+    g = G.load("lightgcn_game_d64_tg")
+    U, I, d, L = int(g["n_users"]), int(g["n_items"]), int(g["dim"]), int(g["layers"])
+    csr = orc.coo_to_csr(U + I, g["graph_row"], g["graph_col"], g["graph_val"])
+    u0, i0 = G.lightgcn_init(g)
+    rng = np.random.default_rng(21)
+    B, n = 256, 256 * 7 + 50
+    users, pos, neg = (torch.from_numpy(rng.integers(0, hi, n)).to(gpu_device) for hi in (U, I, I))
+    outs = []
+    for capture in (False, None):
+        tr = Grid2DLightGCN(U, I, d, L, csr, torch.from_numpy(u0).to(gpu_device), torch.from_numpy(i0).to(gpu_device), chunks=2,
+                            deterministic=True, capture=capture)
+        l1 = tr.train_epoch(users[: 4 * B], pos[: 4 * B], neg[: 4 * B], B).numpy().copy()
+        l2 = tr.train_epoch(users, pos, neg, B).numpy().copy()
+        assert (tr._graph is not None) == (capture is None), "the default must have captured its step"
+        tu, ti = tr.tables()
+        outs.append((l1, l2, tu.cpu().numpy(), ti.cpu().numpy(), tr.t))
+    a, b = outs
+    assert a[4] == b[4] == 4 + 8
+    assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
+
+
 def test_sharded_ordered_scatter_same_bits_for_every_world_size(gpu_device, tmp_path):
     """rk_bpr_rows_ordered in the row-sharded trainer (deterministic=True): no float atomics anywhere in the step, every
     per-row sum in a fixed order that does not depend on the partition -- so the trained tables are bit-identical between a
