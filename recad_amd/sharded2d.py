@@ -178,6 +178,9 @@ class Grid2DLightGCN(ShardedLightGCN):
         own0 = (self.gj * lay.Pr + self.gi) * Mb
         self.own_full = slice(own0, own0 + Mb)                                           # this rank's block inside them
         self.col_full = slice(self.gj * lay.Pr * Mb, (self.gj + 1) * lay.Pr * Mb)        # C_j inside them
+        # frontier bitmap over x[C_j] (+ one spill row for the minibatch nodes outside this column part): the first backward layer
+        # gathers the minibatch's rows only (gprop is zero elsewhere); ops without it (the CPU stand-in) gather everything
+        self.row_bits = self.ops.new_row_bits(lay.Pr * Mb + 1, dev) if hasattr(self.ops, "new_row_bits") else None
         self.t = 0
         self._plan = None
         self._graph = None
@@ -264,7 +267,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         return dist.reduce_scatter_tensor(out, partial, group=self.row_group, async_op=async_op) if async_op else \
             dist.reduce_scatter_tensor(out, partial, group=self.row_group)
 
-    def _layer(self, x_col, out):
+    def _layer(self, x_col, out, src_filter=None):
         """out (own block) = (A x)[block]: per row chunk a tile SpMM on x[C_j], then that chunk's reduce-scatter within the row
         group -- issued asynchronously (it runs on the collective's stream behind the SpMM that produced the chunk) while the
         next chunk's SpMM runs; the layer returns when every chunk has landed."""
@@ -272,7 +275,10 @@ class Grid2DLightGCN(ShardedLightGCN):
         pending = []
         for c in range(lay.C):
             part = self.partial[c * lay.Pc * lay.Mc:(c + 1) * lay.Pc * lay.Mc]
-            self.ops.spmm(self.tiles[c], x_col, y=part)
+            if src_filter is not None:
+                self.ops.spmm(self.tiles[c], x_col, y=part, src_filter=src_filter)   # (only the marked rows of x_col are non-zero)
+            else:
+                self.ops.spmm(self.tiles[c], x_col, y=part)
             w = self._reduce_rows(part, out[c * lay.Mc:(c + 1) * lay.Mc], async_op=lay.C > 1 or self.force_collectives)
             if w is not None:
                 pending.append(w)
@@ -327,9 +333,15 @@ class Grid2DLightGCN(ShardedLightGCN):
         ops.bpr(self.d, L, self.lam, light_rows, self.e0_full, self.gprop, self.gego, ru, rp, rn, lp, keys=keys)
         # backward: t_1 = g + A g, ..., grad = gego + A t_{L-1}; the first layer's x[C_j] is a view of the replicated gprop
         x_col = self.gprop[self.col_full]
+        frontier, cidx = self.row_bits, None
+        if frontier is not None:
+            n_col = self.layout.Pr * self.layout.Mb
+            cidx = idx_pos3 - self.col_full.start
+            cidx = torch.where((cidx >= 0) & (cidx < n_col), cidx, torch.full_like(cidx, n_col))
+            ops.mark_rows(frontier, cidx, True)
         for j in range(1, L + 1):
             last = j == L
-            y = self._layer(x_col, self.ybuf[j & 1])
+            y = self._layer(x_col, self.ybuf[j & 1], src_filter=frontier if j == 1 else None)
             y.add_((self.gego if last else self.gprop)[self.own_full])
             if last:
                 ops.adam(self.e0, y, self.m, self.v, adam["t"], adam["lr"], adam["b1"], adam["b2"], adam["eps"], coef=adam.get("coef"))
