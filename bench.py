@@ -77,7 +77,8 @@ def parse(argv=None):
                          "evaluation through workflow.execute(), with the graph / schedule rebuild of the retrain loop itemised")
     ap.add_argument("--rec-epoch", type=int, default=2, help="--workflow: training epochs per (re)train")
     ap.add_argument("--no-also", action="store_true", help="N = 1 default run: skip the short yelp-shaped measurement (`also`)")
-    ap.add_argument("--also-config4", action="store_true", help="N = 1: add the config-4-shaped measurement (1M x 500K x 100M edges) to `also` (~60 s)")
+    ap.add_argument("--no-also-config4", action="store_true",
+                    help="N = 1 default run: skip the config-4-shaped measurement (1M x 500K x 100M edges, ~6 s) inside `also`")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
     a = ap.parse_args(argv)
@@ -603,7 +604,7 @@ def worker(args):
     also = None
     if rank == 0 and world == 1 and sharded is None and args.workload == "ml1m" and not args.no_also:
         also = {"config3_yelp": also_measure(dev, "yelp", 128, args.layers, B)}
-        if args.also_config4:
+        if not args.no_also_config4:
             also["config4"] = also_measure(dev, "config4", 64, args.layers, B, steps=10, warmup=3, eval_users=65536)
     cpu = cpu_aten = parity = None
     if want_parity:

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $o/${tag}_tests.txt; cat $o/${tag}_tests.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep "^{" > $o/${tag}_bench_s20.json
-timeout 600 python bench.py --also-config4 2>/dev/null | grep "^{" > $o/${tag}_bench.json
+timeout 600 python bench.py 2>/dev/null | grep "^{" > $o/${tag}_bench.json
 timeout 300 python bench.py --graph reference --no-cpu-baseline --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_asis.json
 timeout 300 python bench.py --deterministic --no-cpu-baseline --no-topk --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_ordered.json
 RK_LDS_OFF=1 timeout 300 python bench.py --no-cpu-baseline --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_ldsoff.json
