@@ -121,11 +121,17 @@ class Grid2DLightGCN(ShardedLightGCN):
     """Same interface as ShardedLightGCN (train_epoch / tables / evaluate / describe), 2-D tiled propagation."""
 
     def __init__(self, n_users, n_items, dim, n_layers, csr, user_emb, item_emb, lam=1e-4, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None, force_collectives=False, capture=None):
+                 ops=None, device=None, grid_rows=None, reduce="collective", deterministic=False, chunks=None, force_collectives=False, capture=None, probe_rank_world=None):
         on = dist.is_available() and dist.is_initialized()
         self.group = None
         self.rank = dist.get_rank() if on else 0
         self.world = dist.get_world_size() if on else 1
+        # measurement only (scripts/shard_probe.py): act as rank r of a W-rank job WITHOUT a process group -- every collective
+        # becomes a local copy of this rank's own share, so a step costs exactly what the rank computes and launches
+        self._probe = probe_rank_world is not None
+        if self._probe:
+            self.rank, self.world = int(probe_rank_world[0]), int(probe_rank_world[1])
+            on = False
         self.ops = ops or HipOps()
         self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(dim), int(n_layers)
         if self.L < 1:
@@ -204,7 +210,7 @@ class Grid2DLightGCN(ShardedLightGCN):
         return self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "gloo"
 
     def _all_reduce(self, t):
-        if self.world == 1 and not self.force_collectives:
+        if (self.world == 1 and not self.force_collectives) or self._probe:
             return
         if self._host():
             h = t.cpu()
@@ -215,7 +221,9 @@ class Grid2DLightGCN(ShardedLightGCN):
 
     def _gather_full(self, local, out_full):
         """all-gather over ALL ranks in rank order (tables / evaluation): out_full[b * Mb + q] = row q of rank b"""
-        if self.world == 1 and not self.force_collectives:
+        if self._probe:
+            out_full[self.rank * self.layout.Mb:(self.rank + 1) * self.layout.Mb].copy_(local)
+        elif self.world == 1 and not self.force_collectives:
             out_full.copy_(local)
         elif self._host():
             h = torch.empty(out_full.shape, dtype=out_full.dtype)
@@ -229,6 +237,9 @@ class Grid2DLightGCN(ShardedLightGCN):
         """x[C_j] from the column group's blocks"""
         if self.layout.Pr == 1 and not self.force_collectives:
             return x_own
+        if self._probe:
+            self.xcol[self.gi * self.layout.Mb:(self.gi + 1) * self.layout.Mb].copy_(x_own)
+            return self.xcol
         if self._host():
             h = torch.empty(self.xcol.shape, dtype=self.xcol.dtype)
             dist.all_gather_into_tensor(h, x_own.cpu().contiguous(), group=self.col_group)
@@ -243,6 +254,10 @@ class Grid2DLightGCN(ShardedLightGCN):
         lay = self.layout
         if lay.Pc == 1 and not self.force_collectives:
             out.copy_(partial)
+            return None
+        if self._probe:
+            n = out.shape[0]
+            out.copy_(partial[self.gj * n:(self.gj + 1) * n])
             return None
         if self.reduce_mode == "ordered":
             # direct reduce-scatter with a FIXED summation order: block k of every member goes to member k, which adds the Pc

@@ -96,6 +96,30 @@ for W, pr in ((4, 2), (8, 2), (8, 4), (8, 1)):
           f"receives {(lay.Pr - 1 + lay.Pc - 1) * blk / 1e6:.1f} MB per layer (all-gather {(lay.Pr - 1) * blk / 1e6:.1f} + reduce-scatter {(lay.Pc - 1) * blk / 1e6:.1f})", flush=True)
     del tile, x, y
     torch.cuda.empty_cache()
+# a whole train step of rank 0 of a W-rank job with every collective replaced by a local copy of the rank's own share
+# (Grid2DLightGCN(probe_rank_world=...)): what the rank computes and launches per step, captured like the real step
+from recad_amd.sharded2d import Grid2DLightGCN  # noqa: E402
+out["rank0_step_ms"] = {}
+B, steps = 1024, 8
+gen = torch.Generator(device=dev).manual_seed(5)
+tu = torch.randint(0, ds.n_users, (B * (steps + 3),), device=dev, generator=gen)
+tp = torch.randint(0, ds.n_items, (B * (steps + 3),), device=dev, generator=gen)
+tn = torch.randint(0, ds.n_items, (B * (steps + 3),), device=dev, generator=gen)
+ue = torch.randn(ds.n_users, dim, device=dev) * 0.1
+ie = torch.randn(ds.n_items, dim, device=dev) * 0.1
+for W, pr in ((1, 1), (8, 1), (8, 2)):
+    tr = Grid2DLightGCN(ds.n_users, ds.n_items, dim, 3, g, ue, ie, device=dev, grid_rows=pr, probe_rank_world=(0, W))
+    tr.train_epoch(tu[: 3 * B], tp[: 3 * B], tn[: 3 * B], B)      # eager first step, capture, one replay
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    tr.train_epoch(tu[3 * B:], tp[3 * B:], tn[3 * B:], B)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out["rank0_step_ms"][f"{W}:{tr.layout.Pr}x{tr.layout.Pc}"] = {"ms": ms, "chunks": tr.layout.C, "captured": tr._graph is not None}
+    print(f"W={W} grid {tr.layout.Pr} x {tr.layout.Pc}: rank-0 train step WITHOUT communication {ms:.3f} ms (captured: {tr._graph is not None}, {tr.layout.C} chunk(s))", flush=True)
+    del tr
+    torch.cuda.empty_cache()
 base = out["per_layer_ms"]["1"]["ms"]
 for W, v in out["per_layer_ms"].items():
     v["compute_speedup"] = base / v["ms"]
