@@ -206,8 +206,11 @@ class Grid2DLightGCN(ShardedLightGCN):
                 f"one [6B,d] all-reduce; BPR replicated")
 
     # ------------------------------------------------------------------ collectives
+    def _host_staged(self):
+        return False if self._probe else super()._host_staged()
+
     def _host(self):
-        return self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "gloo"
+        return not self._probe and self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "gloo"
 
     def _all_reduce(self, t):
         if (self.world == 1 and not self.force_collectives) or self._probe:

@@ -7,6 +7,7 @@ Also timed (W > 1): the same layer as C x C tiles chained through the `add` epil
 consumer-side-overlap order of ShardedLightGCN._layer -- i.e. the compute price of starting on arrived column blocks."""
 import json
 import sys
+import time
 
 import torch
 
@@ -18,6 +19,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "config4"
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 n_chunks = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+only_step = len(sys.argv) > 5 and sys.argv[5] == "step"      # just the whole-step section
 dev = torch.device("cuda:0")
 big = name in ("c4s", "config4")
 if big:
@@ -32,7 +34,7 @@ N = ds.n_users + ds.n_items
 ops = HipOps()
 out = {"workload": name, "dim": dim, "n_rows": N, "nnz": int(g.col.numel()), "per_layer_ms": {}}
 x_full = None
-for W in (1, 2, 4, 8):
+for W in (() if only_step else (1, 2, 4, 8)):
     lay = RowLayout(N, W, chunks=n_chunks if W > 1 else 1)
     slabs = [ops.make_slab(rp, cl, vl, dev) for rp, cl, vl in build_slab_chunks(g.rowptr, g.col, g.val, 0, lay)]
     x = torch.randn(W * lay.M, dim, device=dev) * 0.1          # the gathered table every rank reads
@@ -75,7 +77,7 @@ for W in (1, 2, 4, 8):
 # the 2-D tiling (recad_amd/sharded2d.py): rank 0's tile A[R_0, C_0] over x[C_0] (Pr * Mb rows), partial of Pc * Mb rows
 from recad_amd.sharded2d import GridLayout, build_tile  # noqa: E402
 out["grid2d_per_layer_ms"] = {}
-for W, pr in ((4, 2), (8, 2), (8, 4), (8, 1)):
+for W, pr in (() if only_step else ((4, 2), (8, 2), (8, 4), (8, 1))):
     lay = GridLayout(N, W, pr)
     tile = ops.make_slab(*build_tile(g.rowptr, g.col, g.val, 0, lay), dev)
     x = torch.randn(lay.Pr * lay.Mb, dim, device=dev) * 0.1
@@ -111,7 +113,6 @@ for W, pr in ((1, 1), (8, 1), (8, 2)):
     tr = Grid2DLightGCN(ds.n_users, ds.n_items, dim, 3, g, ue, ie, device=dev, grid_rows=pr, probe_rank_world=(0, W))
     tr.train_epoch(tu[: 3 * B], tp[: 3 * B], tn[: 3 * B], B)      # eager first step, capture, one replay
     torch.cuda.synchronize()
-    import time
     t0 = time.perf_counter()
     tr.train_epoch(tu[3 * B:], tp[3 * B:], tn[3 * B:], B)
     torch.cuda.synchronize()
@@ -120,7 +121,8 @@ for W, pr in ((1, 1), (8, 1), (8, 2)):
     print(f"W={W} grid {tr.layout.Pr} x {tr.layout.Pc}: rank-0 train step WITHOUT communication {ms:.3f} ms (captured: {tr._graph is not None}, {tr.layout.C} chunk(s))", flush=True)
     del tr
     torch.cuda.empty_cache()
-base = out["per_layer_ms"]["1"]["ms"]
-for W, v in out["per_layer_ms"].items():
-    v["compute_speedup"] = base / v["ms"]
+if not only_step:
+    base = out["per_layer_ms"]["1"]["ms"]
+    for W, v in out["per_layer_ms"].items():
+        v["compute_speedup"] = base / v["ms"]
 print(json.dumps(out))
