@@ -13,9 +13,11 @@ region).  The full-catalog scoring + top-100 + HR@K pass is timed after it ("top
 
 N > 1: `python bench.py --gpus N` starts its own N worker processes (one per GPU, before anything touches a
 GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is a worker itself.
-Default mode `--parallel rows`: ONE training job whose node rows (embedding tables, Adam state, CSR slab)
-are sharded over the N GPUs with RCCL all-gathers between the propagation layers (recad_amd/sharded.py),
-on the largest shardable workload (config-4-shaped: 1M x 500K x 100M edges; `--workload yelp` for the
+Default mode `--parallel rows2d`: ONE training job whose node rows (embedding tables, Adam state) are dealt
+over the N GPUs, every GPU holding a COLUMN SLAB of the adjacency (1 x N grid of recad_amd/sharded2d.py): per
+propagation layer one tile SpMM on the GPU's own block and one chunk-overlapped RCCL reduce-scatter, no
+all-gather (`--parallel rows`: the 1-D row partition with all-gathers, recad_amd/sharded.py), on the largest
+shardable workload (config-4-shaped: 1M x 500K x 100M edges; `--workload yelp` for the
 yelp-shaped one) => "scaling": "strong".  Rank 0 also times the single-GPU fused path on the same workload
 ("same_workload_1gpu") so that the line carries its own like-for-like reference, and `--parallel replicas`
 (one independent retrain job per GPU, no data-path collective) is kept as a labelled extra mode.
@@ -59,10 +61,10 @@ def parse(argv=None):
                     help="ordered (bit-reproducible) gradient scatter instead of float atomics (fused and row-sharded paths; labelled in config)")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
     ap.add_argument("--parallel", default=None, choices=["rows", "rows2d", "replicas"],
-                    help="N>1: node rows sharded over the GPUs with RCCL all-gathers (strong scaling, default); rows2d: the 2-D "
-                         "(Pr x Pc) tiling -- all-gather within column groups, reduce-scatter within row groups (recad_amd/sharded2d.py); "
+                    help="N>1 default: rows2d = the Pr x Pc tiling (recad_amd/sharded2d.py; default grid 1 x N: column slabs, no all-gather, one "
+                         "chunk-overlapped reduce-scatter per layer -- strong scaling); rows: the 1-D row partition with RCCL all-gathers; "
                          "replicas: one independent victim replica per GPU (weak scaling, no data-path collective)")
-    ap.add_argument("--grid-rows", type=int, default=0, help="rows2d: Pr of the Pr x Pc grid (0 = 2 from 4 ranks on, else 1)")
+    ap.add_argument("--grid-rows", type=int, default=0, help="rows2d: Pr of the Pr x Pc grid (0 = 1: column slabs)")
     ap.add_argument("--reduce", default="collective", choices=["collective", "ordered"],
                     help="rows2d: reduce_scatter_tensor (RCCL picks the algorithm) or all-to-all + sum in group-rank order (fixed order)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the workers")
@@ -85,7 +87,7 @@ def parse(argv=None):
     if a.workload is None:
         a.workload = "ml1m" if a.gpus == 1 else "config4"
     if a.parallel is None:
-        a.parallel = "rows" if (a.gpus > 1 or a.force_collectives) else "replicas"
+        a.parallel = "rows2d" if a.gpus > 1 else "rows" if a.force_collectives else "replicas"
     if a.dim is None:
         a.dim = 128 if a.workload == "yelp" else 64
     if a.steps is None:

@@ -16,7 +16,12 @@ name = sys.argv[1] if len(sys.argv) > 1 else "yelp"
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda:0")
-d = synth.make(name)
+if name in ("c4s", "config4"):
+    dd = synth.make_device(name, dev)
+    d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+    del dd
+else:
+    d = synth.make(name)
 ds = dataset.from_config("implicit", name, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], device=dev, graph_source="train")
 g = ds.graph_csr()
 N = ds.n_users + ds.n_items
@@ -42,8 +47,8 @@ y = torch.empty_like(x)
 ref_us = timed(lambda: ops.spmm(slab, x, y=y))
 out["us"][str(dim)] = ref_us
 print(f"{name} d={dim}: one launch, {dim * 4}-byte rows out of a {N * dim * 4 / 1e6:.1f} MB table: {ref_us:.1f} us", flush=True)
-for D in (64, 32):
-    if D >= dim:
+for D in (64, 32, 16):
+    if D >= dim or D * 4 < dim:
         continue
     ns = dim // D
     xs = x.view(N, ns, D).permute(1, 0, 2).contiguous()          # [ns][N][D]
@@ -97,7 +102,7 @@ def build_pieces(cap):
 
 stream = torch.cuda.current_stream().cuda_stream
 for D, un, cap in ((16, 2, 256), (16, 4, 256), (16, 1, 256), (16, 2, 64), (8, 4, 256), (8, 2, 256), (32, 1, 256), (32, 2, 256), (64, 1, 256)):
-    if D >= dim:
+    if D >= dim or (dim < 128 and D * 4 < dim):
         continue
     ns = dim // D
     pieces, split_rows = build_pieces(cap)

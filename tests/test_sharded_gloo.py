@@ -151,7 +151,7 @@ def test_bench_self_launch_dry_run():
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "rows"
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "rows2d"
     # a world that disagrees with --gpus is refused
     env2 = dict(env, RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
