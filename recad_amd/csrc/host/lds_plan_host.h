@@ -9,6 +9,10 @@
 #include <cmath>
 #include <thread>
 #include <vector>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 #include "../../../include/recad_hip.h"
 #include "layout.h"
@@ -52,29 +56,47 @@ static const int kB128Group[4][16] = {
     {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
     {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
 
+// Scratch of colour_group / build_block, one per builder thread and reused across groups and blocks: the builder used to make
+// ~5 000 small allocations per row block, and concurrent malloc / free from the pool's threads serialised the "parallel" section
+// (measured: 16 blocks of 2 ms each took 33 ms on 8 threads; 8 threads of allocation-only work ran no faster than one).
+struct ColourEdge { int u, v, i, c; };
+struct PlanScratch {
+    std::vector<ColourEdge> es;
+    std::vector<int> atL, atR, ccount, path;
+    std::vector<unsigned long long> useL, useR;
+    std::vector<int> cls, pos, len;          // [K][stride] classes / positions of a lane group's chunks, their lengths
+    std::vector<int> slot_pos, slot_len;     // [SL][stride] positions of every slot of the group
+    std::vector<Chunk> chunks, placed;
+};
+
 // Conflict-free order of the entries of the K chunks that share a lane group.  Table row c occupies bank class c mod K
 // (K = 16 / LP rows cover the 64 banks once), so a wave-instruction is conflict-free iff the K chunks read K different
 // classes.  That is an edge colouring of the bipartite multigraph chunks x classes (one edge per entry, colour =
 // position in the chunk's walk): Delta = max(longest chunk, largest class count) colours always suffice (Koenig); built
 // with alternating-path flips.  cls[j][i] = class of entry i of chunk j; pos[j][i] receives its position.  Returns Delta.
-static int colour_group(const std::vector<std::vector<int>> &cls, int K, std::vector<std::vector<int>> &pos)
+// cls / pos: n rows of `stride` ints; row j holds len[j] entries
+static int colour_group(const int *cls, const int *len, int n, int stride, int K, int *pos, PlanScratch &ws)
 {
-    const int n = (int)cls.size();
-    std::vector<int> ccount((size_t)K, 0);
+    std::vector<int> &ccount = ws.ccount;
+    ccount.assign((size_t)K, 0);
     int delta = 0;
     for (int j = 0; j < n; ++j) {
-        delta = std::max(delta, (int)cls[(size_t)j].size());
-        for (int v : cls[(size_t)j]) ++ccount[(size_t)v];
+        delta = std::max(delta, len[j]);
+        for (int i = 0; i < len[j]; ++i) ++ccount[(size_t)cls[(size_t)j * stride + i]];
     }
     for (int v = 0; v < K; ++v) delta = std::max(delta, ccount[(size_t)v]);
-    pos.assign((size_t)n, std::vector<int>());
     if (delta == 0) return 0;
-    struct Edge { int u, v, i, c; };
-    std::vector<Edge> es;
+    typedef ColourEdge Edge;
+    std::vector<Edge> &es = ws.es;
+    es.clear();
     const size_t D = (size_t)delta, W = (D + 63) / 64;
-    std::vector<int> atL((size_t)n * D, -1), atR((size_t)K * D, -1);
+    std::vector<int> &atL = ws.atL, &atR = ws.atR;
+    atL.assign((size_t)n * D, -1);
+    atR.assign((size_t)K * D, -1);
     // used-colour bitmaps per node (bits >= delta preset): the first free colour is one ctz away
-    std::vector<unsigned long long> useL((size_t)n * W, 0ULL), useR((size_t)K * W, 0ULL);
+    std::vector<unsigned long long> &useL = ws.useL, &useR = ws.useR;
+    useL.assign((size_t)n * W, 0ULL);
+    useR.assign((size_t)K * W, 0ULL);
     auto preset = [&](std::vector<unsigned long long> &m, size_t nodes) {
         for (size_t q = 0; q < nodes; ++q)
             for (size_t c = D; c < W * 64; ++c) m[q * W + c / 64] |= 1ULL << (c % 64);
@@ -90,11 +112,10 @@ static int colour_group(const std::vector<std::vector<int>> &cls, int K, std::ve
     auto set_bit = [&](std::vector<unsigned long long> &m, size_t node, int c, bool on) {
         if (on) m[node * W + (size_t)c / 64] |= 1ULL << (c % 64); else m[node * W + (size_t)c / 64] &= ~(1ULL << (c % 64));
     };
-    std::vector<int> path;
+    std::vector<int> &path = ws.path;
     for (int j = 0; j < n; ++j) {
-        pos[(size_t)j].assign(cls[(size_t)j].size(), -1);
-        for (int i = 0; i < (int)cls[(size_t)j].size(); ++i) {
-            const int u = j, v = cls[(size_t)j][(size_t)i];
+        for (int i = 0; i < len[j]; ++i) {
+            const int u = j, v = cls[(size_t)j * stride + i];
             int a = first_free(&useL[(size_t)u * W], &useR[(size_t)v * W]);   // free at both ends: no flip needed
             if (a < 0) {
                 a = first_free(&useL[(size_t)u * W], nullptr);
@@ -129,8 +150,34 @@ static int colour_group(const std::vector<std::vector<int>> &cls, int K, std::ve
             atR[(size_t)v * D + (size_t)a] = eid; set_bit(useR, (size_t)v, a, true);
         }
     }
-    for (const Edge &e : es) pos[(size_t)e.u][(size_t)e.i] = e.c;
+    for (const Edge &e : es) pos[(size_t)e.u * stride + (size_t)e.i] = e.c;
     return delta;
+}
+
+// The pool's threads live for a few milliseconds.  Measured on this image's hosts: the scheduler leaves such short-lived
+// threads on the CPU that created them, and the "parallel" section ran serially (16 row blocks of 1.7 ms each: 28 ms on 8
+// threads, 16 x a 7 ms spin loop: 122 ms).  So every worker is placed on its own CPU of the CALLER's affinity mask (never
+// outside it; the caller's own thread and CPU are left alone).  With it the section takes 7-10 ms.
+static void place_workers(std::vector<std::thread> &pool)
+{
+#if defined(__linux__)
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int self = sched_getcpu();
+    std::vector<int> cpus;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &allowed) && c != self) cpus.push_back(c);
+    if (cpus.empty()) return;
+    for (size_t k = 0; k < pool.size(); ++k) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[k % cpus.size()], &one);
+        pthread_setaffinity_np(pool[k].native_handle(), sizeof(one), &one);   // (best effort: a refusal leaves the thread where it is)
+    }
+#else
+    (void)pool;
+#endif
 }
 
 struct HalfPlan {
@@ -349,7 +396,7 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
     };
     std::vector<BlockOut> blocks(n_blocks_total);
     static const int no_colour = RK_TUNE_INT("RK_LDS_NOCOLOUR", 0);   // tuning: CSR order
-    auto build_block = [&](size_t bi) {
+    auto build_block = [&](size_t bi, PlanScratch &ws) {
         const int h = bi < (size_t)hp[0].n_blk ? 0 : 1;
         const int rb = (int)(bi - (h ? (size_t)hp[0].n_blk : 0));
         const int SL = 64 / hp[h].lp, C = hp[h].chunk;
@@ -361,7 +408,8 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         BlockOut &o = blocks[bi];
         std::vector<int32_t> &pp = o.pp;
         pp.assign((size_t)n_rows + 1, 0);
-        std::vector<Chunk> chunks;
+        std::vector<Chunk> &chunks = ws.chunks;
+        chunks.clear();
         for (int r = r_lo; r < r_hi; ++r) {
             const int b = rp[r], n = rp[r + 1] - b;
             // ceil(n / C) chunks of (almost) equal length: fewer short leftovers than full chunks + a remainder
@@ -420,31 +468,41 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
                     members[best][n_mem[best]++] = c;
                     for (int k = 0; k < K; ++k) load[best * 16 + k] += hist[(c - c0) * 16 + (size_t)k];
                 }
-                std::vector<Chunk> placed(c1 - c0);
+                std::vector<Chunk> &placed = ws.placed;
+                placed.resize(c1 - c0);
                 for (int gi = 0; gi < 4; ++gi)
                     for (int j = 0; j < K; ++j) placed[(size_t)gslots[gi][(size_t)j]] = chunks[members[gi][j]];
                 std::copy(placed.begin(), placed.end(), chunks.begin() + (long)c0);
             }
             // per 16-lane group: its K slots' entries, ordered so that every wave-instruction reads K different classes
-            std::vector<std::vector<int>> slot_pos((size_t)SL);
+            // (flat scratch: row j of cls / pos = slot gslots[gi][j]; slot_pos row = slot of the group)
+            const int stride = C;
+            ws.slot_pos.resize((size_t)SL * stride);
+            ws.slot_len.assign((size_t)SL, 0);
+            ws.cls.resize((size_t)K * stride);
+            ws.pos.resize((size_t)K * stride);
+            ws.len.resize((size_t)K);
             int longest = 0;
             for (int gi = 0; gi < 4; ++gi) {
-                std::vector<std::vector<int>> cls((size_t)K), pos;
+                int *cls = ws.cls.data(), *pos = ws.pos.data(), *len = ws.len.data();
                 for (int j = 0; j < K; ++j) {
                     const size_t c = c0 + (size_t)gslots[gi][(size_t)j];
+                    len[j] = 0;
                     if (c >= c1) continue;
                     const Chunk &ck = chunks[c];
-                    cls[(size_t)j].resize((size_t)ck.len);
-                    for (int k = 0; k < ck.len; ++k) cls[(size_t)j][(size_t)k] = perm[h][(size_t)(col[ck.e_begin + k] - src0)] % K;
+                    len[j] = ck.len;
+                    for (int k = 0; k < ck.len; ++k) cls[(size_t)j * stride + k] = perm[h][(size_t)(col[ck.e_begin + k] - src0)] % K;
                 }
                 if (no_colour) {
-                    pos.assign((size_t)K, std::vector<int>());
-                    for (int j = 0; j < K; ++j) { pos[(size_t)j].resize(cls[(size_t)j].size()); for (size_t k = 0; k < cls[(size_t)j].size(); ++k) pos[(size_t)j][k] = (int)k; }
-                    for (int j = 0; j < K; ++j) longest = std::max(longest, (int)cls[(size_t)j].size());
+                    for (int j = 0; j < K; ++j) { for (int k = 0; k < len[j]; ++k) pos[(size_t)j * stride + k] = k; longest = std::max(longest, len[j]); }
                 } else {
-                    longest = std::max(longest, colour_group(cls, K, pos));
+                    longest = std::max(longest, colour_group(cls, len, K, stride, K, pos, ws));
                 }
-                for (int j = 0; j < K; ++j) slot_pos[(size_t)gslots[gi][(size_t)j]] = pos[(size_t)j];
+                for (int j = 0; j < K; ++j) {
+                    const int sl = gslots[gi][(size_t)j];
+                    ws.slot_len[(size_t)sl] = len[j];
+                    std::copy(pos + (size_t)j * stride, pos + (size_t)j * stride + len[j], ws.slot_pos.begin() + (long)((size_t)sl * stride));
+                }
             }
             const int nb = std::max(1, (longest + 7) / 8);
             const size_t sbase = stream.size();
@@ -453,7 +511,7 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
             for (size_t c = c0; c < c1; ++c) {
                 const Chunk &ck = chunks[c];
                 const int slot = (int)(c - c0);
-                for (int k = 0; k < ck.len; ++k) at(slot, slot_pos[(size_t)slot][(size_t)k]) = (uint16_t)perm[h][(size_t)(col[ck.e_begin + k] - src0)];
+                for (int k = 0; k < ck.len; ++k) at(slot, ws.slot_pos[(size_t)slot * stride + (size_t)k]) = (uint16_t)perm[h][(size_t)(col[ck.e_begin + k] - src0)];
             }
             // padding: the zero row of a class nobody else in the lane group reads at that position
             for (int gi = 0; gi < 4; ++gi)
@@ -514,9 +572,10 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const size_t n_threads = std::min<size_t>(n_blocks_total, env_threads > 0 ? (size_t)env_threads : std::min<unsigned>(hw, 16u));
         std::atomic<size_t> next(0);
-        auto worker = [&]() { for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi); };
+        auto worker = [&]() { PlanScratch ws; for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi, ws); };
         std::vector<std::thread> pool;
         for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker);
+        place_workers(pool);
         worker();
         for (auto &th : pool) th.join();
     }
