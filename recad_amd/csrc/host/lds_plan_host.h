@@ -156,27 +156,34 @@ static int colour_group(const int *cls, const int *len, int n, int stride, int K
 
 // The pool's threads live for a few milliseconds.  Measured on this image's hosts: the scheduler leaves such short-lived
 // threads on the CPU that created them, and the "parallel" section ran serially (16 row blocks of 1.7 ms each: 28 ms on 8
-// threads, 16 x a 7 ms spin loop: 122 ms).  So every worker is placed on its own CPU of the CALLER's affinity mask (never
+// threads, 16 x a 7 ms spin loop: 122 ms).  So every worker places ITSELF on its own CPU of the caller's affinity mask (never
 // outside it; the caller's own thread and CPU are left alone).  With it the section takes 7-10 ms.
-static void place_workers(std::vector<std::thread> &pool)
+// worker_cpus(): the CPUs the caller may use, without the one it is running on (empty: leave the workers where they are);
+// place_self(cpu): first statement of a worker.  (The caller must not set a worker's affinity from outside: a worker that
+// has already finished has thread id 0, and the call would then pin the CALLER.)
+static std::vector<int> worker_cpus()
 {
+    std::vector<int> cpus;
 #if defined(__linux__)
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return cpus;
     const int self = sched_getcpu();
-    std::vector<int> cpus;
     for (int c = 0; c < CPU_SETSIZE; ++c)
         if (CPU_ISSET(c, &allowed) && c != self) cpus.push_back(c);
-    if (cpus.empty()) return;
-    for (size_t k = 0; k < pool.size(); ++k) {
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(cpus[k % cpus.size()], &one);
-        pthread_setaffinity_np(pool[k].native_handle(), sizeof(one), &one);   // (best effort: a refusal leaves the thread where it is)
-    }
+#endif
+    return cpus;
+}
+static void place_self(int cpu)
+{
+#if defined(__linux__)
+    if (cpu < 0) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    sched_setaffinity(0, sizeof(one), &one);   // (the calling thread; best effort: a refusal leaves it where it is)
 #else
-    (void)pool;
+    (void)cpu;
 #endif
 }
 
@@ -572,11 +579,11 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const size_t n_threads = std::min<size_t>(n_blocks_total, env_threads > 0 ? (size_t)env_threads : std::min<unsigned>(hw, 16u));
         std::atomic<size_t> next(0);
-        auto worker = [&]() { PlanScratch ws; for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi, ws); };
+        auto worker = [&](int cpu) { place_self(cpu); PlanScratch ws; for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi, ws); };
+        const std::vector<int> cpus = worker_cpus();
         std::vector<std::thread> pool;
-        for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker);
-        place_workers(pool);
-        worker();
+        for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker, cpus.empty() ? -1 : cpus[(k - 1) % cpus.size()]);
+        worker(-1);
         for (auto &th : pool) th.join();
     }
     std::vector<uint16_t> stream;   // all blocks' column streams, 16-byte units

@@ -246,3 +246,24 @@ def test_multi_phase_queues_cover_the_launch_and_cannot_deadlock(shape, dim, n_c
             done_items += 1
             running[b] = (q, head[q]); head[q] += 1
         assert done_items == total and not running, (resident, done_items, total)
+
+
+def test_plan_builder_leaves_the_callers_affinity_alone():
+    """The builder places its pool's short-lived workers on CPUs of the caller's mask (host/lds_plan_host.h: place_self).  A first
+    version set the workers' affinity from OUTSIDE: a worker that had already finished has thread id 0, and the call then pinned
+    the CALLER -- every later thread and child process of the host program inherited one CPU.  Tiny graphs (more threads than
+    work: workers exit at once) are the case that showed it."""
+    import os
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity on this platform")
+    before = os.sched_getaffinity(0)
+    rng = np.random.default_rng(7)
+    for k in range(40):
+        U, I = int(rng.integers(20, 400)), int(rng.integers(20, 400))
+        deg = rng.integers(1, min(I, 12), U)
+        ptr = np.zeros(U + 1, dtype=np.int64)
+        ptr[1:] = np.cumsum(deg)
+        idx = np.concatenate([np.sort(rng.choice(I, size=int(n), replace=False)) for n in deg])
+        words, _ = build_plan(U, I, *norm_adj_csr(U, I, ptr, idx), 64)
+        assert words is not None
+        assert os.sched_getaffinity(0) == before, k
