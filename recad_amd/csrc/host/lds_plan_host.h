@@ -580,7 +580,8 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         const size_t n_threads = std::min<size_t>(n_blocks_total, env_threads > 0 ? (size_t)env_threads : std::min<unsigned>(hw, 16u));
         std::atomic<size_t> next(0);
         auto worker = [&](int cpu) { place_self(cpu); PlanScratch ws; for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi, ws); };
-        const std::vector<int> cpus = worker_cpus();
+        static const int pin = RK_TUNE_INT("RK_LDS_PLAN_PIN", 1);   // tuning: 0 = leave the workers to the scheduler
+        const std::vector<int> cpus = pin ? worker_cpus() : std::vector<int>();
         std::vector<std::thread> pool;
         for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker, cpus.empty() ? -1 : cpus[(k - 1) % cpus.size()]);
         worker(-1);
