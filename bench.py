@@ -53,6 +53,10 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--graph-steps", type=int, default=32, help="train steps per hipGraph replay (0 = plain launches)")
+    ap.add_argument("--spmm", default="auto", choices=["auto", "lds", "csr"],
+                    help="LightGCN propagation kernel: auto (the library's choice), lds (LDS-resident sliced SpMM where the graph qualifies), "
+                         "csr (row gather) -- A/B of the two forms on one graph")
+    ap.add_argument("--fuse-layers", action="store_true", help="LDS path: the L layers of a pass as one multi-phase launch (opt-in form, measured slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle replay of the timed path (parity object, cpu_baseline_port)")
     ap.add_argument("--parity-steps", type=int, default=0, help="oracle steps laid next to the timed run (0 = 25 at ml1m size, 3 at yelp size)")
@@ -377,6 +381,8 @@ def worker(args):
     victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers,
                                deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
     victim.graph_steps = args.graph_steps
+    victim.use_lds = {"auto": "auto", "lds": True, "csr": False}[args.spmm]
+    victim.fuse_layers = bool(args.fuse_layers)
     g = ds.graph_csr()
     N, nnz = g.n_rows, g.nnz
     need = (args.steps + args.warmup) * B
@@ -645,6 +651,7 @@ def worker(args):
             v2 = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers,
                                    deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
             v2.graph_steps = args.graph_steps
+            v2.use_lds, v2.fuse_layers = victim.use_lds, victim.fuse_layers
             v2.embedding_user.weight.data.copy_(torch.from_numpy(init_tables[0]))
             v2.embedding_item.weight.data.copy_(torch.from_numpy(init_tables[1]))
             w2 = min(args.warmup, max(n_par // 5, 0))

@@ -5,7 +5,6 @@ orchestration only: parameter ownership (nn.Embedding, so .to()/state_dict() beh
 the reference), the optimizer object, and the C-ABI handle.
 """
 import ctypes as C
-import os
 
 import torch
 from torch import nn
@@ -150,10 +149,10 @@ class LightGCN(BaseVictim):
             self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ws["tpos"] = g.transpose_index() if self.graph_dropout else None
         # LDS-resident sliced propagation (csrc/spmm_lds.h) when the graph qualifies: bipartite normalised binary adjacency
-        # whose class tables fit a CU's LDS (ml1m / Amazon-game size); RK_LDS_OFF=1 keeps the row-gather kernel (A/B)
+        # whose class tables fit a CU's LDS (ml1m / Amazon-game size); use_lds = False keeps the row-gather kernel (bench.py --spmm csr)
         lds = None
         want_lds = self.use_lds if self.use_lds != "auto" else g.nnz >= 24 * N
-        if want_lds and self.n_layers >= 1 and not self.graph_dropout and not os.environ.get("RK_LDS_OFF"):
+        if want_lds and self.n_layers >= 1 and not self.graph_dropout:
             lds = g.lds_plan(d)
         ws["lds"] = lds
         # the row-gather kernel's schedule (host-built) only when this handle will launch it
@@ -161,7 +160,7 @@ class LightGCN(BaseVictim):
         ws["spmm_scratch"] = None if lds else g.new_scratch(d)  # this handle's own long-row counters / partial slots
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
-        fuse = bool(lds) and (bool(self.fuse_layers) or bool(os.environ.get("RK_LDS_FUSE"))) and self.n_layers >= 2   # (RK_LDS_FUSE=1: A/B runs of bench.py)
+        fuse = bool(lds) and bool(self.fuse_layers) and self.n_layers >= 2   # (bench.py --fuse-layers for A/B runs)
         ws["lds_sync"] = torch.zeros(_lib.RK_LDS_SYNC_WORDS, device=dev, dtype=torch.int32) if fuse else None   # this handle's own hand-off counters
         for k in ("e0s", "ms", "vs"):   # sliced working copies of E0 and the Adam moments
             ws[k] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None

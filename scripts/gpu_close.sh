@@ -14,8 +14,8 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep "^
 timeout 600 python bench.py 2>/dev/null | grep "^{" > $o/${tag}_bench.json
 timeout 300 python bench.py --graph reference --no-cpu-baseline --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_asis.json
 timeout 300 python bench.py --deterministic --no-cpu-baseline --no-topk --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_ordered.json
-RK_LDS_OFF=1 timeout 300 python bench.py --no-cpu-baseline --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_ldsoff.json
-RK_LDS_FUSE=1 timeout 300 python bench.py --no-cpu-baseline --no-also --no-topk 2>/dev/null | grep "^{" > $o/${tag}_bench_fused_layers.json
+timeout 300 python bench.py --spmm csr --no-cpu-baseline --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_ldsoff.json
+timeout 300 python bench.py --fuse-layers --no-cpu-baseline --no-also --no-topk 2>/dev/null | grep "^{" > $o/${tag}_bench_fused_layers.json
 timeout 300 python bench.py --workload yelp --no-cpu-baseline 2>/dev/null | grep "^{" > $o/${tag}_bench_yelp_d128.json
 timeout 400 python bench.py --workload c4s --no-cpu-baseline 2>/dev/null | grep "^{" > $o/${tag}_bench_c4s.json
 timeout 600 python bench.py --workload config4 --no-cpu-baseline --eval-users 65536 2>/dev/null | grep "^{" > $o/${tag}_bench_config4.json

@@ -8,7 +8,7 @@ timeout 60 python scripts/lds_multi_probe.py lightgcn_dev_d64 2 2>&1 | grep -v a
 timeout 60 python scripts/lds_multi_probe.py lightgcn_game_d64_tg 3 --time 2>&1 | grep -v amdgpu.ids | tail -8
 timeout 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_layers or timed_path or ncf_train_golden" 2>&1 | tail -15 > $o/${tag}_tests.txt; cat $o/${tag}_tests.txt
 for rep in 1 2; do
-  RK_LDS_FUSE=1 timeout 120 python bench.py --no-cpu-baseline --no-topk --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_fused_$rep.json
+  timeout 120 python bench.py --fuse-layers --no-cpu-baseline --no-topk --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_fused_$rep.json
   timeout 120 python bench.py --no-cpu-baseline --no-topk --no-also 2>/dev/null | grep "^{" > $o/${tag}_bench_unfused_$rep.json
 done
 python3 - <<PY
