@@ -99,10 +99,15 @@ __host__ __device__ inline AdamCoef adam_coef(int t, float lr, float b1, float b
     return c;
 }
 
-// One element of torch.optim.Adam (lerp / addcmul / addcdiv order).
+// One element of torch.optim.Adam (lerp / addcmul / addcdiv order).  Every operation is rounded on its own (no fused
+// multiply-add), like the oracle's orc_adam (gcc -ffp-contract=off): left to the compiler, `v * b2 + w2 * g * g` was
+// contracted one way in one kernel and another way in the next (the vector and the scalar loop of one kernel differed in the
+// last bit), so the Adam paths -- SpMM epilogues, standalone kernels, captured and eager steps -- did not agree with each other
+// or with the oracle to the bit on the same gradient.  (Division and square root are correctly rounded: hipcc's default.)
 __device__ __forceinline__ void adam_elem(float &p, float &m, float &v, float g, float w1, float b2, float w2,
                                           float step_size, float bc2s, float eps)
 {
+#pragma clang fp contract(off)
     m = m + w1 * (g - m);
     v = v * b2 + w2 * g * g;
     float denom = sqrtf(v) / bc2s + eps;

@@ -388,11 +388,30 @@ __global__ void adam_l0_kernel(long long n, float *p, float *gego, float *gprop,
 
 // the same with the step's coefficients {lr / (1 - b1^t), sqrt(1 - b2^t)} read from device memory (rk_adam_coef_advance): a
 // captured step cannot take t from the host
-__global__ void adam_dev_kernel(long long n, float *p, const float *g, float *m, float *v, const float *coef, float b1, float b2, float eps)
+__global__ __launch_bounds__(256) void adam_dev_kernel(long long n, float *p, const float *g, float *m, float *v, const float *coef, float b1, float b2, float eps)
 {
     const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
     const float step_size = coef[0], bc2s = coef[1];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    // 16 bytes per lane when the four arrays allow it (one float per lane keeps too few bytes in flight for the HBM rate)
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    long long done = 0;
+    if (vec) {
+        const long long n4 = n >> 2;
+        float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        for (long long i = tid; i < n4; i += nth) {
+            const float4 gg = g4[i];
+            float4 pp = p4[i], mm = m4[i], vv = v4[i];
+            adam_elem(pp.x, mm.x, vv.x, gg.x, w1, b2, w2, step_size, bc2s, eps);
+            adam_elem(pp.y, mm.y, vv.y, gg.y, w1, b2, w2, step_size, bc2s, eps);
+            adam_elem(pp.z, mm.z, vv.z, gg.z, w1, b2, w2, step_size, bc2s, eps);
+            adam_elem(pp.w, mm.w, vv.w, gg.w, w1, b2, w2, step_size, bc2s, eps);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        done = n4 << 2;
+    }
+    for (long long i = done + tid; i < n; i += nth) {
         float pp = p[i], mm = m[i], vv = v[i];
         adam_elem(pp, mm, vv, g[i], w1, b2, w2, step_size, bc2s, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
@@ -404,7 +423,7 @@ RK_EXPORT int rk_adam_step_dev(int64_t n, float *param, const float *grad, float
 {
     if (n <= 0) return RK_OK;
     if (!param || !grad || !m || !v || !coef) RK_FAIL(RK_EINVAL, "rk_adam_step_dev: bad arguments");
-    const int grid = (int)std::min<long long>((n + 255) / 256, 2048);
+    const int grid = (int)std::min<long long>((n / 4 + 255) / 256 + 1, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long long)n, param, grad, m, v, coef, beta1, beta2, eps);
     RK_CHECK_LAUNCH();
     return RK_OK;

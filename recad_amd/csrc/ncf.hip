@@ -301,12 +301,47 @@ struct MultiAdam {
     long long n[RK_NCF_MAX_TENSORS];
     float step_size, bc2s, b1, b2, eps;
 };
-__global__ void multi_adam_kernel(const MultiAdam a)
+// 16 bytes per lane and two independent float4 quads in flight per thread: with one float per lane a wave had 1 KB in flight per
+// iteration and the launch ran at 4.6 TB/s (485 us for the 80 M parameters of factor 256 / 5 layers); tensors whose four arrays
+// are not all 16-byte aligned take the scalar loop.
+__global__ __launch_bounds__(256) void multi_adam_kernel(const MultiAdam a)
 {
     const int t = blockIdx.y;
     const float w1 = (float)(1.0 - (double)a.b1), w2 = (float)(1.0 - (double)a.b2);
     float *p = a.p[t], *g = a.g[t], *m = a.m[t], *v = a.v[t];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[t]; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = a.n[t];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    long long done = 0;
+    if (vec) {
+        const long long n4 = n >> 2;
+        float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+        auto upd = [&](float4 &pp, float4 &mm, float4 &vv, const float4 &gg) {
+            adam_elem(pp.x, mm.x, vv.x, gg.x, w1, a.b2, w2, a.step_size, a.bc2s, a.eps);
+            adam_elem(pp.y, mm.y, vv.y, gg.y, w1, a.b2, w2, a.step_size, a.bc2s, a.eps);
+            adam_elem(pp.z, mm.z, vv.z, gg.z, w1, a.b2, w2, a.step_size, a.bc2s, a.eps);
+            adam_elem(pp.w, mm.w, vv.w, gg.w, w1, a.b2, w2, a.step_size, a.bc2s, a.eps);
+        };
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        long long i = tid;
+        for (; i + nth < n4; i += 2 * nth) {
+            const long long j = i + nth;
+            const float4 g0 = g4[i], g1 = g4[j];
+            float4 p0 = p4[i], m0 = m4[i], v0 = v4[i], p1 = p4[j], m1 = m4[j], v1 = v4[j];
+            upd(p0, m0, v0, g0);
+            upd(p1, m1, v1, g1);
+            g4[i] = z; p4[i] = p0; m4[i] = m0; v4[i] = v0;
+            g4[j] = z; p4[j] = p1; m4[j] = m1; v4[j] = v1;
+        }
+        if (i < n4) {
+            const float4 g0 = g4[i];
+            float4 p0 = p4[i], m0 = m4[i], v0 = v4[i];
+            upd(p0, m0, v0, g0);
+            g4[i] = z; p4[i] = p0; m4[i] = m0; v4[i] = v0;
+        }
+        done = n4 << 2;
+    }
+    for (long long i = done + tid; i < n; i += nth) {
         const float gg = g[i];
         g[i] = 0.f;
         float pp = p[i], mm = m[i], vv = v[i];
@@ -531,7 +566,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         long long maxn = 0;
         for (int t = 0; t < T; ++t) { a.p[t] = P[t]; a.g[t] = d.grad[t]; a.m[t] = d.m[t]; a.v[t] = d.v[t]; a.n[t] = NN[t]; maxn = std::max(maxn, NN[t]); }
         a.step_size = c.step_size; a.bc2s = c.bc2s; a.b1 = d.beta1; a.b2 = d.beta2; a.eps = d.eps;
-        hipLaunchKernelGGL(multi_adam_kernel, dim3((int)std::min<long long>((maxn + 255) / 256, 1024), T), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(multi_adam_kernel, dim3((int)std::min<long long>((maxn / 4 + 255) / 256 + 1, 1024), T), dim3(256), 0, s, a);
         RK_CHECK_LAUNCH();
     }
     return RK_OK;

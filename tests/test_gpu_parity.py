@@ -921,6 +921,44 @@ def test_grid2d_trainer_hip(gpu_device, tmp_path, world, grid_rows, reduce):
                         res["users"], res["items"])
 
 
+def test_adam_step_dev_vector_and_scalar_paths_agree(gpu_device):
+    """rk_adam_step_dev takes 16 bytes per lane when its four arrays are 16-byte aligned and one float per lane otherwise: the same
+    data through both (a block on the 16-byte grid and the same block one float off it) must give the same bits, for lengths
+    that are not multiples of 4 as well (the vector path's scalar tail); and both equal the oracle's Adam BIT FOR BIT on the same
+    gradient (adam_elem rounds every operation on its own, like orc_adam: no contraction left to the compiler)."""
+    from recad_amd import _lib
+    from tests._oracle_ops import OracleOps
+    L = _lib.lib()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for n in (4096, 1003, 7, 262147):
+        g_ = torch.Generator(device=gpu_device).manual_seed(n)
+        data = [torch.randn(n, device=gpu_device, generator=g_) * s for s in (0.1, 0.01, 0.0, 0.0)]
+        runs = []
+        for shift in (0, 1, 2):
+            bufs = []
+            for t in data:
+                buf = torch.zeros(n + 8, device=gpu_device)
+                off = ((-buf.data_ptr() // 4) % 4 + shift) % 4 if shift == 0 else ((-buf.data_ptr() // 4) % 4 + shift)
+                v = buf[off: off + n]
+                v.copy_(t)
+                assert (v.data_ptr() % 16 == 0) == (shift == 0)
+                bufs.append(v)
+            runs.append(bufs)
+        ref = [t.cpu().numpy().copy() for t in data]
+        coef = torch.zeros(2, device=gpu_device)
+        counter = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+        for t in range(1, 4):
+            _lib.check(L.rk_adam_coef_advance(_lib.ptr(coef), _lib.ptr(counter), lr, b1, b2, _lib.stream_ptr()), "coef")
+            for a in runs:
+                _lib.check(L.rk_adam_step_dev(n, _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), _lib.ptr(coef), b1, b2, eps, _lib.stream_ptr()), "dev")
+            pr, gr, mr, vr = (torch.from_numpy(x) for x in ref)
+            OracleOps().adam(pr, gr, mr, vr, t, lr, b1, b2, eps)
+        torch.cuda.synchronize()
+        for k in (0, 2, 3):
+            assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), (n, k)
+            assert np.array_equal(runs[0][k].cpu().numpy(), ref[k]), (n, k, float(np.abs(runs[0][k].cpu().numpy() - ref[k]).max()))
+
+
 def test_grid2d_step_capture_matches_eager(gpu_device):
     """The 2-D trainer's captured step (tile SpMMs, the [6B, d] all-reduce, reduce-scatter / all-gather calls and the dense Adam with
     device-resident coefficients recorded once, replayed per step) against its eager step: ordered scatter and ordered reduce, so
