@@ -558,15 +558,19 @@ def worker(args):
                 replay, timed_as = None, f"direct launches (capture failed: {type(e).__name__})"
                 torch.cuda.synchronize()
         stream = torch.cuda.current_stream()
-        ev0.record(stream)
-        if replay is not None:
-            replay.replay()
-        else:
-            for _ in range(reps):
-                spmm_once()
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        spmm_ms = ev0.elapsed_time(ev1) / (reps * per_call)
+        rounds = 7 if nnz < 20_000_000 else 1    # median of 7 windows of `reps` launches (a 2 ms window alone moved 9.7 - 10.7 us run to run)
+        windows = []
+        for _ in range(rounds):
+            ev0.record(stream)
+            if replay is not None:
+                replay.replay()
+            else:
+                for _ in range(reps):
+                    spmm_once()
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            windows.append(ev0.elapsed_time(ev1) / (reps * per_call))
+        spmm_ms = sorted(windows)[len(windows) // 2]
         spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
         traffic = traffic_src = None
@@ -583,7 +587,7 @@ def worker(args):
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
                     "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
-                    "timed_as": timed_as,
+                    "timed_as": timed_as + (f"; median of {rounds} windows ({min(windows) * 1e3:.2f} - {max(windows) * 1e3:.2f} us)" if rounds > 1 else ""),
                     "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
                             "inter-kernel boundary); algorithmic bytes = SURVEY 8d's 8 nnz + 4 (N+1) + 8 N d"}
         if lds is not None:
