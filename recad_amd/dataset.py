@@ -53,7 +53,9 @@ def _sorted_unique_rows(ptr, idx):
     n = len(ptr) - 1
     users = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
     width = int(idx.max()) + 1 if len(idx) else 1
-    keys = np.unique(users * width + idx.astype(np.int64))
+    keys = users * width + idx.astype(np.int64)
+    if len(keys) > 1 and not bool(np.all(keys[1:] > keys[:-1])):   # (lists that are already sorted and unique skip the sort: 0.6 vs 10.6 ms at ml1m size)
+        keys = np.unique(keys)
     cnt = np.bincount(keys // width, minlength=n)
     out = np.zeros(n + 1, dtype=np.int64)
     out[1:] = np.cumsum(cnt)
