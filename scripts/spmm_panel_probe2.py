@@ -90,6 +90,11 @@ def build_plan(rp, col, U, I, B, CAP, PANEL_MAX=8800):
                             blockw[base[j] + t, m] = col[f[m] + t] - src0 - p * PR
                         real += int(c.sum())
                     padded += tot * 2 * 64
+                    if os.environ.get("PROBE_CONFLICT_FREE"):
+                        # timing experiment only (results are WRONG): lane l reads bank class l % 16, so no ds_read_b128 of a
+                        # 16-lane service group meets a bank conflict -- what a coloured schedule would buy
+                        real_e = blockw != PR
+                        blockw = np.where(real_e, np.minimum((blockw // 16) * 16 + (np.arange(64) % 16)[None, :], PR - 1), blockw)
                     words = (blockw[0::2] | (blockw[1::2] << 16)).astype(np.uint32)     # [tot][64]
                     tot4 = -(-tot // 4) * 4                                              # whole chunks: a lane reads 4 pair-steps as one 16-byte word
                     if tot4 > tot:
