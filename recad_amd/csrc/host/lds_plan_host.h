@@ -171,6 +171,11 @@ static std::vector<int> worker_cpus()
     const int self = sched_getcpu();
     for (int c = 0; c < CPU_SETSIZE; ++c)
         if (CPU_ISSET(c, &allowed) && c != self) cpus.push_back(c);
+    // start behind the caller's own CPU: several callers (one process per GPU building their plans at the same time, concurrent
+    // victims) then take different neighbours instead of all piling onto the first CPUs of the mask
+    size_t first = 0;
+    while (first < cpus.size() && cpus[first] < self) ++first;
+    std::rotate(cpus.begin(), cpus.begin() + (long)(first % std::max<size_t>(cpus.size(), 1)), cpus.end());
 #endif
     return cpus;
 }
