@@ -13,14 +13,15 @@ region).  The full-catalog scoring + top-100 + HR@K pass is timed after it ("top
 
 N > 1: `python bench.py --gpus N` starts its own N worker processes (one per GPU, before anything touches a
 GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is a worker itself.
-Default mode `--parallel rows2d`: ONE training job whose node rows (embedding tables, Adam state) are dealt
-over the N GPUs, every GPU holding a COLUMN SLAB of the adjacency (1 x N grid of recad_amd/sharded2d.py): per
-propagation layer one tile SpMM on the GPU's own block and one chunk-overlapped RCCL reduce-scatter, no
-all-gather (`--parallel rows`: the 1-D row partition with all-gathers, recad_amd/sharded.py), on the largest
-shardable workload (config-4-shaped: 1M x 500K x 100M edges; `--workload yelp` for the
-yelp-shaped one) => "scaling": "strong".  Rank 0 also times the single-GPU fused path on the same workload
-("same_workload_1gpu") so that the line carries its own like-for-like reference, and `--parallel replicas`
-(one independent retrain job per GPU, no data-path collective) is kept as a labelled extra mode.
+The TOP-LEVEL line is the SAME quantity for every N: the metric's own workload (ml1m-shaped, the one `--gpus 1`
+reports) as N independent victim replicas -- one retrain job per GPU, no data-path collective, "scaling":
+"weak", value = N x steps x B / max-over-ranks time -- so that the 1 -> 8 series is one curve and N = 1 equals
+BENCH.  The strong-scaling measurements of ONE training job sharded over the N GPUs live in `also`, each with
+its own single-GPU denominator and a `ranks_seen` record: `also.config4_rows2d` (1M x 500K x 100M edges, the
+1 x N column-slab form of recad_amd/sharded2d.py: per propagation layer one tile SpMM on the GPU's own block
+and one chunk-overlapped RCCL reduce-scatter) and `also.config3_yelp_rows2d`.  `--parallel rows2d | rows`
+(with `--workload`) makes such a sharded job the top-level line instead -- a labelled extra mode whose
+`metric` names its workload.
 """
 import argparse
 import json
@@ -37,16 +38,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # same guide: v_mfma_f32_32x32x2_f32 dense peak
+LDS_PEAK_GBS = 256 * 256 * 2.4   # same guide, "LDS": ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s
 METRIC = "BPR train interactions/sec + full-catalog top-K scorings/sec, LightGCN ml1m dim=64"
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: one ml1m epoch = 458 at N=1, 20 at N>1)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: one ml1m epoch = 458; 20 for the larger shapes / sharded modes)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default=None, choices=["ml1m", "yelp", "tiny", "c4s", "config4"],
-                    help="default: ml1m at N=1, config4 at N>1")
+                    help="default: ml1m (BASELINE.json config[1]) for every N")
     ap.add_argument("--graph", default="train", choices=["train", "reference"],
                     help="adjacency from the train edges (BASELINE '~470K edges') or the reference's as-is test-edge graph")
     ap.add_argument("--dim", type=int, default=None, help="default 64 (128 for --workload yelp, BASELINE config 3)")
@@ -65,9 +67,10 @@ def parse(argv=None):
                     help="ordered (bit-reproducible) gradient scatter instead of float atomics (fused and row-sharded paths; labelled in config)")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n eligible users (0 = all)")
     ap.add_argument("--parallel", default=None, choices=["rows", "rows2d", "replicas"],
-                    help="N>1 default: rows2d = the Pr x Pc tiling (recad_amd/sharded2d.py; default grid 1 x N: column slabs, no all-gather, one "
-                         "chunk-overlapped reduce-scatter per layer -- strong scaling); rows: the 1-D row partition with RCCL all-gathers; "
-                         "replicas: one independent victim replica per GPU (weak scaling, no data-path collective)")
+                    help="N>1 default: replicas = one independent victim replica per GPU on the metric's workload (weak scaling, no data-path "
+                         "collective; the sharded legs go to `also`).  As the TOP-LEVEL line instead (labelled extra mode): rows2d = the Pr x Pc "
+                         "tiling (recad_amd/sharded2d.py; default grid 1 x N: column slabs, no all-gather, one chunk-overlapped reduce-scatter "
+                         "per layer -- strong scaling); rows: the 1-D row partition with RCCL all-gathers")
     ap.add_argument("--grid-rows", type=int, default=0, help="rows2d: Pr of the Pr x Pc grid (0 = 1: column slabs)")
     ap.add_argument("--reduce", default="collective", choices=["collective", "ordered"],
                     help="rows2d: reduce_scatter_tensor (RCCL picks the algorithm) or all-to-all + sum in group-rank order (fixed order)")
@@ -85,19 +88,27 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true", help="N = 1 default run: skip the short yelp-shaped measurement (`also`)")
     ap.add_argument("--no-also-config4", action="store_true",
                     help="N = 1 default run: skip the config-4-shaped measurement (1M x 500K x 100M edges, ~6 s) inside `also`")
+    ap.add_argument("--no-also-sharded", action="store_true",
+                    help="N > 1 default run: skip the strong-scaling legs (ONE job sharded over the N GPUs: config-4 and yelp shapes, rows2d) in `also`")
+    ap.add_argument("--also-timeout", type=float, default=480.0,
+                    help="N > 1: seconds the sharded `also` legs may take before the (already measured) top-level line is printed without them")
+    ap.add_argument("--share-gpu", action="store_true", help="box check: several nccl / gloo ranks on ONE GPU (rank -> device rank %% n_devices)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: workers rendezvous over gloo, all-reduce their ranks and exit")
     a = ap.parse_args(argv)
     if a.workload is None:
-        a.workload = "ml1m" if a.gpus == 1 else "config4"
+        a.workload = "ml1m"          # the metric's own workload for EVERY N: the 1 -> 8 series is one quantity
     if a.parallel is None:
-        a.parallel = "rows2d" if a.gpus > 1 else "rows" if a.force_collectives else "replicas"
+        a.parallel = "rows" if (a.force_collectives and a.gpus == 1) else "replicas"
     if a.dim is None:
         a.dim = 128 if a.workload == "yelp" else 64
+    small = a.workload in ("ml1m", "tiny") and a.parallel == "replicas"
     if a.steps is None:
-        a.steps = 458 if (a.gpus == 1 and a.workload in ("ml1m", "tiny")) else 20
+        a.steps = 458 if small else 20
     if a.warmup is None:
-        a.warmup = 32 if (a.gpus == 1 and a.workload in ("ml1m", "tiny")) else 5
+        a.warmup = 32 if small else 5
     return a
 
 
@@ -140,16 +151,32 @@ def launch_workers(args, argv):
 
 
 def dry_run_worker(args, rank, world):
+    """Launcher check without a GPU: the workers rendezvous over gloo; rank 0 prints what the real run's line would carry as
+    `metric` / `config.workload` / mode for this N (built from the synthetic shape on the CPU)."""
     import torch
     import torch.distributed as dist
 
+    if "MASTER_ADDR" not in os.environ:   # (N = 1 without a launcher)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(sk.getsockname()[1])})
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank)])
     dist.all_reduce(t)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "parallel": args.parallel,
-                          "workload": args.workload}))
+        out = {"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "parallel": args.parallel, "workload": args.workload,
+               "metric": metric_for(args), "steps": args.steps, "warmup": args.warmup,
+               "scaling": "strong" if (args.parallel in ("rows", "rows2d") and (world > 1 or args.force_collectives)) else "weak",
+               "also_sharded_legs": (["config4_rows2d", "config3_yelp_rows2d"] if (world > 1 and args.parallel == "replicas" and not args.no_also_sharded) else [])}
+        if args.workload not in ("c4s", "config4"):
+            from recad_amd import synth
+            d = synth.make(args.workload)
+            ptr, idx = d["train"] if args.graph == "train" else d["test"]
+            out["config"] = {"workload": workload_string(args.workload, d["n_users"], d["n_items"], int(len(d["train"][1])), args.graph, 2 * int(len(idx)),
+                                                         args.dim, args.layers, args.batch),
+                             "mode": args.parallel if world > 1 else "single"}
+        print(json.dumps(out))
     dist.destroy_process_group()
 
 
@@ -331,8 +358,389 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
             "seconds_total": time.perf_counter() - t_all}
 
 
+# ------------------------------------------------------------------------------------------------ worker pieces
+def workload_string(name, n_users, n_items, train_edges, graph, nnz, dim, layers, B):
+    return (f"LightGCN victim, {name}-shaped synthetic {n_users}x{n_items}, {train_edges} train edges, graph={graph} (nnz {nnz}), "
+            f"dim={dim}, layers={layers}, batch={B}, Adam lr 1e-3, lambda 1e-4")
+
+
+def metric_for(args):
+    """BASELINE.json's metric string for its own workload; any other workload / a sharded job as the top-level line is a labelled
+    extra mode and says so in `metric`."""
+    sharded_top = args.parallel in ("rows", "rows2d") and (args.gpus > 1 or args.force_collectives)
+    if args.workload == "ml1m" and args.dim == 64 and not sharded_top:
+        return METRIC
+    return (f"BPR train interactions/sec + full-catalog top-K scorings/sec, LightGCN {args.workload}-shaped dim={args.dim}"
+            + (f", ONE job sharded over the GPUs ({args.parallel})" if sharded_top else "") + " [extra mode: not BASELINE.json's headline workload]")
+
+
+def load_workload(workload, dev, graph, B, seed):
+    """Synthetic interactions of the named shape + the dataset object on `dev` (same seed => identical on every rank)."""
+    from recad_amd import dataset, synth
+    if workload in ("c4s", "config4"):
+        dd = synth.make_device(workload, dev)
+        d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+        del dd
+    else:
+        d = synth.make(workload)
+    ds = dataset.from_config("implicit", workload, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"], need_graph=True,
+                             device=dev, graph_source=graph, pairwise_batch_size=B, seed=seed)
+    return d, ds
+
+
+def resident_triplets(ds, need):
+    import torch
+    cols = [[], [], []]
+    have = 0
+    while have < need:
+        ep = ds.generate_epoch()
+        for c, k in zip(cols, ("users", "positive_items", "negative_items")):
+            c.append(ep[k])
+        have += len(ep["users"])
+    return tuple(torch.cat(c)[:need].contiguous() for c in cols)
+
+
+def ranks_seen(dev, world, collectives):
+    """What actually took part: the process group's world size and every rank's device, all-gathered (N > 1 or a one-rank
+    group), so a line cannot claim more GPUs than ran."""
+    import torch
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"device_index": int(dev.index), "name": props.name, "pci_bus_id": int(getattr(props, "pci_bus_id", -1))}
+    if not collectives:
+        return {"world_size": 1, "devices": [mine]}
+    t = torch.tensor([int(os.environ.get("RANK", 0)), int(dev.index), mine["pci_bus_id"]], device=dev, dtype=torch.int64)
+    if dist.get_backend() == "gloo":
+        t = t.cpu()
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return {"world_size": int(dist.get_world_size()), "backend": dist.get_backend(),
+            "devices": [{"rank": int(o[0]), "device_index": int(o[1]), "pci_bus_id": int(o[2])} for o in out], "name": props.name}
+
+
+def wait_done(stream):
+    """Spin on a completion event before the contract's torch.cuda.synchronize(): the blocking wait's wake-up latency (tens of
+    microseconds on this stack) would otherwise sit inside a 20-step timed region of ~1.4 ms."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    while not ev.query():
+        pass
+    torch.cuda.synchronize()
+
+
+def spmm_roofline(args, victim, N, nnz, traffic_live=None):
+    """The dominant kernel: per-launch time by HIP events on ITS stream (captured + replayed for the ~9 us LDS kernel), SURVEY 8d's
+    algorithmic bytes, and -- for the LDS-resident kernel -- the bound it actually runs against (`lds_frac`)."""
+    import ctypes as C
+    import torch
+    from recad_amd import _lib
+    reps = 200 if nnz < 20_000_000 else 10
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h = victim._ensure_handle()
+    lds = victim._ws.get("lds")
+    if lds is not None:
+        # the LDS-resident sliced kernel (csrc/spmm_lds.h), launched exactly as the first forward layer of a train step
+        ws = victim._ws
+        plan, info = lds
+        epi = _lib.LdsEpilogue(y=_lib.ptr(ws["buf_a"]), sum_in=_lib.ptr(ws["e0s"]), sum_out=_lib.ptr(ws["lsum"]), sum_scale=1.0)
+
+        def spmm_once():
+            _lib.check(_lib.lib().rk_spmm_lds(C.byref(info), _lib.ptr(plan), _lib.ptr(ws["e0s"]), C.byref(epi), _lib.stream_ptr()), "rk_spmm_lds")
+        per_call, kname = 1, f"spmm_lds_kernel<{info.lpa}, {info.lpb}>"
+    else:
+        def spmm_once():
+            _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
+        per_call, kname = args.layers, f"spmm_csr_kernel<{args.dim}>"
+    for _ in range(3):
+        spmm_once()
+    # The LDS kernel runs ~9 us: 200 separate ctypes calls can be HOST-bound (10-14 us each on a busy host: the same tree gave
+    # 9.2 and 14.1 us on two boxes), which would time Python, not the kernel.  So the launches are captured once and replayed
+    # (same kernel, same arguments, back to back on the stream the events are recorded on); a failed capture falls back to
+    # the plain loop and says so.
+    timed_as = "direct launches"
+    replay = None
+    if lds is not None:
+        try:
+            torch.cuda.synchronize()
+            gcap = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gcap):
+                for _ in range(reps):
+                    spmm_once()
+            gcap.replay()
+            torch.cuda.synchronize()
+            replay, timed_as = gcap, f"{reps} launches captured in one hipGraph, replayed"
+        except Exception as e:   # noqa: BLE001
+            replay, timed_as = None, f"direct launches (capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    rounds = 7 if nnz < 20_000_000 else 1    # median of 7 windows of `reps` launches (a 2 ms window alone moved 9.7 - 10.7 us run to run)
+    windows = []
+    for _ in range(rounds):
+        ev0.record(stream)
+        if replay is not None:
+            replay.replay()
+        else:
+            for _ in range(reps):
+                spmm_once()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        windows.append(ev0.elapsed_time(ev1) / (reps * per_call))
+    spmm_ms = sorted(windows)[len(windows) // 2]
+    spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # SURVEY 8d: A once, X once, Y once
+    achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
+    traffic = traffic_src = None
+    tkey = f"{args.workload}_{args.graph}_d{args.dim}" + ("_lds" if lds is not None else "")
+    if traffic_live and traffic_live.get("bytes") and traffic_live.get("key") == tkey:
+        traffic, traffic_src = traffic_live["bytes"], traffic_live["source"]
+    else:
+        for tname in ("r05_spmm_traffic.json", "r04_spmm_traffic.json", "r03_spmm_traffic.json", "r02_spmm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(tkey)
+                    traffic_src = f"profiles/{tname} (rocprofv3 PMC passes on a builder-run box, not measured in this run)" if traffic is not None else None
+                except Exception:
+                    traffic = None
+        if traffic_live and traffic_live.get("error"):
+            traffic_src = (traffic_src or "none") + f"; live PMC passes unavailable in this run: {traffic_live['error']}"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
+                "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
+                "timed_as": timed_as + (f"; median of {rounds} windows ({min(windows) * 1e3:.2f} - {max(windows) * 1e3:.2f} us)" if rounds > 1 else ""),
+                "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
+                        "inter-kernel boundary); algorithmic bytes = SURVEY 8d's 8 nnz + 4 (N+1) + 8 N d"}
+    if traffic_live and traffic_live.get("detail"):
+        roofline["traffic_detail"] = traffic_live["detail"]
+    if lds is not None:
+        on_chip = 4 * nnz * args.dim   # one 16-byte ds_read_b128 per nonzero and 4-float slice: what the LDS pipes deliver instead of the L2 -> L1 gather
+        roofline["on_chip_bytes_per_launch"] = on_chip
+        roofline["lds_peak_GBs"] = LDS_PEAK_GBS
+        roofline["lds_frac"] = on_chip / (spmm_ms * 1e-3) / 1e9 / LDS_PEAK_GBS
+        roofline["lds_note"] = ("the bound this kernel runs against: the graph's tables are LDS-resident, every nonzero costs one ds_read_b128; "
+                                "lds_frac = on-chip gather bytes / WHOLE launch time / (256 CUs x 256 B/clk x 2.4 GHz, MI355X_MICROARCH.md 'LDS'); "
+                                "the gather phase alone is ~45 % of the launch (stage, row reduction and the launch boundary are the rest: DESIGN 4.1b)")
+    return roofline
+
+
+def live_traffic_probe(args, timeout_s=150):
+    """HBM-side traffic of the dominant kernel FROM THIS RUN: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per
+    pass (MI355X_MICROARCH.md 'HBM'; on gfx950 FETCH_SIZE counts a 128-byte request as 64 B => x2; WRITE_SIZE as is), around
+    scripts/spmm_lds_probe.py (20 launches of the same kernel on the same synthetic graph), as CHILD processes started before
+    this process touches the GPU (the program goes directly after `--`).  -> {"key", "bytes", "source", "detail"} or {"error"}."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import tempfile
+    if args.workload not in ("ml1m", "tiny") or args.graph != "train" or args.spmm == "csr":
+        return {"error": "live PMC passes are wired for the headline (LDS-resident) kernel only"}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    kern = "spmm_lds_kernel"
+    vals = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="recad_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+               os.path.join(ROOT, "scripts", "spmm_lds_probe.py"), "--shape", args.workload, "--dim", str(args.dim), "--iters", "20", "--no-stamps", "--lds-only"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)      # exactly the process group this call started
+                p.wait()
+                shutil.rmtree(out_dir, ignore_errors=True)
+                return {"error": f"rocprofv3 --pmc {counter} did not finish within {timeout_s} s"}
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter}: rc {p.returncode}, {len(files)} counter file(s)"}
+            got = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0])) if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not got:
+                return {"error": f"no {kern} dispatch in the {counter} pass"}
+            vals[counter] = (statistics.mean(got), len(got))
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    fetch_kib, write_kib = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    nbytes = int((2.0 * fetch_kib + write_kib) * 1024.0)
+    return {"key": f"{args.workload}_{args.graph}_d{args.dim}_lds", "bytes": nbytes,
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, run by this bench.py as child processes before its own GPU "
+                      "work (scripts/spmm_lds_probe.py: the same kernel on the same synthetic graph); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB "
+                      "(gfx950: FETCH_SIZE tallies 128-byte requests at 64 B); fabric-side traffic, Infinity-Cache hits included",
+            "detail": {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "dispatches": vals["FETCH_SIZE"][1], "seconds": time.perf_counter() - t0}}
+
+
+def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, with_eval=True, with_replicas=True):
+    """ONE LightGCN training job whose node rows are dealt over the process group's ranks (recad_amd/sharded.py: 1-D row
+    partition with all-gathers; recad_amd/sharded2d.py: Pr x Pc tiling / column slabs with reduce-scatters), timed like the
+    headline (warm-up, barrier + synchronize, K steps, barrier + synchronize, MAX over ranks) -- plus ITS OWN denominators on
+    the same workload: the fused single-GPU step on rank 0 (`same_workload_1gpu`) and N independent replicas
+    (`same_workload_replicas`), the receive-bytes model, the user-sharded evaluation and `ranks_seen`.
+    Every rank calls it; rank 0 gets the dict."""
+    import torch
+    import torch.distributed as dist
+    from recad_amd import model
+
+    collectives = world > 1 or args.force_collectives
+    B = args.batch
+    t_leg = time.perf_counter()
+    d, ds = load_workload(workload, dev, args.graph, B, 1234)
+    torch.manual_seed(2023)
+    victim = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=args.layers,
+                               deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
+    victim.graph_steps = args.graph_steps
+    g = ds.graph_csr()
+    N, nnz = g.n_rows, g.nnz
+    users, pos, neg = resident_triplets(ds, (steps + warmup) * B)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if collectives:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # every rank must see the same triplets and start from the same tables
+    if collectives:
+        for t in (users, pos, neg):
+            dist.broadcast(t, src=0)
+        for p_ in victim.parameters():
+            dist.broadcast(p_.data, src=0)
+        # every rank generated the workload itself (same seed): refuse to go on if the graphs differ
+        chk = torch.stack([g.col.long().sum(), g.rowptr.long().sum(), torch.tensor(g.nnz, device=dev)]).double()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool(torch.equal(lo, hi)):
+            raise RuntimeError("the ranks generated different graphs (synthetic workload not reproducible across ranks)")
+    if parallel == "rows2d":
+        from recad_amd.sharded2d import Grid2DLightGCN
+        sharded = Grid2DLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, victim.embedding_user.weight,
+                                 victim.embedding_item.weight, device=dev, grid_rows=args.grid_rows or None, reduce=args.reduce,
+                                 deterministic=bool(args.deterministic), force_collectives=args.force_collectives)
+    else:
+        from recad_amd.sharded import ShardedLightGCN
+        sharded = ShardedLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, victim.embedding_user.weight,
+                                  victim.embedding_item.weight, device=dev, gather=args.gather,
+                                  force_collectives=args.force_collectives, deterministic=bool(args.deterministic))
+    sharded.reserve(max(steps, warmup) * B, B)
+
+    def run(lo, n_steps):
+        sl = slice(lo * B, (lo + n_steps) * B)
+        return sharded.train_epoch(users[sl], pos[sl], neg[sl], B)
+
+    if warmup > 0:
+        run(0, warmup)
+    barrier()
+    t0 = time.perf_counter()
+    losses = run(warmup, steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if collectives:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    last_loss = float(losses[-1])
+    assert np.isfinite(last_loss), "training diverged"
+
+    ev = None
+    if with_eval:
+        ptr, idx = ds.train_csr_sorted()
+        ev = sharded.evaluate(ptr, idx, np.array([0], dtype=np.int32), K=100, topks=(10, 20, 50, 100), reps=2)
+
+    # like-for-like single-GPU reference on rank 0 (the others wait), then the same workload as N independent replicas
+    same_1gpu = replicas_same = None
+    if rank == 0:
+        victim.reserve(max(steps, warmup) * B, B)
+        s1 = min(steps, 10)
+        w1 = min(warmup, 3) * B or B
+        victim._run_epoch(users[:w1], pos[:w1], neg[:w1], B)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        victim._run_epoch(users[: s1 * B], pos[: s1 * B], neg[: s1 * B], B)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        same_1gpu = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
+                     "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait: "
+                             "the denominator of this leg's strong scaling"}
+    barrier()
+    if world > 1 and with_replicas:
+        # what the node delivers when the perturb-retrain loop is parallelised over jobs instead of inside one -- the comparison
+        # north_star's 6x on the yelp shape has to be read against (the rows modes are communication-bound there: DESIGN 6)
+        if rank != 0:
+            victim.reserve(max(steps, warmup) * B, B)
+        sr = min(steps, 10)
+        victim._run_epoch(users[: 3 * B], pos[: 3 * B], neg[: 3 * B], B)
+        barrier()
+        t1 = time.perf_counter()
+        victim._run_epoch(users[: sr * B], pos[: sr * B], neg[: sr * B], B)
+        barrier()
+        tr_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+        replicas_same = {"value": world * sr * B / float(tr_.item()), "unit": "interactions/s", "ms_per_step": float(tr_.item()) / sr * 1e3,
+                         "steps": sr, "note": f"{world} independent victims (one per GPU, fused single-GPU path) on this workload, all at once"}
+    seen = ranks_seen(dev, world, collectives)
+    out = None
+    if rank == 0:
+        # the arithmetic the rows modes live under: bytes a rank must RECEIVE per propagation layer over its xGMI links
+        # (7 links x ~77 GB/s one direction on MI355X) against the local SpMM time a layer needs
+        blk = (N + world - 1) // world * dim * 4
+        if parallel == "rows2d":
+            recv = (sharded.layout.Pr - 1 + sharded.layout.Pc - 1) * blk
+        else:
+            recv = (world - 1) * blk
+        comm_model = {"bytes_received_per_rank_and_layer": recv, "xgmi_in_GBps_assumed": 7 * 76.5,
+                      "receive_floor_us_per_layer": recv / (7 * 76.5e3) if world > 1 else 0.0,
+                      "layers_with_exchange_per_step": 2 * args.layers - 1,
+                      "note": "a layer cannot finish before its inputs have arrived: when receive_floor_us_per_layer exceeds the local SpMM "
+                              "time (same_workload_1gpu's step / (2 L) / N), the mode is communication-bound at this N"}
+        out = {"workload": workload_string(workload, ds.n_users, ds.n_items, ds.traindataSize, args.graph, nnz, dim, args.layers, B),
+               "mode": parallel, "parallelism": sharded.describe(), "backend": (dist.get_backend() if collectives else None),
+               "scaling": "strong", "value": steps * B / elapsed, "unit": "interactions/s", "ms_per_step": elapsed / steps * 1e3,
+               "steps": steps, "warmup": warmup, "n_gpus": world, "ranks_seen": seen, "last_step_loss": last_loss,
+               "step_captured": bool(getattr(sharded, "_graph", None) is not None),
+               "same_workload_1gpu": same_1gpu, "same_workload_replicas": replicas_same, "rows_comm_model": comm_model, "topk": ev,
+               "seconds_total": time.perf_counter() - t_leg}
+        same_1gpu["speedup_of_this_leg"] = out["value"] / same_1gpu["value"]
+    del sharded, victim
+    torch.cuda.empty_cache()
+    return out
+
+
+class Deadline:
+    """The sharded `also` legs have never met a real 8-GPU RCCL fabric in this repository's history: if one of them hangs (a
+    collective that never completes), the top-level line -- already measured -- must still come out.  Every rank arms the
+    same timer; on expiry rank 0 prints the line with what it has and every rank leaves with os._exit(0) (a rank stuck inside a
+    collective cannot unwind)."""
+
+    def __init__(self, seconds, rank, emit):
+        import threading
+        self.done = self.printed = False
+        self._t = threading.Timer(seconds + (0.0 if rank == 0 else 3.0), self._fire)
+        self._t.daemon = True
+        self.rank, self.emit, self.seconds = rank, emit, seconds
+        self._t.start()
+
+    def _fire(self):
+        if self.done:
+            return
+        try:
+            if self.rank == 0 and not self.printed:
+                self.emit(f"the sharded legs did not finish within {self.seconds:.0f} s (deadline; the top-level line was measured before them)")
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    def cancel(self):
+        self.done = True
+        self._t.cancel()
+
+
 # ------------------------------------------------------------------------------------------------ worker
-def worker(args):
+def worker(args, traffic_live=None):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -345,13 +753,14 @@ def worker(args):
     import torch
     import torch.distributed as dist
 
-    # gloo workers may share one GPU (the 1-GPU box check of the sharded path); nccl needs one GPU per rank
+    # gloo workers may share one GPU (the 1-GPU box check of the sharded path: --share-gpu); nccl needs one GPU per rank
     n_dev = torch.cuda.device_count()
-    share = args.backend == "gloo" or os.environ.get("RECAD_BENCH_SHARE_GPU") == "1"   # (box check: several ranks on one GPU)
+    share = args.backend == "gloo" or args.share_gpu
     local_dev = local % max(n_dev, 1) if share else local
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1 or args.force_collectives:
+    collectives = world > 1 or args.force_collectives
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
@@ -360,23 +769,34 @@ def worker(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import recad_amd  # noqa: F401
-    from recad_amd import _lib, dataset, model, synth
+    from recad_amd import model
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 
-    rows_mode = (world > 1 or args.force_collectives) and args.parallel in ("rows", "rows2d")
     B = args.batch
+    metric = metric_for(args)
 
-    # ---------------- workload: synthetic interactions of the named shape, resident on the GPU
+    # ================= labelled extra mode: ONE sharded job as the top-level line (--parallel rows | rows2d)
+    if collectives and args.parallel in ("rows", "rows2d"):
+        leg = sharded_leg(args, dev, rank, world, args.workload, args.dim, args.parallel, args.steps, args.warmup, with_eval=not args.no_topk)
+        if rank == 0:
+            out = {"metric": metric, "value": leg["value"], "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                   "data": "synthetic",
+                   "config": {"workload": leg["workload"], "parallelism": leg["parallelism"], "mode": args.parallel, "backend": args.backend,
+                              "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
+                   "topk": leg["topk"], "roofline": None, "cpu_baseline": None, "ranks_seen": leg["ranks_seen"],
+                   "same_workload_1gpu": leg["same_workload_1gpu"], "same_workload_replicas": leg["same_workload_replicas"],
+                   "rows_comm_model": leg["rows_comm_model"], "last_step_loss": leg["last_step_loss"], "step_captured": leg["step_captured"]}
+            if out["same_workload_1gpu"] is not None:
+                out["same_workload_1gpu"]["speedup_of_this_run"] = out["same_workload_1gpu"].pop("speedup_of_this_leg")
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ================= the headline: the metric's workload on one GPU, or as N independent replicas (one per GPU)
     big = args.workload in ("c4s", "config4")
-    if big:
-        dd = synth.make_device(args.workload, dev)     # same seed => identical on every rank
-        d = {k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
-        del dd
-    else:
-        d = synth.make(args.workload)
-    ds = dataset.from_config("implicit", args.workload, train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
-                             need_graph=True, device=dev, graph_source=args.graph, pairwise_batch_size=B,
-                             seed=1234 + (0 if rows_mode else rank))
+    d, ds = load_workload(args.workload, dev, args.graph, B, 1234 + rank)
     torch.manual_seed(2023)
     victim = model.from_config("victim", "lightgcn", latent_dim_rec=args.dim, lightGCN_n_layers=args.layers,
                                deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
@@ -385,71 +805,39 @@ def worker(args):
     victim.fuse_layers = bool(args.fuse_layers)
     g = ds.graph_csr()
     N, nnz = g.n_rows, g.nnz
-    need = (args.steps + args.warmup) * B
-    cols = [[], [], []]
-    have = 0
-    while have < need:
-        ep = ds.generate_epoch()
-        for c, k in zip(cols, ("users", "positive_items", "negative_items")):
-            c.append(ep[k])
-        have += len(ep["users"])
-    users, pos, neg = (torch.cat(c)[:need].contiguous() for c in cols)
+    users, pos, neg = resident_triplets(ds, (args.steps + args.warmup) * B)
     host_triplets = tuple(t[: B * 64].cpu().numpy() for t in (users, pos, neg))  # cpu_baseline / parity sample
-    want_parity = world == 1 and not rows_mode and not big and not args.no_parity
+    want_parity = world == 1 and not collectives and not big and not args.no_parity
     n_par = min(args.warmup + args.steps, args.parity_steps or (25 if args.workload in ("ml1m", "tiny") else 3), 64) if want_parity else 0
     init_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (victim.embedding_user.weight, victim.embedding_item.weight)) if want_parity else None
-
-    sharded = None
-    if rows_mode:
-        # every rank must see the same triplets and start from the same tables
-        from recad_amd.sharded import ShardedLightGCN
-        for t in (users, pos, neg):
-            dist.broadcast(t, src=0)
-        for p_ in victim.parameters():
-            dist.broadcast(p_.data, src=0)
-        # every rank generated the workload itself (same seed): refuse to go on if the graphs differ
-        chk = torch.stack([g.col.long().sum(), g.rowptr.long().sum(), torch.tensor(g.nnz, device=dev)]).double()
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not bool(torch.equal(lo, hi)):
-            raise SystemExit("bench.py: the ranks generated different graphs (synthetic workload not reproducible across ranks)")
-        if args.parallel == "rows2d":
-            from recad_amd.sharded2d import Grid2DLightGCN
-            sharded = Grid2DLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g, victim.embedding_user.weight,
-                                     victim.embedding_item.weight, device=dev, grid_rows=args.grid_rows or None, reduce=args.reduce,
-                                     deterministic=bool(args.deterministic), force_collectives=args.force_collectives)
-        else:
-            sharded = ShardedLightGCN(ds.n_users, ds.n_items, args.dim, args.layers, g,
-                                      victim.embedding_user.weight, victim.embedding_item.weight, device=dev,
-                                      gather=args.gather, force_collectives=args.force_collectives,
-                                      deterministic=bool(args.deterministic))
-        sharded.reserve(max(args.steps, args.warmup) * B, B)
-    else:
-        victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
-
-    def run(lo, n_steps):
-        if sharded is not None:
-            sl = slice(lo * B, (lo + n_steps) * B)
-            return sharded.train_epoch(users[sl], pos[sl], neg[sl], B)
-        return run_steps(victim, (users, pos, neg), B, lo, n_steps)
+    victim.reserve(max(args.steps, args.warmup) * B, B)   # staging + hipGraph capture/upload, before any timing
+    stream = torch.cuda.current_stream()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1 or args.force_collectives:
+        if collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---------------- dominant kernel first: the SpMM's per-launch time by HIP events on its stream.  It runs BEFORE the timed
+    # region on purpose: ~15 ms of the step's own dominant kernel bring the device to its working clocks, so the K timed steps
+    # are measured at the rate an epoch runs at (the driver's 20-step call used to run its kernels ~8 % slower than a
+    # 458-step epoch: profiles/r04_call_trace.txt).  It touches workspace buffers only, never the tables.
+    roofline = spmm_roofline(args, victim, N, nnz, traffic_live)
+
     warm_losses = None
     if args.warmup > 0:
-        wp = run(0, args.warmup)
+        wp = run_steps(victim, (users, pos, neg), B, 0, args.warmup)
         if want_parity:
             warm_losses = wp.sum(dim=1).double()   # device-side copy now (the loss buffer is reused by the timed call), read back after the timing
     barrier()
     t0 = time.perf_counter()
-    partials = run(args.warmup, args.steps)
+    partials = run_steps(victim, (users, pos, neg), B, args.warmup, args.steps)
+    wait_done(stream)
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.fuse_layers:
+        victim.check_handoffs()
     run_losses = run_tables = None
     if want_parity:   # what the timed path produced, to be laid next to the oracle below (outside the timed region)
         tl = partials.sum(dim=1).double().cpu().numpy()
@@ -460,144 +848,31 @@ def worker(args):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    last_loss = float(partials[-1].sum().item()) if sharded is None else float(partials[-1])
+    last_loss = float(partials[-1].sum().item())
     assert np.isfinite(last_loss), "training diverged"
-    work_ranks = 1 if sharded is not None else world  # rows: all ranks work on ONE training job
-
-    # ---------------- rows mode: like-for-like single-GPU reference on rank 0 (others wait), then evaluation
-    same_1gpu = replicas_same = None
-    sharded_eval = None
-    if sharded is not None:
-        if not args.no_topk:
-            ptr, idx = ds.train_csr_sorted()
-            sharded_eval = sharded.evaluate(ptr, idx, np.array([0], dtype=np.int32), K=100, topks=(10, 20, 50, 100), reps=2)
-        if rank == 0:
-            victim.reserve(max(args.steps, args.warmup) * B, B)
-            s1 = min(args.steps, 10)
-            victim._run_epoch(users[: min(args.warmup, 3) * B or B], pos[: min(args.warmup, 3) * B or B], neg[: min(args.warmup, 3) * B or B], B)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            victim._run_epoch(users[: s1 * B], pos[: s1 * B], neg[: s1 * B], B)
-            torch.cuda.synchronize()
-            e1 = time.perf_counter() - t1
-            same_1gpu = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
-                         "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait"}
-        barrier()
-        # the SAME workload as N independent replicas (one retrain job per GPU, no data-path collective): what the node delivers
-        # when the perturb-retrain loop is parallelised over jobs instead of inside one -- the comparison north_star's 6x on the
-        # yelp shape has to be read against (the rows modes are communication-bound there: DESIGN 6)
-        if world > 1:
-            if rank != 0:
-                victim.reserve(max(args.steps, args.warmup) * B, B)
-            sr = min(args.steps, 10)
-            victim._run_epoch(users[: 3 * B], pos[: 3 * B], neg[: 3 * B], B)
-            barrier()
-            t1 = time.perf_counter()
-            victim._run_epoch(users[: sr * B], pos[: sr * B], neg[: sr * B], B)
-            barrier()
-            tr_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
-            replicas_same = {"value": world * sr * B / float(tr_.item()), "unit": "interactions/s", "ms_per_step": float(tr_.item()) / sr * 1e3,
-                             "steps": sr, "note": f"{world} independent victims (one per GPU, fused single-GPU path) on this workload, all at once"}
+    seen = ranks_seen(dev, world, collectives)
 
     # ---------------- secondary: one whole train_step() epoch, the build's device sampler included
     epoch_obj = None
-    if sharded is None and args.workload in ("ml1m", "tiny"):
+    if args.workload in ("ml1m", "tiny"):
         victim.train_step(progress_bar=None)  # warm: sampler kernels, staging buffers
         barrier()
         te = time.perf_counter()
         victim.train_step(progress_bar=None)  # samples an epoch on the device, runs it, reads the losses back
         torch.cuda.synchronize()
         te = time.perf_counter() - te
+        if world > 1:
+            t = torch.tensor([te], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te = float(t.item())
         n_ep = int(len(ds.generate_epoch()["users"]))  # triplets of one epoch (traindataSize draws with a positive)
         epoch_obj = {"seconds": te, "includes": "device BPR sampler + every step of one epoch + loss read-back (model.train_step())"}
         if n_ep:
             epoch_obj.update({"value": world * n_ep / te, "unit": "interactions/s", "triplets": n_ep})
 
-    # ---------------- dominant kernel: the SpMM; per-launch time by HIP events on its stream
-    roofline = None
-    if sharded is None or rank == 0:
-        import ctypes as C
-        stream = torch.cuda.current_stream()
-        reps = 200 if nnz < 20_000_000 else 10
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        h = victim._ensure_handle()
-        lds = victim._ws.get("lds")
-        if lds is not None:
-            # the LDS-resident sliced kernel (csrc/spmm_lds.h), launched exactly as the first forward layer of a train step
-            ws = victim._ws
-            plan, info = lds
-            epi = _lib.LdsEpilogue(y=_lib.ptr(ws["buf_a"]), sum_in=_lib.ptr(ws["e0s"]), sum_out=_lib.ptr(ws["lsum"]), sum_scale=1.0)
-
-            def spmm_once():
-                _lib.check(_lib.lib().rk_spmm_lds(C.byref(info), _lib.ptr(plan), _lib.ptr(ws["e0s"]), C.byref(epi), _lib.stream_ptr()), "rk_spmm_lds")
-            per_call, kname = 1, f"spmm_lds_kernel<{info.lpa}, {info.lpb}>"
-        else:
-            def spmm_once():
-                _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "propagate")
-            per_call, kname = args.layers, f"spmm_csr_kernel<{args.dim}>"
-        for _ in range(3):
-            spmm_once()
-        # The LDS kernel runs ~9 us: 200 separate ctypes calls can be HOST-bound (10-14 us each on a busy host: the same tree gave
-        # 9.2 and 14.1 us on two boxes), which would time Python, not the kernel.  So the launches are captured once and replayed
-        # (same kernel, same arguments, back to back on the stream the events are recorded on); a failed capture falls back to
-        # the plain loop and says so.
-        timed_as = "direct launches"
-        replay = None
-        if lds is not None:
-            try:
-                torch.cuda.synchronize()
-                gcap = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gcap):
-                    for _ in range(reps):
-                        spmm_once()
-                gcap.replay()
-                torch.cuda.synchronize()
-                replay, timed_as = gcap, f"{reps} launches captured in one hipGraph, replayed"
-            except Exception as e:   # noqa: BLE001
-                replay, timed_as = None, f"direct launches (capture failed: {type(e).__name__})"
-                torch.cuda.synchronize()
-        stream = torch.cuda.current_stream()
-        rounds = 7 if nnz < 20_000_000 else 1    # median of 7 windows of `reps` launches (a 2 ms window alone moved 9.7 - 10.7 us run to run)
-        windows = []
-        for _ in range(rounds):
-            ev0.record(stream)
-            if replay is not None:
-                replay.replay()
-            else:
-                for _ in range(reps):
-                    spmm_once()
-            ev1.record(stream)
-            torch.cuda.synchronize()
-            windows.append(ev0.elapsed_time(ev1) / (reps * per_call))
-        spmm_ms = sorted(windows)[len(windows) // 2]
-        spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
-        achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-        traffic = traffic_src = None
-        tkey = f"{args.workload}_{args.graph}_d{args.dim}" + ("_lds" if lds is not None else "")
-        for tname in ("r04_spmm_traffic.json", "r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if traffic is None and os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(tkey)
-                    traffic_src = f"profiles/{tname} (rocprofv3 PMC passes on a builder-run box, not measured in this run)" if traffic is not None else None
-                except Exception:
-                    traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "bytes_per_launch": spmm_bytes, "avg_launch_us": spmm_ms * 1e3,
-                    "gather_bytes_per_launch": 8 * nnz + 4 * nnz * args.dim + 4 * N * args.dim,
-                    "timed_as": timed_as + (f"; median of {rounds} windows ({min(windows) * 1e3:.2f} - {max(windows) * 1e3:.2f} us)" if rounds > 1 else ""),
-                    "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
-                            "inter-kernel boundary); algorithmic bytes = SURVEY 8d's 8 nnz + 4 (N+1) + 8 N d"}
-        if lds is not None:
-            roofline["on_chip_bytes_per_launch"] = 4 * nnz * args.dim   # what the LDS pipes deliver instead of the L2 -> L1 gather
-
     # ---------------- second half of the metric: full-catalog scoring + top-100 + HR@K
     topk = None
-    if sharded is not None:
-        topk = sharded_eval
-    elif not args.no_topk:
+    if not args.no_topk:
         ptr, idx = ds.train_csr_sorted()
         targets = np.array([0], dtype=np.int32)
         ev_users = eligible_users(ptr, idx, targets)
@@ -618,8 +893,12 @@ def worker(args):
         for _ in range(EV_REPS):
             res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
             hits_t = hit_counts(res["target_rank"], (10, 20, 50, 100))
-        torch.cuda.synchronize()
+        wait_done(stream)
         ev_el = (time.perf_counter() - t1) / EV_REPS
+        if world > 1:
+            t = torch.tensor([ev_el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ev_el = float(t.item())
         hr50 = float(hits_t[0, 2].item()) / max(len(ev_users), 1)
         t1 = time.perf_counter()  # one evaluation on an idle device, host enqueue included (latency, not throughput)
         res = full_catalog_topk(victim, ev_dev, ptr_dev, idx_dev, tg_dev, K=100, chunk=ev_chunk, to_host=False)
@@ -632,13 +911,14 @@ def worker(args):
                 "eligible_users": int(len(ev_users)), "seconds": ev_el, "evaluations_timed": EV_REPS,
                 "single_evaluation_seconds": ev_single, "hr@50": hr50,
                 "gemm_tflops_e2e": flops / ev_el / 1e12,
-                "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@{10,20,50,100} counts; inputs and outputs resident in HBM"}
+                "includes": "propagate + fp32-MFMA GEMM + seen mask + top-100 + target rank + HR@{10,20,50,100} counts; inputs and outputs resident in HBM"
+                            + (f"; {world} replicas, one per GPU, slowest rank's time" if world > 1 else "")}
 
     mfma = None
-    if rank == 0 and world == 1 and not args.no_topk and not big and not args.force_collectives:
+    if rank == 0 and world == 1 and not args.no_topk and not big and not collectives:
         mfma = mfma_gemm_probe(dev)
     also = None
-    if rank == 0 and world == 1 and sharded is None and args.workload == "ml1m" and not args.no_also:
+    if rank == 0 and world == 1 and not collectives and args.workload == "ml1m" and not args.no_also:
         also = {"config3_yelp": also_measure(dev, "yelp", 128, args.layers, B)}
         if not args.no_also_config4:
             also["config4"] = also_measure(dev, "config4", 64, args.layers, B, steps=10, warmup=3, eval_users=65536)
@@ -677,50 +957,55 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         cpu_aten = cpu_baseline_aten(d, args.graph, args.dim, args.layers, B, host_triplets)
 
-    comm_model = None
-    if sharded is not None and rank == 0:
-        # the arithmetic the rows modes live under: bytes a rank must RECEIVE per propagation layer over its xGMI links
-        # (7 links x ~77 GB/s one direction on MI355X) against the local SpMM time a layer needs
-        blk = (N + world - 1) // world * args.dim * 4
-        if args.parallel == "rows2d":
-            pr_, pc_ = sharded.layout.Pr, sharded.layout.Pc
-            recv = (pr_ - 1 + pc_ - 1) * blk
-        else:
-            recv = (world - 1) * blk
-        comm_model = {"bytes_received_per_rank_and_layer": recv, "xgmi_in_GBps_assumed": 7 * 76.5,
-                      "receive_floor_us_per_layer": recv / (7 * 76.5e3) if world > 1 else 0.0,
-                      "layers_with_exchange_per_step": 2 * args.layers - 1,
-                      "note": "a layer cannot finish before its inputs have arrived: when receive_floor_us_per_layer exceeds the local SpMM "
-                              "time (same_workload_1gpu's step / (2 L) / N), the mode is communication-bound at this N"}
+    out = None
     if rank == 0:
-        if sharded is not None:
-            par = sharded.describe()
-        elif world == 1:
-            par = "single GPU"
-        elif sharded is None:
-            par = "1 independent victim replica per GPU (no data-path collective)"
-        else:
-            par = sharded.describe()
+        par = "single GPU" if world == 1 else f"{world} independent victim replicas, one per GPU (no data-path collective)"
         out = {
-            "metric": METRIC,
-            "value": work_ranks * args.steps * B / elapsed, "unit": "interactions/s",
+            "metric": metric,
+            "value": world * args.steps * B / elapsed, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if sharded is None else "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"LightGCN victim, {args.workload}-shaped synthetic {ds.n_users}x{ds.n_items}, "
-                                   f"{ds.traindataSize} train edges, graph={args.graph} (nnz {nnz}), dim={args.dim}, "
-                                   f"layers={args.layers}, batch={B}, Adam lr 1e-3, lambda 1e-4",
-                       "parallelism": par, "mode": args.parallel if (world > 1 or sharded is not None) else "single",
-                       "backend": args.backend if (world > 1 or sharded is not None) else None,
+            "config": {"workload": workload_string(args.workload, ds.n_users, ds.n_items, ds.traindataSize, args.graph, nnz, args.dim, args.layers, B),
+                       "parallelism": par, "mode": "replicas" if world > 1 else "single",
+                       "backend": args.backend if collectives else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
             "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
-            "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "same_workload_1gpu": same_1gpu,
-            "same_workload_replicas": replicas_same, "rows_comm_model": comm_model, "last_step_loss": last_loss,
+            "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "ranks_seen": seen, "last_step_loss": last_loss,
         }
-        if same_1gpu is not None:   # strong scaling of ONE workload: the N-rank job against the fused single-GPU step on the same data
-            same_1gpu["speedup_of_this_run"] = out["value"] / same_1gpu["value"]
+
+    # ================= N > 1: the strong-scaling legs (ONE job sharded over the ranks) go into `also`, under a deadline
+    if world > 1 and not args.no_also_sharded:
+        del victim
+        torch.cuda.empty_cache()
+        legs = {}
+
+        def emit(err=None):
+            if rank == 0:
+                out["also"] = dict(legs)
+                if err:
+                    out["also"]["error"] = err
+                print(json.dumps(out), flush=True)
+
+        dl = Deadline(args.also_timeout, rank, emit)
+        for name, wl, dim_, st_, wu_ in (("config4_rows2d", "config4", 64, 10, 3), ("config3_yelp_rows2d", "yelp", 128, 20, 5)):
+            if name == "config4_rows2d" and args.no_also_config4:
+                continue
+            try:
+                leg = sharded_leg(args, dev, rank, world, wl, dim_, "rows2d", st_, wu_)
+                if rank == 0:
+                    legs[name] = leg
+            except Exception as e:   # noqa: BLE001 -- a failed leg is recorded; the ranks re-synchronise at the next leg's first collective
+                legs[name] = {"error": f"{type(e).__name__}: {e}"}
+        emit()
+        dl.printed = True
+        dist.barrier()       # (still under the deadline: a rank whose leg failed half-way may never arrive)
+        dl.cancel()
+        dist.destroy_process_group()
+        return
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1 or args.force_collectives:
+    if collectives:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -803,7 +1088,14 @@ def main():
         return workflow_bench(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_workers(args, argv))
-    worker(args)
+    traffic_live = None
+    if args.gpus == 1 and not args.dry_run and not args.no_live_traffic and not args.force_collectives:
+        # BEFORE this process touches the GPU: the PMC passes are child processes (rocprofv3 ... -- python3 probe)
+        try:
+            traffic_live = live_traffic_probe(args)
+        except Exception as e:   # noqa: BLE001 -- the bench line must come out; the roofline says why traffic is not live
+            traffic_live = {"error": f"{type(e).__name__}: {e}"}
+    worker(args, traffic_live)
 
 
 if __name__ == "__main__":

@@ -248,7 +248,7 @@ typedef struct rk_lightgcn_desc {
                                                * layers per launch) whose workgroups hand the layers over to each other per column
                                                * group through agent-scope counters kept here (recad_amd/csrc/spmm_lds.h:
                                                * spmm_lds_multi_kernel; same sums, same bits as one launch per layer).  Word
-                                               * RK_LDS_SYNC_ERR is set if a wait ever gave up (rk_lightgcn_sync_status). */
+                                               * RK_LDS_SYNC_ERR is set if a wait ever gave up and stays set until rk_lightgcn_sync_status reads it. */
 } rk_lightgcn_desc;
 #define RK_LDS_SYNC_WORDS 2560
 #define RK_LDS_SYNC_ERR 2336
@@ -257,7 +257,10 @@ typedef struct rk_lightgcn_desc {
 typedef struct rk_lightgcn *rk_lightgcn_t;
 
 int rk_lightgcn_create(const rk_lightgcn_desc *desc, rk_lightgcn_t *out);
-/* *status = desc.lds_sync[RK_LDS_SYNC_ERR] (0 = every in-launch hand-off completed; no lds_sync: 0).  Synchronises the stream. */
+/* *status = desc.lds_sync[RK_LDS_SYNC_ERR] (0 = every in-launch hand-off completed; no lds_sync: 0).  Synchronises the stream.
+ * The word is STICKY: no launch and no call prologue clears it (the caller's zero-initialisation and this call are the only
+ * resets), so a time-out in any propagate / train call since the last status read is reported; a non-zero status is
+ * cleared by the read. */
 int rk_lightgcn_sync_status(rk_lightgcn_t h, int32_t *status, void *stream);
 int rk_lightgcn_destroy(rk_lightgcn_t h);
 

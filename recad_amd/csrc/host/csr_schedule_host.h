@@ -2,6 +2,9 @@
 // (make -C recad_amd/csrc host-asan host-tsan).
 #pragma once
 #include <algorithm>
+#include <exception>
+#include <memory>
+#include <new>
 #include <numeric>
 #include <vector>
 
@@ -20,7 +23,21 @@ struct rk_schedule {
 };
 
 // rowptr: HOST array of n_rows + 1 entries
+inline int csr_schedule_build_host_body(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim,
+                                        rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words);
+// what the C-ABI entry points call: no C++ exception unwinds through extern "C" (see host/lds_plan_host.h)
 inline int csr_schedule_build_host_impl(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim,
+                                        rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words)
+{
+    try {
+        return csr_schedule_build_host_body(n_rows, rowptr, class_split, dim, out, n_blocks, n_words, scratch_words);
+    } catch (const std::bad_alloc &) {
+        RK_FAIL(RK_ENOMEM, "rk_csr_schedule_build: out of host memory");
+    } catch (const std::exception &e) {
+        RK_FAIL(RK_EINVAL, "rk_csr_schedule_build: %s", e.what());
+    }
+}
+inline int csr_schedule_build_host_body(int32_t n_rows, const int32_t *rowptr, int32_t class_split, int32_t dim,
                                         rk_schedule_t *out, int32_t *n_blocks, int64_t *n_words, int64_t *scratch_words)
 {
     if (n_rows <= 0 || !rowptr || !out || !n_blocks || !n_words || !scratch_words || class_split < 0 || class_split > n_rows || dim <= 0 || dim > 256)
@@ -57,7 +74,8 @@ inline int csr_schedule_build_host_impl(int32_t n_rows, const int32_t *rowptr, i
         for (int32_t r = 0; r < n_rows; ++r) { const int32_t k = rp[r + 1] - rp[r]; if (k > kSegNnz) over += k; }
         if (2 * over >= (long long)rp[n_rows]) seg_nnz = 2 * kSegNnz;
     }
-    rk_schedule *sc = new rk_schedule();
+    std::unique_ptr<rk_schedule> sc_owner(new rk_schedule());   // freed if anything below throws
+    rk_schedule *sc = sc_owner.get();
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  With
     // class_split > 0 the rows < split (users) and >= split (items) are scheduled into separate
     // workgroup lists that are then interleaved 4:4 per group of 8, so an XCD's L2 only ever
@@ -170,7 +188,7 @@ inline int csr_schedule_build_host_impl(int32_t n_rows, const int32_t *rowptr, i
     }
     sc->n_blocks = (int32_t)(d.size() / bw);
     sc->n_long = n_long; sc->n_slots = n_slots; sc->dim = dim;
-    *out = sc;
+    *out = sc_owner.release();
     *n_blocks = sc->n_blocks | (sc->packed.empty() ? 0 : kSchedPackedFlag) | sched_waves_code(kSpmmWaves) |
                 (n_long ? kSchedLongFlag : 0);  // opaque launch parameter
     *n_words = (int64_t)sc->words();

@@ -7,6 +7,11 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 #if defined(__linux__)
@@ -248,7 +253,27 @@ using namespace rk_plan_detail;
 
 // Host-only builder (no HIP call): every array is host memory.  *n_words == 0 on return: the graph does not qualify
 // (not bipartite / not the normalised binary adjacency / a class table does not fit a CU's LDS) -- use spmm.h's kernel.
+inline int lds_plan_build_host_body(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val,
+                                    int32_t dim, int32_t n_cu, rk_lds_plan_t *out, int64_t *n_words, rk_lds_info *info);
+// The C-ABI entry points call THIS: no C++ exception (std::bad_alloc of a builder vector, std::system_error of the thread
+// pool) may unwind through extern "C" -- the perturb-retrain loop calls the builder once per injected graph, and a transient
+// resource limit must come back as RK_E*, not std::terminate.
 inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val,
+                                    int32_t dim, int32_t n_cu, rk_lds_plan_t *out, int64_t *n_words, rk_lds_info *info)
+{
+    try {
+        return lds_plan_build_host_body(n_users, n_items, rowptr, col, val, dim, n_cu, out, n_words, info);
+    } catch (const std::bad_alloc &) {
+        if (out) *out = nullptr;
+        if (n_words) *n_words = 0;
+        RK_FAIL(RK_ENOMEM, "rk_lds_plan_build_host: out of host memory");
+    } catch (const std::exception &e) {
+        if (out) *out = nullptr;
+        if (n_words) *n_words = 0;
+        RK_FAIL(RK_EINVAL, "rk_lds_plan_build_host: %s", e.what());
+    }
+}
+inline int lds_plan_build_host_body(int32_t n_users, int32_t n_items, const int32_t *rowptr, const int32_t *col, const float *val,
                                     int32_t dim, int32_t n_cu, rk_lds_plan_t *out, int64_t *n_words, rk_lds_info *info)
 {
     if (n_users <= 0 || n_items <= 0 || !rowptr || !col || dim <= 0 || !out || !n_words || !info)
@@ -286,7 +311,8 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
     if (!choose_half(rp, 0, U, I, dim, n_cu / 2, force_sa, force_c, &hp[0])) return RK_OK;
     if (!choose_half(rp, U, N, U, dim, n_cu - n_cu / 2, force_sb, force_c, &hp[1])) return RK_OK;
 
-    rk_lds_plan *pl = new rk_lds_plan();
+    std::unique_ptr<rk_lds_plan> pl_owner(new rk_lds_plan());   // freed if anything below throws
+    rk_lds_plan *pl = pl_owner.get();
     std::vector<int32_t> &w = pl->words;
     const int n_wg = hp[0].n_slices * hp[0].n_blk + hp[1].n_slices * hp[1].n_blk;
     w.assign(LP_HDR_WORDS, 0);
@@ -584,13 +610,34 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const size_t n_threads = std::min<size_t>(n_blocks_total, env_threads > 0 ? (size_t)env_threads : std::min<unsigned>(hw, 16u));
         std::atomic<size_t> next(0);
-        auto worker = [&](int cpu) { place_self(cpu); PlanScratch ws; for (size_t bi = next++; bi < n_blocks_total; bi = next++) build_block(bi, ws); };
+        // a worker never lets an exception escape its thread (that would be std::terminate): the first one is parked and
+        // rethrown on the caller's thread after the join; the others stop taking blocks
+        std::atomic<bool> failed(false);
+        std::exception_ptr first_error;
+        std::mutex error_mutex;
+        auto worker = [&](int cpu) {
+            try {
+                place_self(cpu);
+                PlanScratch ws;
+                for (size_t bi = next++; bi < n_blocks_total && !failed.load(std::memory_order_relaxed); bi = next++) build_block(bi, ws);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(error_mutex);
+                if (!first_error) first_error = std::current_exception();
+                failed.store(true, std::memory_order_relaxed);
+            }
+        };
         static const int pin = RK_TUNE_INT("RK_LDS_PLAN_PIN", 1);   // tuning: 0 = leave the workers to the scheduler
         const std::vector<int> cpus = pin ? worker_cpus() : std::vector<int>();
         std::vector<std::thread> pool;
-        for (size_t k = 1; k < n_threads; ++k) pool.emplace_back(worker, cpus.empty() ? -1 : cpus[(k - 1) % cpus.size()]);
+        pool.reserve(n_threads);
+        for (size_t k = 1; k < n_threads; ++k) {
+            // thread / pids limit reached (std::system_error): go on with the workers that did start -- the caller's thread
+            // drains the queue anyway
+            try { pool.emplace_back(worker, cpus.empty() ? -1 : cpus[(k - 1) % cpus.size()]); } catch (const std::system_error &) { break; }
+        }
         worker(-1);
         for (auto &th : pool) th.join();
+        if (first_error) std::rethrow_exception(first_error);
     }
     std::vector<uint16_t> stream;   // all blocks' column streams, 16-byte units
     std::vector<size_t> stream_ofs16(n_blocks_total, 0);
@@ -644,7 +691,7 @@ inline int lds_plan_build_host_impl(int32_t n_users, int32_t n_items, const int3
     fi.wgx_ofs = w[LP_WGX_OFS]; fi.dinv_ofs = w[LP_DINV_OFS]; fi.perm0_ofs = w[LP_PERM0]; fi.perm1_ofs = w[LP_PERM1]; fi.mq_ofs = w[LP_MQ_OFS];
     *info = fi;
     *n_words = (int64_t)w.size();
-    *out = pl;
+    *out = pl_owner.release();
     return RK_OK;
 }
 

@@ -492,6 +492,9 @@ RK_EXPORT int rk_lightgcn_sync_status(rk_lightgcn_t h, int32_t *status, void *st
     if (!h->d.lds_sync) return RK_OK;
     RK_HIP(hipMemcpyAsync(status, h->d.lds_sync + LS_ERR, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     RK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // read-and-clear: the word is sticky across launches and call prologues (nothing else resets it), so a reported timeout
+    // does not poison the calls after it
+    if (*status) RK_HIP(hipMemsetAsync(h->d.lds_sync + LS_ERR, 0, sizeof(int32_t), (hipStream_t)stream));
     return RK_OK;
 }
 

@@ -411,7 +411,8 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_kernel(const LdsArgs a)
 // "payload sc1 + agent-scope counter" (see ld16_sc1 above); workgroup b pulls from queue (b % 8) % n_queues, which keeps a
 // group on one XCD under round-robin dispatch -- speed only (the re-staged slice tables are then same-XCD traffic).
 // sync words (int32, caller-owned, one launch at a time, zero before the first launch; the last workgroup to leave zeroes
-// them again, and every train / propagate call's prologue does too):
+// the counters again, and every train / propagate call's prologue does too -- but never LS_ERR: a timed-out wait stays
+// recorded until rk_lightgcn_sync_status reads (and then clears) it):
 enum { LS_HEAD = 0 /* 8 queue heads, one per 128-byte line */, LS_ARRIVE = 8 * 32 /* per group, one line each */,
        LS_MAX_GROUPS = 64, LS_DONE = LS_ARRIVE + LS_MAX_GROUPS * 32, LS_ERR = LS_DONE + 32, LS_WORDS = LS_ERR + 32 };
 // plan words at LP_MQ_OFS: {n_queues, n_groups, G, 0}, then n_queues x {n_items, first int4 of its list (in int4 units from
@@ -461,12 +462,15 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
     // (scalar) branch, never by `if (tid == 0)`: with a single-lane branch at the bottom AND the top of this loop the
     // compiler rotated the loop so that lane 0 left it alone (arrival add, next ticket, LDS store) while lanes 1-63 of its
     // wave went on to the barrier -- s_barrier counts waves, not lanes, so the workgroup read a stale ticket and never
-    // terminated (ROCm 7.2, gfx950).  Every lane of that wave adds 1, so the counters advance in units of 64 (the compiler
-    // folds a wave's equal adds into ONE atomic of 64 whose first lane receives the old value -- no per-lane scan).
+    // terminated (ROCm 7.2, gfx950).  The counters advance in units of 64: lane 0 of that wave adds 64, lanes 1-63 add 0,
+    // and the first lane's return value is the ticket.  Correct WITHOUT relying on the compiler's atomic optimizer: folded
+    // (one atomic of 64 per wave, what ROCm 7.2 emits) or not (63 no-op adds interleaving with other workgroups' adds of
+    // 64), lane 0 always receives a distinct multiple of 64.
     const bool w0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const int one64 = (tid & 63) == 0 ? 64 : 0;
     int iters = 0;
     int t_next = 0;   // (first wave) the NEXT ticket, drawn while this item's stores drain
-    if (w0) t_next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w0) t_next = __hip_atomic_fetch_add(head, one64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         LDS_MARK(0, 1); LDS_MARK(2, iters); ++iters;
         if (w0) bc[0] = __builtin_amdgcn_readfirstlane(t_next) >> 6;
@@ -505,16 +509,16 @@ __global__ __launch_bounds__(kLdsThreads) void spmm_lds_multi_kernel(const LdsMu
         else lds_body<LPB, true>(ph.x, ph.e, plan, a.h, rec, lds_dyn, st ? st + 2 : nullptr);
         LDS_STAMP(4);
         LDS_MARK(0, 4);
-        if (w0) t_next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the drain
+        if (w0) t_next = __hip_atomic_fetch_add(head, one64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the drain
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
         __syncthreads();                                    // ... before the ONE wave that signals for all of them
         LDS_STAMP(5);
         LDS_MARK(0, 5);
-        if (w0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w0) __hip_atomic_fetch_add(arrive, one64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     LDS_MARK(0, 6);
     // leave the sync words zero for the next launch: the last workgroup out (nobody reads or adds after its own done-add)
-    if (w0) bc[1] = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(a.sync + LS_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6;
+    if (w0) bc[1] = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(a.sync + LS_DONE, one64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6;
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(bc[1]) == (int)gridDim.x - 1) {
         if (tid < 8) __hip_atomic_store(a.sync + LS_HEAD + tid * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -529,14 +533,14 @@ struct LdsPackJob {
     int n;
     float *zero[2];         // nullable: [N, d] buffers cleared by the same launch (a train call's scatter targets)
     int *zero_i;            // nullable: int32[N] cleared too (incidence counts)
-    int *zero_sync;         // nullable: the multi-phase launch's LS_WORDS sync words (a call starts from clean counters whatever came before)
+    int *zero_sync;         // nullable: the multi-phase launch's sync words: the counters [0, LS_ERR) are cleared (a call starts from clean counters whatever came before)
 };
 static __global__ void lds_pack_kernel(LdsDims g, LdsPackJob job, int to_sliced)
 {
     const int d4 = g.d / 4;
     const long long n = (long long)(g.U + g.I) * d4;
     if (job.zero_sync && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < LS_WORDS; i += blockDim.x) job.zero_sync[i] = 0;
+        for (int i = threadIdx.x; i < LS_ERR; i += blockDim.x) job.zero_sync[i] = 0;   // heads / arrivals / done only: LS_ERR is sticky until rk_lightgcn_sync_status has read it
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / d4), k = (int)(i % d4) * 4;
         const size_t so = sl_off(g, r, k), ro = (size_t)r * g.d + k;

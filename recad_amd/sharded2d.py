@@ -366,3 +366,7 @@ class Grid2DLightGCN(ShardedLightGCN):
             else:
                 x_col = self._gather_col(y)
         ops.zero_rows(self.gprop, self.gego, idx_pos3)
+        if frontier is not None:
+            # the bitmap describes THIS minibatch only (like ShardedLightGCN._step_core): stale bits would widen the next step's
+            # filtered gather and make its summation order depend on the minibatches that came before
+            ops.mark_rows(frontier, cidx, False)

@@ -231,6 +231,8 @@ class LightGCN(BaseVictim):
                        "rk_lightgcn_propagate_dropout")
         else:
             _lib.check(_lib.lib().rk_lightgcn_propagate(h, _lib.stream_ptr()), "rk_lightgcn_propagate")
+        if self.fuse_layers:
+            self.check_handoffs()   # (opt-in multi-phase launch only; synchronises) a timed-out hand-off means `light` is invalid
         light = self._ws["light"]
         return light[: self.num_users], light[self.num_users:]
 
@@ -291,6 +293,8 @@ class LightGCN(BaseVictim):
         """loss partials and dLoss/dE0 of ONE minibatch (no update): the gradient half of lightgcn.py:149-167."""
         u, p, n = cols
         part = self._run_epoch(u, p, n, max(u.numel(), 1), apply_update=False, want_grad=True)
+        if self.fuse_layers:
+            self.check_handoffs()
         g = self._ws["grad"]
         U = self.num_users
         return part.clone(), {self.embedding_user.weight: g[:U].clone(), self.embedding_item.weight: g[U:].clone()}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch durations of one LightGCN train step by position, from rocprofv3: one launch per layer (f1 f2 f3 bpr b1 b2 b3) or
-# the multi-phase form (F bpr B).  Extra arguments go to bench.py; RK_LDS_NO_FUSE=1 in the environment selects the former.
+# the multi-phase form (F bpr B).  Extra arguments go to bench.py: one launch per layer is the default, --fuse-layers selects the latter.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/st_$$
 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-parity --no-also --no-topk --steps 64 --warmup 8 --graph-steps 0 "$@" > /dev/null 2>&1

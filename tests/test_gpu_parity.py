@@ -979,6 +979,8 @@ def test_grid2d_step_capture_matches_eager(gpu_device):
         l2 = tr.train_epoch(users, pos, neg, B).numpy().copy()
         assert (tr._graph is not None) == (capture is None), "the default must have captured its step"
         tu, ti = tr.tables()
+        # the frontier bitmap describes one minibatch: every step clears the bits it set (eager and captured alike)
+        assert tr.row_bits is not None and int(tr.row_bits.ne(0).sum().item()) == 0, "stale frontier bits after a step"
         outs.append((l1, l2, tu.cpu().numpy(), ti.cpu().numpy(), tr.t))
     a, b = outs
     assert a[4] == b[4] == 4 + 8

@@ -151,12 +151,44 @@ def test_bench_self_launch_dry_run():
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "rows2d"
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "replicas" and d["scaling"] == "weak"
+    assert d["also_sharded_legs"] == ["config4_rows2d", "config3_yelp_rows2d"]   # the strong-scaling jobs live in `also`
     # a world that disagrees with --gpus is refused
     env2 = dict(env, RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env2)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_bench_line_is_one_quantity_for_every_n():
+    """SCALE-readiness: `bench.py --gpus N` reports BASELINE.json's metric on BASELINE.json's workload for N = 1 and N = 8 alike
+    (replicas, weak scaling), so the driver's 1 -> 8 series is one curve; a sharded job as the top-level line is a labelled extra
+    mode whose metric says so."""
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    lines = {}
+    for n in (1, 2, 4, 8):
+        a = bench.parse(["--gpus", str(n), "--steps", "20", "--warmup", "5"])
+        assert (a.workload, a.parallel, a.dim, a.steps, a.warmup) == ("ml1m", "replicas", 64, 20, 5)
+        lines[n] = (bench.metric_for(a), a.workload, a.dim, a.layers, a.batch, a.graph)
+        assert bench.metric_for(a) == base["metric"]
+    assert len(set(lines.values())) == 1
+    a = bench.parse(["--gpus", "8"])
+    assert (a.steps, a.warmup) == (bench.parse([]).steps, bench.parse([]).warmup)       # same defaults for every N
+    a = bench.parse(["--gpus", "8", "--parallel", "rows2d", "--workload", "config4"])
+    assert bench.metric_for(a) != base["metric"] and "extra mode" in bench.metric_for(a) and a.steps == 20
+    a = bench.parse(["--gpus", "1", "--workload", "yelp"])
+    assert bench.metric_for(a) != base["metric"] and a.dim == 128
+    # the dry run prints the same metric / workload string for N = 1 and N = 2 (what the real line carries)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    got = []
+    for n in ("1", "2"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n, "--dry-run"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        got.append((d["metric"], d["config"]["workload"], d["scaling"]))
+    assert got[0] == got[1] and got[0][0] == base["metric"] and "ml1m-shaped" in got[0][1]
 
 
 def test_grid_tiles_cover_graph():
