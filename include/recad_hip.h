@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RK_ABI_VERSION 8
+#define RK_ABI_VERSION 9
 #define RK_OK 0
 #define RK_EINVAL (-22)   /* bad argument / unsupported shape */
 #define RK_EHIP (-5)      /* a HIP runtime call failed */
@@ -323,7 +323,7 @@ int rk_adam_step_dev(int64_t n, float *param, const float *grad, float *m, float
  * are excluded (normal.py:133-143).  Outputs per user: top_ids/top_scores[K] sorted by (score desc, item id
  * asc), padded with -1/-inf; for each target t its score and rank among the unseen items (hit@k <=> rank < k).
  * Two paths, identical results (ids, scores, target scores and ranks bit for bit):
- *   RK_SCORE_GEMM  -- GEMM into a [nb, n_items] matrix in `scratch` + a selection pass: small user blocks, catalogues of < 16 384
+ *   RK_SCORE_GEMM  -- GEMM into a [nb, n_items] matrix (row stride plan.ld_scores) in `scratch` + a selection pass: small user blocks, catalogues of < 16 384
  *                     items, and everything the panel form does not take;
  *   RK_SCORE_PANEL -- the register-resident panel form, recad_amd/csrc/score_panel.h: a workgroup holds the scores of 16 / 32
  *                     users x 1920 items in its registers, selects from there and never writes a score (K <= 256, n_targets <= 4,
@@ -344,8 +344,10 @@ typedef struct rk_score_plan {
     int32_t panel_ntw;        /* PANEL: 16-item tiles per wave and panel: 8 (1024-item panels) or 15 (1920) (request: 0 = by catalogue size) */
     int32_t panel_safe;       /* PANEL: 1 = every panel through the exact safe form (tests) */
     int32_t nb, n_items, dim, K, n_targets;   /* what the plan was made for: rk_score_topk refuses anything else */
-    int32_t reserved[3];
-    int64_t scratch_floats;   /* device float[scratch_floats], 16-byte aligned */
+    int32_t ld_scores;        /* GEMM (ABI 9): row stride of the score matrix in floats = n_items rounded up to 32, so that every row and every
+                               * 16-column store segment of the GEMM's tiles starts on a 128- / 64-byte line (3 702 -> 3 712); PANEL: 0 */
+    int32_t reserved[2];
+    int64_t scratch_floats;   /* device float[scratch_floats], 16-byte aligned (GEMM: nb * ld_scores) */
 } rk_score_plan;
 int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets, const rk_score_plan *request /*nullable*/,
                        rk_score_plan *out);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
-ABI_VERSION = 8
+ABI_VERSION = 9
 RK_LDS_SYNC_WORDS = 2560
 
 
@@ -77,7 +77,7 @@ class ScorePlan(C.Structure):
     _fields_ = [
         ("path", C.c_int32), ("panel_rows", C.c_int32), ("panel_ntw", C.c_int32), ("panel_safe", C.c_int32),
         ("nb", C.c_int32), ("n_items", C.c_int32), ("dim", C.c_int32), ("K", C.c_int32), ("n_targets", C.c_int32),
-        ("reserved", C.c_int32 * 3), ("scratch_floats", C.c_int64),
+        ("ld_scores", C.c_int32), ("reserved", C.c_int32 * 2), ("scratch_floats", C.c_int64),
     ]
 
 

@@ -573,7 +573,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
 }
 
 // ---------------------------------------------------------------- top-K over a ready score matrix
-extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *user_ids, const int *seen_ptr,
+extern "C" int rk_topk_rows_impl(float *scores, long long ld, int nb, int n_items, const int *user_ids, const int *seen_ptr,
                                  const int *seen_idx, int K, int *top_ids, float *top_scores, const int *targets,
                                  int n_targets, float *target_score, int *target_rank, hipStream_t s);
 
@@ -585,6 +585,6 @@ RK_EXPORT int rk_topk_rows(float *scores, int32_t nb, int32_t n_items, const int
     if (nb <= 0) return RK_OK;
     if (!scores || n_items <= 0 || !user_ids || !seen_ptr || !seen_idx || !top_ids || !top_scores)
         RK_FAIL(RK_EINVAL, "rk_topk_rows: bad arguments");
-    return rk_topk_rows_impl(scores, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
+    return rk_topk_rows_impl(scores, n_items, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
                              target_score, target_rank, (hipStream_t)stream);
 }

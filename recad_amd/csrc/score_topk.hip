@@ -58,7 +58,7 @@ __device__ __forceinline__ void find_bin(const int *hist, int need, int tid, int
 //      bits resolved the ties are taken in id order.
 // LDS: 3 KB + the key row, so 8 workgroups per CU hide the dependent loads of the prologue.
 template <bool LDS_ROW>
-__global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ scores, int n_items, const int *__restrict__ user_ids,
+__global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ scores, long long ld, int n_items, const int *__restrict__ user_ids,
                                                             const int *__restrict__ seen_ptr, const int *__restrict__ seen_idx, int K,
                                                             int *__restrict__ top_ids, float *__restrict__ top_scores,
                                                             const int *__restrict__ targets, int n_targets,
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned lds_keys[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x;
-    float *grow = scores + (size_t)b * n_items;
+    float *grow = scores + (size_t)b * (size_t)ld;
     auto key_at = [&](int i) -> unsigned { return LDS_ROW ? lds_keys[i] : score_key(grow[i]); };
     // f(item, key) over this thread's share of the row: four consecutive items per 16-byte LDS read
     // (the LDS row is padded with excluded keys to a multiple of 4), or a strided walk of the row in L2.
@@ -330,13 +330,320 @@ __global__ __launch_bounds__(kTopkNT) void topk_rows_kernel(float *__restrict__ 
     }
 }
 
-extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *user_ids, const int *seen_ptr,
+// ---------------------------------------------------------------- pass 2, short rows: ONE WAVE per user row, the row in registers
+// Rows of up to NQ x 64 floats (NQ = 16 ... 96: <= 6 144 items -- ml1m, Amazon-game, dev): no workgroup barrier, no LDS
+// atomics on the item path, every reduction a wave reduction.  A workgroup is four independent waves.
+//   0. one wave per row, six waves per SIMD (79 VGPRs at NQ = 58), so all 5 893 rows of the headline evaluation are resident at
+//      once.  Measured alternatives (scripts/topk_wave_probe.sh, profiles/r05_topk_wave_probe*.txt): the kernel is bound by
+//      instruction ISSUE -- ~3 600 wave instructions per row (2 250 vector, 900 scalar, 200 LDS, 100 memory), 41 us at any
+//      occupancy from 3 to 6 -- so what pays is fewer instructions per item, not more waves: persistent waves that walk two rows and
+//      load the next row under the current one (two rows' registers: 3 waves per SIMD) took 52 us; the dispatcher starts ~3 400
+//      waves in the first two microseconds and the rest at ~400 per microsecond, which is where 12 of the 41 us go;
+//   1. lane l holds items l, l + 64, l + 128, ... (NQ coalesced dword loads through a buffer descriptor of the row: any row
+//      alignment, one address register, past-the-end lanes read 0); the excluded items are a TRANSPOSED per-wave LDS bitmap --
+//      bit q of lane l's word = item 64 q + l -- so a lane reads its NQ bits as NQ / 32 dwords and tests them with immediate
+//      masks; positions past the row's end start out excluded.  Keys: monotone uint of the score, 0 = excluded;
+//   2. target ranks: #(key > kt) + #(key == kt and id < target): two compares per key, ties through a rare slow path;
+//   3. lower bound of the K-th largest key: the K-th largest of the 256 GROUP MAXIMA (group = lane x (q mod 4); every maximum
+//      is a distinct item), found to 20 bits by a bitwise search with ballots -- ~125 keys lie at or above it for K = 100,
+//      whatever the row length;
+//   4. candidates (keys >= bound) are compacted into a per-wave list (per-lane counts, wave prefix sum); if more than 256
+//      (large K, heavy ties, near-constant rows): the EXACT K-th key by a 32-step bitwise search over all keys, everything above
+//      it in any order and the needed ties in ascending item id (ballot order);
+//   5. rank sort of the <= 256 composites (key << 32 | ~id: distinct, so ranks are a permutation; ties resolve to the lowest
+//      item id exactly like the oracle's scan), permuted in LDS, written out coalesced.
+// The score matrix is only READ (the row-per-workgroup kernel below overwrites seen items in place).
+// a copy of a per-lane value the compiler cannot hoist or merge with other copies (item ids are formed where they are used and
+// die there: left alone, all NQ of them stay alive across the passes)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// a compile-time constant as a scalar register the compiler cannot fold, hoist or merge: `x - scalar_here(c)` is ONE vector
+// instruction formed where it stands (NQ item ids precomputed ahead of the branches they are used under cost NQ registers)
+__device__ __forceinline__ unsigned scalar_here(unsigned c) { unsigned r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(c)); return r; }
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+// score_key() without a branch: the same key for every finite score, +-0 and +inf; 0 ("excluded") for -inf like score_key --
+// and for a NaN with the sign bit set, which score_key ranks below every number (a NaN score has no meaningful place either
+// way; a positive NaN keeps its key above +inf in both).  s + 0.0f folds -0.0 onto +0.0 and changes nothing else that matters.
+__device__ __forceinline__ unsigned score_key_sel(float s, bool excluded)
+{
+    const unsigned u = __float_as_uint(s + 0.0f);
+    const unsigned k = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+    return (excluded || k <= 0x007fffffu) ? 0u : k;   // k <= 0x007fffff: -inf (exactly 0x007fffff) or a negative NaN
+}
+
+#ifndef TOPK_STAMP   // (scripts/topk_wave_probe.sh builds this kernel alone with per-phase cycle stamps)
+#define TOPK_STAMP(i) do { } while (0)
+#endif
+#ifndef TOPK_WAVES_EU   // (probe builds: occupancy A/B)
+#define TOPK_WAVES_EU(NQ) (NQ <= 58 ? 6 : NQ <= 72 ? 5 : 4), 8
+#endif
+#ifndef TOPK_WAVE_WG    // waves per workgroup
+#define TOPK_WAVE_WG 4
+#endif
+template <int NQ>
+__global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_eu(TOPK_WAVES_EU(NQ)))) void topk_wave_kernel(
+    const float *__restrict__ scores, long long ld, int nb, int n_items, const int *__restrict__ user_ids, const int *__restrict__ seen_ptr,
+    const int *__restrict__ seen_idx, int K, int *__restrict__ top_ids, float *__restrict__ top_scores, const int *__restrict__ targets,
+    int n_targets, float *__restrict__ target_score, int *__restrict__ target_rank)
+{
+    constexpr int NW = (NQ + 31) / 32;   // bitmap dwords per lane
+    __shared__ unsigned bm_all[TOPK_WAVE_WG][NW * 64];
+    __shared__ unsigned long long sel_all[TOPK_WAVE_WG][kMaxK + 4];   // (+4: the rank loop reads whole groups of four slots)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = (int)blockIdx.x * TOPK_WAVE_WG + w;
+    if (b >= nb) return;   // (waves are independent: no workgroup barrier anywhere below)
+    TOPK_STAMP(0);
+    unsigned *bm = bm_all[w];
+    // composite of a candidate = key << 32 | ~item id, one 8-byte LDS slot each, read back as 64-bit words.  WRITTEN as two dword
+    // stores whose adjacency the compiler cannot see (the upper half's index goes through `hi`, an opaque 1): one 64-bit store wants
+    // the key in the upper half of an aligned register PAIR -- every key register was then allocated as half of a pair, doubling
+    // the keys' footprint, and a private copy of the key is coalesced away where the store is the key's last use
+    unsigned long long *sel = sel_all[w];
+    unsigned *sel32 = reinterpret_cast<unsigned *>(sel_all[w]);
+    const int hi = opaque(1);
+    auto sel_put = [&](int slot, unsigned not_id, unsigned k) { sel32[2 * slot] = not_id; sel32[2 * slot + hi] = k; };
+
+    const float *grow = scores + (size_t)b * (size_t)ld;
+    // the row through a buffer descriptor of exactly its bytes: ONE address register for all NQ loads (4 * lane; 256 q goes into the
+    // instruction's offset field / a scalar), and lanes past the row's end read 0 instead of faulting (those positions are excluded)
+    const unsigned long long gaddr = reinterpret_cast<unsigned long long>(grow);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gaddr >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)gaddr)),
+        (short)0, n_items * 4, 0x00020000);
+    float v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, q * 256, 0));
+    TOPK_STAMP(1);
+    // the seen list hangs off two dependent (scalar) loads; the row is already in flight
+    const int u = user_ids[b];
+    const int seen_b = seen_ptr[u], seen_e = seen_ptr[u + 1];
+    {
+        const int nq = (n_items - lane + 63) >> 6;   // this lane's items: q < nq
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = nq - 32 * i;
+            bm[i * 64 + lane] = n >= 32 ? 0u : n <= 0 ? 0xffffffffu : (0xffffffffu << n);
+        }
+    }
+    wave_lds_sync();
+    for (int k = seen_b + lane; k < seen_e; k += 64) {
+        const unsigned i = (unsigned)seen_idx[k];
+        if (i < (unsigned)(NQ * 64)) atomicOr(&bm[(i >> 11) * 64 + (i & 63u)], 1u << ((i >> 6) & 31u));
+    }
+    // target scores before masking (normal.py:83-85); the first target's id and score are wanted right after the keys: their
+    // (dependent) loads start here, under the row's
+    for (int t = lane; t < n_targets; t += 64) target_score[(size_t)b * n_targets + t] = grow[targets[t]];
+    const int tg0 = n_targets > 0 ? targets[0] : 0;
+    const float ts0 = n_targets > 0 ? grow[tg0] : 0.f;
+    wave_lds_sync();
+    unsigned excl[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) excl[i] = bm[i * 64 + lane];
+    TOPK_STAMP(2);
+    unsigned key[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) key[q] = score_key_sel(v[q], (excl[q >> 5] & (1u << (q & 31))) != 0u);
+    TOPK_STAMP(3);
+    {
+        // ---- target ranks:  #(s > st) + #(s == st and id < target), the target itself and excluded items not counted.
+        for (int t = 0; t < n_targets; ++t) {
+            const int tg = t == 0 ? tg0 : targets[t];
+            const unsigned kt = score_key(t == 0 ? ts0 : grow[tg]);
+            // per-lane counters (compare + add-with-carry), one wave sum of both at the end: counting ballots on the scalar side kept
+            // 2 NQ mask registers alive (the sums are re-associated) and spilled
+            int c_gt = 0, c_eq = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                c_gt += key[q] > kt ? 1 : 0;
+                c_eq += key[q] == kt ? 1 : 0;
+            }
+            const int packed = wave_sum_i(c_gt + (c_eq << 16));   // (both < 2^13 per wave)
+            int cnt = packed & 0xffff;
+            const int n_eq = packed >> 16;
+            // the target itself is one of the keys equal to kt unless it is excluded: only OTHER items with its score need the id test
+            const int self = (unsigned)tg < (unsigned)(NQ * 64) && !((bm[(tg >> 11) * 64 + (tg & 63)] >> ((tg >> 6) & 31)) & 1u) ? 1 : 0;
+            if (n_eq > self && kt != 0u) {
+                int ce = 0;
+                const int lane_here = opaque(lane);   // (loop-invariant otherwise: NQ hoisted `lane | 64 q` registers live across the target loop)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    ce += (key[q] == kt && lane_here + 64 * q < tg) ? 1 : 0;
+                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                cnt += wave_sum_i(ce);
+            }
+            if (lane == 0) target_rank[(size_t)b * n_targets + t] = cnt;
+        }
+        TOPK_STAMP(4);
+        // ---- lower bound of the K-th largest key from the 256 group maxima
+        unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m[q & 3] = max(m[q & 3], key[q]);
+        auto count_ge = [&](unsigned x) -> int {
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c += __popcll(__ballot(m[j] >= x));
+            return c;
+        };
+        unsigned cthr = 1u;   // candidates: keys >= cthr (1 = every valid key)
+        if (count_ge(1u) >= K) {
+            unsigned T = 0u;
+#pragma unroll 1
+            for (int bit = 31; bit >= 12; --bit) {
+                const unsigned cand = T | (1u << bit);
+                if (count_ge(cand) >= K) T = cand;
+            }
+            cthr = max(T, 1u);
+        }
+        TOPK_STAMP(5);
+        // ---- candidates: per-lane counts, wave prefix sum, compaction into the wave's list
+        auto compact = [&](unsigned thr0) -> int {   // the list <- composites of the keys >= thr0, if they fit; returns how many
+            int cl = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                cl += key[q] >= thr0 ? 1 : 0;
+                if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            const int incl = wave_incl_scan_i(cl, lane);
+            const int total = __shfl(incl, 63, 64);
+            if (total <= kMaxK) {
+                int slot = incl - cl;   // this lane's next list slot
+                // (a private copy of the threshold: sharing the first pass's NQ compare results kept 2 NQ scalar registers alive -- spills)
+                const unsigned thr = (unsigned)__builtin_amdgcn_readfirstlane(opaque((int)thr0));
+                const unsigned not_lane = ~(unsigned)lane;   // ~(lane + 64 q) = ~lane - 64 q
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (key[q] >= thr) {
+                        sel_put(slot, not_lane - scalar_here(64 * q), key[q]);
+                        ++slot;
+                    }
+            }
+            return total;
+        };
+        int n_sel = compact(cthr);
+        if (n_sel > kMaxK) {
+            // ---- exact path: the K-th largest key itself (at least K keys are >= cthr here), bit by bit over ALL keys
+            auto count_all_ge = [&](unsigned x) -> int {
+                int c = 0;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    c += __popcll(__ballot(key[q] >= x));
+                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                return c;
+            };
+            unsigned T = 0u;
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = T | (1u << bit);
+                if (count_all_ge(cand) >= K) T = cand;
+            }
+            // T >= cthr >= 1.  Everything above T in any order (fewer than K), then the ties in ascending item id = (q, lane) order
+            const int n_gt = T == 0xffffffffu ? 0 : compact(T + 1u);   // keys > T
+            const int need = K - n_gt;
+            int before = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned long long eq = __ballot(key[q] == T);
+                const int pos = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(eq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eq, 0u));
+                if (key[q] == T && pos < need) sel_put(n_gt + pos, ~(unsigned)lane - scalar_here(64 * q), T);
+                before += __popcll(eq);
+            }
+            n_sel = K;
+        }
+        n_sel = __builtin_amdgcn_readfirstlane(n_sel);   // (uniform by construction: the loops below run on the scalar side)
+        if (lane < 4) sel[n_sel + lane] = 0ULL;          // pad to a whole group of four
+        wave_lds_sync();
+        TOPK_STAMP(6);
+        // ---- rank sort: composites are distinct (item id in the low word), so ranks are a permutation
+        unsigned long long mine[4];
+        int rk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[e] = lane + 64 * e < n_sel ? sel[lane + 64 * e] : ~0ULL;
+        auto rank_all = [&](auto ne) {
+            constexpr int NE = decltype(ne)::value;
+            // four slots per trip (the list is padded with zero composites: never greater than anything), their reads issued
+            // together ahead of the compares: one slot per trip exposed an LDS round trip per comparison
+#pragma clang loop unroll(disable)
+            for (int j = 0; j < n_sel; j += 4) {
+                unsigned long long c[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = sel[j + i];   // (uniform addresses: broadcast reads)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) rk[e] += c[i] > mine[e] ? 1 : 0;
+            }
+        };
+        if (n_sel <= 64) rank_all(std::integral_constant<int, 1>{});
+        else if (n_sel <= 128) rank_all(std::integral_constant<int, 2>{});
+        else rank_all(std::integral_constant<int, 4>{});
+        TOPK_STAMP(7);
+        wave_lds_sync();   // every lane has read the list: permute it in place
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lane + 64 * e < n_sel) sel_put(rk[e], (unsigned)mine[e], (unsigned)(mine[e] >> 32));
+        wave_lds_sync();
+        for (int k = lane; k < K; k += 64) {
+            int id = -1;
+            float sc = -INFINITY;
+            if (k < n_sel) {
+                const unsigned long long c = sel[k];
+                id = (int)(~(unsigned)c);
+                sc = key_score((unsigned)(c >> 32));
+            }
+            top_ids[(size_t)b * K + k] = id;
+            top_scores[(size_t)b * K + k] = sc;
+        }
+        TOPK_STAMP(8);
+    }
+}
+
+extern "C" int rk_topk_rows_impl(float *scores, long long ld, int nb, int n_items, const int *user_ids, const int *seen_ptr,
                                  const int *seen_idx, int K, int *top_ids, float *top_scores, const int *targets,
                                  int n_targets, float *target_score, int *target_rank, hipStream_t s)
 {
     if (K <= 0 || K > kMaxK) RK_FAIL(RK_EINVAL, "top-K: K must be in [1,%d]", kMaxK);
     if (n_targets < 0 || n_targets > 256 || (n_targets > 0 && (!targets || !target_score || !target_rank)))
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
+    if (ld < n_items) RK_FAIL(RK_EINVAL, "top-K: row stride %lld < n_items %d", ld, n_items);
+    // short rows (ml1m 3 702, Amazon-game 5 600 items): one wave per row, the row in registers.  Measured on 5 893 x 3 702
+    // (the headline evaluation): XX us against 50.5 us for the row-per-workgroup kernel below.
+    static const int no_wave = RK_TUNE_INT("RK_TOPK_NO_WAVE", 0);   // A/B only
+    if (!no_wave && n_items <= 96 * 64) {
+        const int nq = (n_items + 63) / 64;
+        const dim3 grid((nb + TOPK_WAVE_WG - 1) / TOPK_WAVE_WG), block(64 * TOPK_WAVE_WG);
+#define RK_TOPK_WAVE(NQ)                                                                                                              \
+    hipLaunchKernelGGL((topk_wave_kernel<NQ>), grid, block, 0, s, scores, ld, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, \
+                       top_scores, targets, n_targets, target_score, target_rank)
+        // NQ = ceil(n_items / 64) rounded up to an instantiated size (58 = the ml1m catalogue, 3 702 items, exactly)
+        if (nq <= 16) RK_TOPK_WAVE(16);
+        else if (nq <= 32) RK_TOPK_WAVE(32);
+        else if (nq <= 48) RK_TOPK_WAVE(48);
+        else if (nq <= 58) RK_TOPK_WAVE(58);
+        else if (nq <= 64) RK_TOPK_WAVE(64);
+        else if (nq <= 80) RK_TOPK_WAVE(80);
+        else if (nq <= 88) RK_TOPK_WAVE(88);
+        else RK_TOPK_WAVE(96);
+#undef RK_TOPK_WAVE
+        RK_CHECK_LAUNCH();
+        return RK_OK;
+    }
     const size_t row_bytes = ((size_t)n_items * sizeof(float) + 15) & ~(size_t)15;
     // LDS staging only pays while several workgroups still fit per CU (measured: a 138 KB row in LDS
     // is 2.8x SLOWER than streaming it from L2 -- one 4-wave workgroup per CU); ml1m-size rows tie.
@@ -352,10 +659,10 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
             attr_once.done(attr_dev);
         }
         // (one wave per short row -- NT = 64 -- was measured too: 333 vs 250 us for 5950 x 3702)
-        hipLaunchKernelGGL((topk_rows_kernel<true>), dim3(nb), dim3(kTopkNT), row_bytes, s, scores, n_items, user_ids, seen_ptr, seen_idx,
+        hipLaunchKernelGGL((topk_rows_kernel<true>), dim3(nb), dim3(kTopkNT), row_bytes, s, scores, ld, n_items, user_ids, seen_ptr, seen_idx,
                            K, top_ids, top_scores, targets, n_targets, target_score, target_rank);
     } else {
-        hipLaunchKernelGGL((topk_rows_kernel<false>), dim3(nb), dim3(kTopkNT), 0, s, scores, n_items, user_ids, seen_ptr, seen_idx, K,
+        hipLaunchKernelGGL((topk_rows_kernel<false>), dim3(nb), dim3(kTopkNT), 0, s, scores, ld, n_items, user_ids, seen_ptr, seen_idx, K,
                            top_ids, top_scores, targets, n_targets, target_score, target_rank);
     }
     RK_CHECK_LAUNCH();
@@ -369,6 +676,11 @@ extern "C" int rk_topk_rows_impl(float *scores, int nb, int n_items, const int *
 // 4 096 x 34 474 x 64 0.47 vs 0.51, 4 096 x 500 000 x 64 5.56 vs 6.44, 4 000 x 300 000 x 64 3.43 vs 3.89; and where it is NOT
 // taken: 5 893 x 3 702 x 64 0.105 vs 0.098, 2 048 x 131 072 x 64 1.55 vs 1.02, 2 048 x 300 000 x 64 3.39 vs 2.19, 4 096 x 34 474 x
 // 128 0.72 vs 0.64 (profiles/r04_score_corner.txt).
+// Row stride of the GEMM path's score matrix: n_items rounded up to 32 floats.  Rows then start on 128-byte lines and every
+// 16-column (64-byte) segment a wave of the GEMM stores is one aligned half line -- with the natural stride (3 702 floats: rows
+// 8-byte aligned) each of those segments straddled two lines.  Costs 0.3 % more scratch at the ml1m size.
+static inline long long score_ld(int n_items) { return ((long long)n_items + 31) & ~31LL; }
+
 static bool panel_by_default(int nb, int n_items, int dim, int K, int n_targets)
 {
     if (!pan_supported(n_items, dim, K, n_targets)) return false;
@@ -397,7 +709,8 @@ RK_EXPORT int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32
         pl.panel_safe = request && request->panel_safe ? 1 : 0;
         pl.scratch_floats = (int64_t)pan_scratch_floats(n_items, dim);   // the k-permuted item table
     } else {
-        pl.scratch_floats = (int64_t)nb * n_items;                      // the score matrix
+        pl.ld_scores = (int32_t)score_ld(n_items);
+        pl.scratch_floats = (int64_t)nb * pl.ld_scores;                 // the score matrix
     }
     *out = pl;
     return RK_OK;
@@ -439,10 +752,11 @@ RK_EXPORT int rk_score_topk(int32_t dim, const float *utab, int32_t nb, const in
     g.M = nb; g.N = n_items; g.K = dim;
     g.A = utab; g.a_rs = dim; g.a_cs = 1; g.a_ridx = user_ids;  // the user rows are gathered by the tile loads
     g.B = itab; g.b_rs = dim; g.b_cs = 1;
-    g.C = scratch; g.ldc = n_items;
+    if (plan->ld_scores != (int32_t)score_ld(n_items)) RK_FAIL(RK_EINVAL, "rk_score_topk: plan->ld_scores %d (rk_score_topk_plan sets it)", plan->ld_scores);
+    g.C = scratch; g.ldc = plan->ld_scores;
     g.row_bias = ubias; g.col_bias = ibias; g.const_add = mean;
     RK_HIP(gemm_f32_launch(g, s));
-    return rk_topk_rows_impl(scratch, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
+    return rk_topk_rows_impl(scratch, plan->ld_scores, nb, n_items, user_ids, seen_ptr, seen_idx, K, top_ids, top_scores, targets, n_targets,
                              target_score, target_rank, s);
 }
 

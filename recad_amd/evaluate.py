@@ -110,6 +110,106 @@ def full_catalog_topk(victim, user_ids, seen_ptr, seen_idx, targets, K=100, chun
     }
 
 
+class EvalSession:
+    """A full evaluation of ONE victim on a FIXED user list, set up once and run many times (normal.py:57-93,111-160: propagate,
+    score every unseen item, top-K, target score / rank, HR@k numerators): every buffer, the scoring plan and the argument
+    marshalling are made in __init__, run() only launches -- and, from its second call on (graph=True), replays ONE hipGraph
+    holding the victim's propagation, the GEMM + selection launches of every user block and the HR@k reduction, so an
+    evaluation costs one enqueue instead of a Python loop (the perturb-retrain loops that re-score a victim after every
+    epoch, bench.py's scorings / s).  Results are device tensors owned by the session, overwritten by the next run().
+
+    The graph holds the victim's table / workspace pointers: it is re-captured when the victim's native handle changes
+    (new graph, new dimension), and never used for victims without scoring_tables() (NCF: score_matrix) or with a
+    host-synchronising propagation (fuse_layers)."""
+
+    def __init__(self, victim, user_ids, seen_ptr, seen_idx, targets, K=100, topks=(10, 20, 50, 100), chunk=None, request=None, graph=True):
+        _lib.require_gpu()
+        if not hasattr(victim, "scoring_tables"):
+            raise TypeError("EvalSession needs a victim with scoring_tables() (dot-product scoring); use full_catalog_topk")
+        self.victim, self.K, self.topks = victim, int(K), tuple(int(k) for k in topks)
+        self.request = SCORE_REQUEST if request is None else request
+        tabs = victim.scoring_tables()
+        if tabs is None:
+            raise TypeError("EvalSession: the victim scores through score_matrix() right now (logit dropout active); use full_catalog_topk")
+        # victims whose tables are plain parameter views (MF: scoring_tables_static) are asked once -- their scoring_tables() reads
+        # a scalar back, which a stream capture does not allow; LightGCN's launches the propagation and is called per run
+        self._static_tabs = tabs if getattr(victim, "scoring_tables_static", False) else None
+        utab, itab = tabs[0], tabs[1]
+        dev = itab.device
+        self.dev = dev
+        as_dev = lambda a: (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
+                            else torch.as_tensor(np.asarray(a), dtype=torch.int32, device=dev)).contiguous()
+        self.users, self.seen_ptr, self.seen_idx, self.targets = as_dev(user_ids), as_dev(seen_ptr), as_dev(seen_idx), as_dev(targets)
+        if self.seen_idx.numel() == 0:
+            self.seen_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        n, T = self.users.numel(), self.targets.numel()
+        self.n, self.T = n, T
+        n_items, d = itab.shape
+        if chunk is None:
+            chunk = max(256, min(8192, (1 << 31) // max(n_items, 1)))
+        chunk = max(1, min(int(chunk), max(n, 1)))
+        plan = score_plan(max(n, 1), n_items, d, self.K, T, self.request)
+        if plan.path != _lib.RK_SCORE_PANEL:
+            plan = score_plan(chunk, n_items, d, self.K, T, self.request)
+        else:
+            chunk = max(n, 1)
+        self.plan, self.chunk = plan, chunk
+        self.scratch = torch.empty(int(plan.scratch_floats), dtype=torch.float32, device=dev)
+        self.top_ids = torch.empty(n, self.K, dtype=torch.int32, device=dev)
+        self.top_scores = torch.empty(n, self.K, dtype=torch.float32, device=dev)
+        self.tscore = torch.empty(n, max(T, 1), dtype=torch.float32, device=dev)
+        self.trank = torch.empty(n, max(T, 1), dtype=torch.int32, device=dev)
+        self.ks = torch.as_tensor(list(self.topks), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(max(T, 1), len(self.topks), dtype=torch.int32, device=dev)
+        self.want_graph = bool(graph) and not getattr(victim, "fuse_layers", False)
+        self._graph, self._graph_key, self._runs = None, None, 0
+
+    def _launch(self):
+        v, L, plan = self.victim, _lib.lib(), self.plan
+        utab, itab, ubias, ibias, mean = self._static_tabs if self._static_tabs is not None else v.scoring_tables()   # (LightGCN: the propagation's launches)
+        utab, itab = utab.contiguous(), itab.contiguous()
+        if ubias is not None:
+            ubias, ibias = ubias.contiguous().view(-1), ibias.contiguous().view(-1)
+        n_items, d = itab.shape
+        st = _lib.stream_ptr()
+        for s in range(0, self.n, self.chunk):
+            e = min(self.n, s + self.chunk)
+            _lib.check(L.rk_score_topk(
+                d, _lib.ptr(utab), e - s, _lib.ptr(self.users[s:e]), _lib.ptr(itab), n_items, _lib.ptr(ubias), _lib.ptr(ibias), float(mean),
+                _lib.ptr(self.seen_ptr), _lib.ptr(self.seen_idx), self.K, _lib.ptr(self.top_ids[s:e]), _lib.ptr(self.top_scores[s:e]),
+                _lib.ptr(self.targets), self.T, _lib.ptr(self.tscore[s:e]), _lib.ptr(self.trank[s:e]), C.byref(plan), _lib.ptr(self.scratch), st),
+                "rk_score_topk")
+        if self.T and self.n:
+            _lib.check(L.rk_hit_counts(_lib.ptr(self.trank), self.n, self.T, _lib.ptr(self.ks), len(self.topks), _lib.ptr(self.counts), st), "rk_hit_counts")
+
+    def run(self):
+        """-> dict of device tensors (top_ids [n, K], top_scores, target_score [n, T], target_rank, hit_counts [T, len(topks)]);
+        no synchronisation."""
+        self._runs += 1
+        key = getattr(self.victim, "_handle_key", None)
+        if self.want_graph and self._graph is not None and self._graph_key == key:
+            self._graph.replay()
+        else:
+            self._launch()
+            if self.want_graph and self._runs >= 2 and (self._graph is None or self._graph_key != key):
+                # capture on the SECOND run (a single evaluation never pays for a capture; handles, plans and lazily built
+                # schedules exist by now); a failed capture keeps the eager path
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._launch()
+                    self._graph, self._graph_key = g, getattr(self.victim, "_handle_key", None)
+                    self._graph.replay()     # (the capture itself ran nothing: results must come from an execution)
+                except Exception as exc:    # noqa: BLE001
+                    import warnings
+                    warnings.warn(f"EvalSession: hipGraph capture unavailable ({type(exc).__name__}: {exc}); evaluating with direct launches")
+                    self.want_graph, self._graph = False, None
+                    torch.cuda.synchronize()
+        return {"top_ids": self.top_ids, "top_scores": self.top_scores, "target_score": self.tscore[:, :self.T],
+                "target_rank": self.trank[:, :self.T], "hit_counts": self.counts[: max(self.T, 0)]}
+
+
 _KS_CACHE = {}
 
 

@@ -151,6 +151,8 @@ class MF(BaseVictim):
             pbar.set_description(f"loss: {mean_loss:.4f}")
         return (mean_loss,)
 
+    scoring_tables_static = True   # views of the parameters, no launches: evaluate.EvalSession asks once and keeps them
+
     def scoring_tables(self):
         """Tables for the dot-product scoring path; None while a logit dropout is active (the evaluation then goes
         through score_matrix())."""

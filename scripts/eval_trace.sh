@@ -8,7 +8,7 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 # last evaluation = from the last-but-one topk kernel's successor to the end
-idx = [i for i, r in enumerate(rows) if "topk_rows" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "topk_" in r["Kernel_Name"]]
 lo, hi = idx[-2] + 1, idx[-1] + 1
 # include trailing HR reduction kernels of the last evaluation
 seg = rows[lo:min(len(rows), hi + 6)]

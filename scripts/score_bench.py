@@ -14,7 +14,7 @@ tg = torch.zeros(1, dtype=torch.int32, device=dev)
 top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev); top_sc = torch.empty(nb, K, device=dev)
 ts = torch.empty(nb, 1, device=dev); tr = torch.empty(nb, 1, dtype=torch.int32, device=dev)
 plan = score_plan(nb, I, d, K, 1, {"path": "gemm"})
-scratch = torch.empty(nb * I, device=dev)
+scratch = torch.empty(int(plan.scratch_floats), device=dev)
 def run():
     _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(u), nb, _lib.ptr(ids), _lib.ptr(it), I, None, None, 0.0, _lib.ptr(seen_ptr), _lib.ptr(seen_idx), K,
                                         _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 1, _lib.ptr(ts), _lib.ptr(tr), C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "x")

@@ -371,8 +371,8 @@ def test_score_topk_bitexact_vs_oracle(gpu_device, d, with_bias, path):
         assert (plan.panel_rows, plan.panel_ntw, plan.panel_safe) == (16 if narrow else 32 if path.startswith("panel32") else 16,
                                                                       8 if narrow else 15, 1 if path.endswith("safe") else 0)
     else:
-        assert need == nb * I
-    got_scores = None if path.startswith("panel") else scratch[: nb * I].view(nb, I).cpu().numpy()
+        assert plan.ld_scores == (I + 31) // 32 * 32 and need == nb * plan.ld_scores
+    got_scores = None if path.startswith("panel") else scratch[: nb * plan.ld_scores].view(nb, plan.ld_scores)[:, :I].cpu().numpy()
     top_ids, top_sc, ts, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts.cpu().numpy(), tr.cpu().numpy()
     for b in range(nb):
         seen = seen_lists[int(user_ids[b])]
@@ -459,6 +459,39 @@ def test_workflow_end_to_end_on_device(gpu_device):
                                ds.n_items, ptr.astype(np.int32), idx, [0], [10, 20, 50, 100], users=users)
         for i, k in enumerate([10, 20, 50, 100]):
             assert abs(rows[:, 2 + i].mean() - res[f"HR@{k}"]) < 1e-12, (name, k)
+
+
+def test_eval_session_matches_full_catalog_topk(gpu_device):
+    """evaluate.EvalSession (buffers and plan made once; from its second run on ONE hipGraph replay of propagation + GEMM +
+    selection + HR@k counts) against full_catalog_topk + hit_counts: identical bits on the first (eager), second (captured) and
+    third (replayed) run, across user blocks (chunk < n), for LightGCN (both SpMM forms) and MF -- and after a train epoch in
+    between the replay must score the UPDATED tables (the graph holds pointers, not values)."""
+    from recad_amd import dataset, model, synth
+    from recad_amd.evaluate import EvalSession, eligible_users, full_catalog_topk, hit_counts
+    d = synth.make("tiny")
+    topks = (10, 20, 50, 100)
+    for name, sample, need_graph, use_lds in (("lightgcn", "pairwise", True, True), ("lightgcn", "pairwise", True, False), ("mf", "pointwise", False, None)):
+        ds = dataset.from_config("implicit", "tiny", train_csr=d["train"], valid_csr=d["valid"], test_csr=d["test"],
+                                 need_graph=need_graph, device=gpu_device, sample=sample, graph_source="train", seed=5)
+        kw = {"latent_dim_rec": 32} if name == "lightgcn" else {"embedding_size": 32}
+        torch.manual_seed(3)
+        v = model.from_config("victim", name, **kw).I(dataset=ds).to(gpu_device)
+        if use_lds is not None:
+            v.use_lds = use_lds
+        ptr, idx = ds.train_csr_sorted()
+        targets = np.array([0, 7], dtype=np.int32)
+        users = eligible_users(ptr, idx, targets)
+        sess = EvalSession(v, users, ptr, idx, targets, K=100, topks=topks, chunk=max(64, len(users) // 3))
+        for round_ in range(5):
+            if round_ == 3:
+                v.train_step(progress_bar=None)     # the tables move; the captured graph must see the new values
+            got = {k: t.clone() for k, t in sess.run().items()}
+            ref = full_catalog_topk(v, users, ptr, idx, targets, K=100, chunk=max(64, len(users) // 3), to_host=False)
+            ref_hits = hit_counts(ref["target_rank"], topks)
+            for k in ("top_ids", "top_scores", "target_score", "target_rank"):
+                assert torch.equal(got[k], ref[k]), (name, use_lds, round_, k)
+            assert torch.equal(got["hit_counts"], ref_hits), (name, use_lds, round_)
+        assert sess._graph is not None, "the second run must have captured the evaluation"
 
 
 def test_defense_workflow_on_device(gpu_device):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/recad_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().rk_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().rk_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_no_cpu_fallback():
@@ -333,7 +333,7 @@ def test_score_topk_plan_names_the_path():
             assert (p.nb, p.n_items, p.dim, p.K, p.n_targets) == (nb, I, d, K, T)
             return p.path, int(p.scratch_floats)
         panel = lambda I, d: (_lib.RK_SCORE_PANEL, I * 16 * (2 if d <= 32 else 4 if d <= 64 else 8 if d <= 128 else 16) + 4)
-        gemm = lambda nb, I: (_lib.RK_SCORE_GEMM, nb * I)
+        gemm = lambda nb, I: (_lib.RK_SCORE_GEMM, nb * ((I + 31) // 32 * 32))   # rows padded to 128-byte lines (plan.ld_scores)
         assert f(5893, 3702, 64) == gemm(5893, 3702)                  # ml1m: GEMM + selection
         assert f(16384, 34474, 64) == panel(34474, 64)
         assert f(54617, 34474, 128) == panel(34474, 128)
