@@ -436,9 +436,13 @@ typedef struct rk_ncf_desc {
     float *acts, *dacts;                       /* each float[max_batch * sum_{l=0..L} in_l] */
     float *d0;                                 /* float[max_batch] */
     int32_t max_batch, reserved;
-    /* optional split-K workspace for the backward (dX) tower GEMMs whose whole-K tiling would not fill
-     * the chip (batch 1024 against a few hundred outputs): K-slices park partial products here and are
-     * added in slice order (deterministic).  8 M floats is plenty for batch 1024; NULL / 0: no splitting. */
+    /* K-slice workspace.  (1) backward (dX) tower GEMMs whose whole-K tiling would not fill the chip (batch 1024 against a
+     * few hundred outputs): K-slices park partial products here and are added in slice order (deterministic); optional
+     * for that.  (2) REQUIRED by rk_ncf_train_epoch when a tower layer's input width is a multiple of 256: the training
+     * forward of such a layer sums its products in 8 consecutive k-blocks combined pairwise (ATen-like error: the ReLU
+     * gates it decides are the masks of the backward; csrc/ncf.hip gemm_fwd_blocked, oracle ncf_forward_one_ex), the blocks
+     * parked here as [8][rows, out] -- 8 * max_batch * (widest layer output) floats run every layer in one piece, less
+     * makes row chunks (>= 8 * 64 * out).  rk_ncf_forward (scoring) keeps the single k-ordered chain. */
     float *gemm_scratch;
     int64_t gemm_scratch_floats;
     float *wgrad_part;                         /* training: float[ceil(max_batch/64) * (2*factor + 1)] */

@@ -290,9 +290,15 @@ API float orc_mf_step(int32_t U, int32_t I, int32_t d, float *ue, float *ie, flo
  * Tower layer l: Linear(in_l -> in_l/2) + ReLU, in_0 = 2E, E = f*2^(L-1) (ncf.py:41-47).
  * W[l] is [out,in] row-major (nn.Linear), pw is [2f] (gmf part first, ncf.py:129), pb scalar.
  * acts (optional) receives per pair: x0[2E], then each layer's post-ReLU output. */
-static void ncf_forward_one(int32_t f, int32_t L, const float *ug, const float *ig, const float *um, const float *im,
-                            const float *const *W, const float *const *bias, const float *pw, float pb,
-                            float *acts, float *out)
+/* blocked != 0: the TRAINING forward of the HIP path (csrc/ncf.hip, ncf_forward_chunk(train)): a tower layer whose input width
+ * is a multiple of 256 sums its products in 8 consecutive k-blocks (each a k-ordered chain) combined pairwise,
+ * ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- the error of ATen's blocked sgemm (2e-6 of the layer's rms at K = 2048 instead of
+ * 9e-6 for one chain), so that four times fewer numerically-zero pre-activations land on the other side of their ReLU gate
+ * than fp64 / the reference puts them (one flipped gate changes every lower dW by a rank-1 term of weight 1/B).  Narrower
+ * layers and the evaluation forward keep the single chain. */
+static void ncf_forward_one_ex(int32_t f, int32_t L, const float *ug, const float *ig, const float *um, const float *im,
+                               const float *const *W, const float *const *bias, const float *pw, float pb,
+                               float *acts, float *out, int blocked)
 {
     int32_t E = f << (L - 1);
     float *x = acts;
@@ -305,7 +311,18 @@ static void ncf_forward_one(int32_t f, int32_t L, const float *ug, const float *
         for (int32_t r = 0; r < o; ++r) {
             const float *w = W[l] + (size_t)r * in;
             float s = 0.f;
-            for (int32_t k = 0; k < in; ++k) s += w[k] * x[k];
+            if (blocked && in % 256 == 0) {
+                float p[8];
+                const int32_t blk = in / 8;
+                for (int32_t q = 0; q < 8; ++q) {
+                    float t = 0.f;
+                    for (int32_t k = q * blk; k < (q + 1) * blk; ++k) t += w[k] * x[k];
+                    p[q] = t;
+                }
+                s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            } else {
+                for (int32_t k = 0; k < in; ++k) s += w[k] * x[k];
+            }
             s += bias[l][r];
             y[r] = s > 0.f ? s : 0.f;
         }
@@ -316,6 +333,13 @@ static void ncf_forward_one(int32_t f, int32_t L, const float *ug, const float *
     for (int32_t k = 0; k < f; ++k) s += pw[k] * (ug[k] * ig[k]);
     for (int32_t k = 0; k < f; ++k) s += pw[f + k] * x[k];
     *out = s + pb;
+}
+
+static void ncf_forward_one(int32_t f, int32_t L, const float *ug, const float *ig, const float *um, const float *im,
+                            const float *const *W, const float *const *bias, const float *pw, float pb,
+                            float *acts, float *out)
+{
+    ncf_forward_one_ex(f, L, ug, ig, um, im, W, bias, pw, pb, acts, out, 0);
 }
 
 static size_t ncf_act_floats(int32_t f, int32_t L)
@@ -362,7 +386,7 @@ API float orc_ncf_grads(int32_t U, int32_t I, int32_t f, int32_t L, const float 
         size_t u = (size_t)users[b], i = (size_t)items[b];
         const float *ug = ugt + u * f, *ig = igt + i * f;
         float x;
-        ncf_forward_one(f, L, ug, ig, umt + u * E, imt + i * E, W, bias, pw, pb, acts, &x);
+        ncf_forward_one_ex(f, L, ug, ig, umt + u * E, imt + i * E, W, bias, pw, pb, acts, &x, 1);
         float y = (float)labels[b];
         loss += (double)bce_logits(x, y);
         float d0 = (sigmoid_f(x) - y) * invB;

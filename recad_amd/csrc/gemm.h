@@ -790,7 +790,9 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         attr_once.done(attr_dev);
     }
     const int nwg128 = ((g.N + 127) / 128) * ((g.M + 127) / 128);
-    if (nwg128 < 384 && variant != 3 && !g.a_ridx && !g.a_rmod) {  // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs
+    // skinny problem (NCF tower at B=1024): 64-tiles fill 4x more CUs; parked K-slices (sk_part) are only wired for this form and
+    // take it at any size (the blocked training forward of large batches)
+    if ((nwg128 < 384 || (g.split_k > 1 && g.sk_part)) && variant != 3 && !g.a_ridx && !g.a_rmod) {
         const int nwg = ((g.N + 63) / 64) * ((g.M + 63) / 64);
         GemmArgs g2 = g;
         const int splits = g2.split_k = gemm_effective_splits(g.K, g.split_k);

@@ -36,13 +36,22 @@ static int pick_splits(int M, int N, int K, long long cap_floats)
 
 // y = epilogue(sum_q part[q]) in slice order q = 0..sp-1: bias + ReLU (forward) or the ReLU mask (dX)
 __global__ void slices_epilogue_kernel(long long n4, int N, int sp, const float *__restrict__ part, float *__restrict__ y,
-                                       const float *__restrict__ bias, int relu, const float *__restrict__ mask)
+                                       const float *__restrict__ bias, int relu, const float *__restrict__ mask, int pairwise)
 {
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4 *>(part)[q];
-        for (int k = 1; k < sp; ++k) {
-            const float4 t = reinterpret_cast<const float4 *>(part)[(long long)k * n4 + q];
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        if (pairwise && sp == 8) {   // ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)): the blocked training forward
+            float4 t[8];
+            t[0] = v;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = reinterpret_cast<const float4 *>(part)[(long long)k * n4 + q];
+            auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+            v = add(add(add(t[0], t[1]), add(t[2], t[3])), add(add(t[4], t[5]), add(t[6], t[7])));
+        } else {
+            for (int k = 1; k < sp; ++k) {
+                const float4 t = reinterpret_cast<const float4 *>(part)[(long long)k * n4 + q];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
         }
         if (bias) {
             const float4 bb = *reinterpret_cast<const float4 *>(bias + (q * 4) % N);
@@ -80,8 +89,39 @@ static int gemm_auto(hipStream_t s, int M, int N, int K, const float *A, long lo
     RK_HIP(gemm_f32_launch(g, s));
     const long long n4 = (long long)M * N / 4;
     hipLaunchKernelGGL(slices_epilogue_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, n4, N, sp,
-                       scratch, C, bias, relu, mask);
+                       scratch, C, bias, relu, mask, 0);
     RK_CHECK_LAUNCH();
+    return RK_OK;
+}
+
+// The TRAINING forward of a tower layer whose input width K is a multiple of 256: y = relu(sum + bias) with the products summed
+// in kFwdBlocks consecutive k-blocks (each the MFMA's k-ordered chain) combined PAIRWISE -- the oracle's ncf_forward_one_ex
+// (blocked) order.  Why: a layer's ReLU gates are the masks of its backward, and a pre-activation that is zero to within the
+// summation noise can land on either side; one flipped gate changes every lower dW by a rank-1 term of weight 1/B (1e-3 of
+// the largest entry at factor 256).  One 2048-long chain is 9e-6 of the layer's rms off fp64, ATen's blocked sgemm 2.5e-6,
+// this form 2e-6: on the reference's golden batch the single chain flips one of 1.8 M gates (|z| = 7e-10), this form none, and
+// the step-1 gradients go from 9e-4 to 1e-6 of the reference's.  K-slices of the 64-tile kernels park their partial products in
+// `scratch` ([8][rows, N], rows in chunks that fit); they also fill the chip better than whole-K tiles at batch 1024.
+static constexpr int kFwdBlocks = 8;
+static inline bool fwd_blocked(int K) { return K % 256 == 0; }
+static int gemm_fwd_blocked(hipStream_t s, int M, int N, int K, const float *A, const float *W, float *Y, const float *bias,
+                            float *scratch, long long cap_floats)
+{
+    if (!scratch || cap_floats < (long long)kFwdBlocks * 64 * N || N % 4) RK_FAIL(RK_EINVAL, "ncf: the blocked forward needs desc.gemm_scratch of >= %lld floats", (long long)kFwdBlocks * 64 * N);
+    const int rows_cap = (int)std::min<long long>(M, cap_floats / ((long long)kFwdBlocks * N) / 64 * 64);
+    for (int m0 = 0; m0 < M; m0 += rows_cap) {
+        const int mc = std::min(rows_cap, M - m0);
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.split_k = kFwdBlocks; g.sk_part = scratch; g.sk_stride = (long long)mc * N;
+        g.M = mc; g.N = N; g.K = K; g.A = A + (size_t)m0 * K; g.a_rs = K; g.a_cs = 1; g.B = W; g.b_rs = K; g.b_cs = 1;
+        g.C = Y + (size_t)m0 * N; g.ldc = N;
+        RK_HIP(gemm_f32_launch(g, s));
+        const long long n4 = (long long)mc * N / 4;
+        hipLaunchKernelGGL(slices_epilogue_kernel, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, n4, N, kFwdBlocks,
+                           scratch, Y + (size_t)m0 * N, bias, 1, (const float *)nullptr, 1);
+        RK_CHECK_LAUNCH();
+    }
     return RK_OK;
 }
 
@@ -385,7 +425,8 @@ static DropSpec drop_spec(const rk_ncf_desc &d, unsigned long long call, int lay
 // forward for one chunk of nb pairs; acts[l] = input of layer l (after its dropout), acts[L] = tower output [nb, f].
 // `call` numbers the dropout masks (train: the global step; scoring: desc.drop_call and the chunk).
 static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, unsigned long long call, hipStream_t s,
-                             const float *prefix = nullptr)   // prefix: [users of the call][out0] layer-0 user halves
+                             const float *prefix = nullptr,   // prefix: [users of the call][out0] layer-0 user halves
+                             bool train = false)              // train: layers of width % 256 == 0 use the blocked sums (gemm_fwd_blocked)
 {
     if (d.mode == RK_NCF_GMF) return RK_OK;   // no tower (ncf.py:118-127)
     const int L = d.n_layers, E = d.factor << (L - 1);
@@ -410,7 +451,11 @@ static int ncf_forward_chunk(const rk_ncf_desc &d, const PairSrc &p, int nb, uns
     for (int l = l_first; l < L; ++l) {
         const int in = in_of(d, l), out = in / 2;
         float *y = d.acts + act_off(d, l + 1, d.max_batch);
-        int rc = gemm_auto(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
+        int rc;
+        if (train && fwd_blocked(in))
+            rc = gemm_fwd_blocked(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), d.W[l], y, d.b[l], d.gemm_scratch, d.gemm_scratch_floats);
+        else
+            rc = gemm_auto(s, nb, out, in, d.acts + act_off(d, l, d.max_batch), in, 1, d.W[l], in, 1,
                            y, d.b[l], 1, nullptr, nullptr, 0);  // whole-K: see gemm_auto
         if (rc) return rc;
         if (d.dropout > 0.f && l + 1 < L) {   // Dropout in front of layer l+1 (none in front of predict_layer)
@@ -502,7 +547,7 @@ RK_EXPORT int rk_ncf_train_epoch(const rk_ncf_desc *desc, const int64_t *users, 
         const int nb = (int)std::min<long long>(batch, n - off);
         PairSrc p{users, items, nullptr, 0, off};
         const unsigned long long call = (unsigned long long)(adam_t0 + step);
-        rc = ncf_forward_chunk(d, p, nb, call, s);
+        rc = ncf_forward_chunk(d, p, nb, call, s, nullptr, true);
         if (rc) return rc;
         float *xl = d.acts + act_off(d, L, d.max_batch), *dxl = d.dacts + act_off(d, L, d.max_batch);
         hipLaunchKernelGGL(ncf_predict_kernel, dim3(std::min(RK_LOSS_PARTIALS, (nb + 3) / 4)), dim3(256), 0, s, p, nb, f, d.mode, d.ug, d.ig,

@@ -100,7 +100,8 @@ class NCF(BaseVictim):
                   "grad": [torch.zeros_like(t) for t in ts],
                   "acts": torch.empty(mb * widths, device=dev), "dacts": torch.empty(mb * widths, device=dev),
                   "d0": torch.empty(mb, device=dev), "max_batch": mb,
-                  "gemm_scratch": torch.empty(8 << 20, device=dev),  # split-K slices of the dX GEMMs (rk_ncf_desc)
+                  # split-K slices of the dX GEMMs and the 8 k-blocks of the blocked training forward ([8][batch, widest output])
+                  "gemm_scratch": torch.empty(max(8 << 20, 8 * mb * (f * 2 ** (L - 1))), device=dev),
                   "wgrad_part": torch.empty(((mb + 63) // 64) * (2 * f + 1), device=dev)}
             self._ws = ws
         ws = self._ws

@@ -244,12 +244,15 @@ def test_lightgcn_forward_matches_oracle(gpu_device):
     assert np.allclose(out, ref, rtol=1e-5, atol=1e-7)
 
 
-def _eval_against_golden(g, m, device):
+def _eval_against_golden(g, m, device, first_users_only=False, chunk=1000, min_exact=0.97):
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hr_rows
     users = eligible_users(g["train_ptr"], g["train_idx"], g["target_ids"])
+    if first_users_only:   # (the factor-256 goldens: the reference's per-user evaluation was recorded for the first eligible users only)
+        assert np.array_equal(users[: len(g["eval_users"])], g["eval_users"])
+        users = users[: len(g["eval_users"])]
     assert np.array_equal(users, g["eval_users"])
     K = 100
-    res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=K + 1, chunk=1000)   # (the 101st score decides ties at the @100 cutoff)
+    res = full_catalog_topk(m, users, g["train_ptr"], g["train_idx"], g["target_ids"], K=K + 1, chunk=chunk)   # (the 101st score decides ties at the @100 cutoff)
     rows = hr_rows(users, res, g["topks"])
     ref = g["eval_rows"]
     assert rows.shape == ref.shape and np.array_equal(rows[:, 0], ref[:, 0])
@@ -271,8 +274,8 @@ def _eval_against_golden(g, m, device):
         assert amb.sum() <= 0.02 * len(rows) + 2, (k, int(amb.sum()))   # the allowance must stay a handful of rows, not a blanket
     es = int(g["eval_stride"])
     mine = [(res["top_ids"][r][:K], res["top_scores"][r][:K]) for r in range(0, len(users), es)]
-    exact = G.compare_topk_lists(mine, g["top_ids"], g["top_scores"])
-    assert exact >= 0.97 * len(mine), exact
+    exact = G.compare_topk_lists(mine, g["top_ids"], g["top_scores"])   # (asserts: every differing position sits in a run of reference scores tied to 2e-6)
+    assert exact >= min_exact * len(mine), exact
     res = dict(res, top_ids=res["top_ids"][:, :K], top_scores=res["top_scores"][:, :K])
     return res, users
 
@@ -638,12 +641,16 @@ def test_ncf_train_golden(gpu_device, name):
     part = m._run_epoch(b0["users"], b0["items"], b0["labels"], n0, apply_update=False)
     assert abs(float(part.sum()) - g["losses"][0]) <= LOSS_RTOL * abs(g["losses"][0])
     big = f >= 256
-    if not big:
+    # f256 / L = 3 joins the tight pin against the REFERENCE's golden (round 5): the training forward sums wide layers in 8 k-blocks
+    # combined pairwise (csrc/ncf.hip gemm_fwd_blocked: ATen-like error), and on the golden batch no ReLU gate differs from fp64 /
+    # the reference any more -- one 2048-long chain flipped one of 1.8 M gates (|z| = 7e-10) and was 9e-4 off on MLP_layers.1.weight
+    tight = not big or name == "ncf_game_f256_l3"
+    if tight:
         for nme, gr in zip(names, m._ws["grad"]):
             got, ref = pick(nme, gr), g["grad1_" + nme]
             err = np.abs(got - ref.reshape(got.shape)).max() / np.abs(ref).max()
             assert err < 2e-5, (nme, err)
-    else:
+    if big:
         # factor_num = 256: step-1 gradients of the lower tower layers differ from the golden by up to 1e-3 (L = 3) / 1e-2
         # (L = 5) of the largest entry.  The fp64 arbiter below shows what that is: a handful of the 1.8 M (L = 3) / 8 M
         # (L = 5) pre-activations are zero to within fp32 summation noise, the k-ordered fmaf chain (GPU == oracle) and
@@ -653,7 +660,7 @@ def test_ncf_train_golden(gpu_device, name):
         # the tie-ambiguous positions of this path, like equal scores in a top-K list; (2) with the gates forced to the
         # GPU's choice the fp64 gradient equals the GPU's to fp32 rounding, for EVERY tensor -- no 3e-2 allowance.
         n_amb = _ncf_fp64_gate_arbiter(m, g, (ug, ig, um, im), W, b, pw, pb, names, pick)
-        assert n_amb <= 64, n_amb
+        assert n_amb <= (0 if L <= 3 else 64), n_amb   # L = 3: every gate as fp64 decides it; L = 5: the reference itself is 1.3e-2 off fp64
     if big:
         # and tightly against the oracle (same summation order): the whole batch at L = 3 (3 s of CPU), a 128-sample batch
         # at L = 5 (the reference default depth, default.py:123-125: 10 s of CPU)
@@ -673,21 +680,20 @@ def test_ncf_train_golden(gpu_device, name):
         ds.steps = [s]
         (loss,) = m.train_step()
         assert abs(loss - g["losses"][s]) <= LOSS_RTOL * abs(g["losses"][s]), (s, loss, g["losses"][s])
-        if s == 0 and not big:   # (Adam's first step is +-lr * sign(g): a flipped gate row moves by a full lr, see below)
+        if s == 0 and tight:   # (Adam's first step is +-lr * sign(g): a flipped gate row moves by a full lr, see below)
             for nme in names:
                 assert G.relerr(pick(nme, params[nme]), g["after1_" + nme].reshape(pick(nme, params[nme]).shape)) < 2e-5, nme
     steps = len(g["batch_len"])
-    if not big:
+    if tight:
         for nme in names:
             # float-atomic summation order (embedding scatter, dW K-slices, bias column sums) varies run to run;
             # Adam turns that into O(lr) noise on near-cancelling entries, so allow a few more outliers than the
             # (deterministic) oracle check.  The activations themselves are deterministic (ordered K-slices).
             ok, info = G.adam_close(pick(nme, params[nme]), g["final_" + nme], 1e-3, steps, outlier_frac=5e-3, travel_frac=0.5)
             assert ok, (nme, info)
-    elif name == "ncf_game_f256_l3":
-        # f256: most entries of the first tower layers have gradients BELOW fp32 summation noise at this init, so Adam's
-        # sign-like first steps differ entry by entry between ATen and ANY k-ordered implementation: the trained tables
-        # are pinned by the oracle replaying the same steps instead (10 s of CPU)
+    if name == "ncf_game_f256_l3":
+        # ... and by the oracle replaying the same steps (10 s of CPU).  (Rounds 3-4 could pin the f256 tables ONLY this way and
+        # blamed gradients below fp32 summation noise; it was the one flipped gate of the single-chain forward, amplified by Adam.)
         for s_ in range(steps):
             nb_ = int(g["batch_len"][s_])
             orc.ncf_step(P, *(g["batches"][s_, k, :nb_] for k in range(3)))
@@ -695,7 +701,7 @@ def test_ncf_train_golden(gpu_device, name):
             ok, info = G.adam_close(params[nme].detach().cpu().numpy(), ref.reshape(tuple(params[nme].shape)), 1e-3, steps,
                                     outlier_frac=5e-3, travel_frac=0.5)
             assert ok, (nme, info)
-    else:
+    if name == "ncf_game_f256_l5":
         # f256 / L = 5 (the reference's default depth): the same pin on a model restarted from the initial tensors and
         # trained for 3 steps of 64 samples, GPU and oracle side by side (the oracle needs 5 s per such step)
         m2 = model.from_config("victim", "ncf", factor_num=f, num_layers=L).I(dataset=ds)
@@ -722,6 +728,12 @@ def test_ncf_train_golden(gpu_device, name):
         del m2, p2
     if name == "ncf_dev_f8_l3":
         _eval_against_golden(g, m, gpu_device)
+    if name == "ncf_game_f256_l3":
+        # config 5 against the REFERENCE's evaluation rows: target scores 1e-5, hit flags identical on tie-free rows, HR@{10,20,50,100}
+        # within 1e-4 relative + the cutoff-ambiguous rows, top-100 lists identical on the tie-free prefixes (normal.py:57-93)
+        # (24 recorded lists over a 5 600-item catalogue whose scores sit 1e-4 apart: 22 are identical outright, two differ inside
+        # runs of reference scores tied to 2e-6)
+        _eval_against_golden(g, m, gpu_device, first_users_only=True, chunk=8, min_exact=0.85)
     if "f256" in name:
         # the reference's per-user evaluation was recorded for the first eligible users only (eval_max_users)
         from recad_amd.evaluate import full_catalog_topk, hr_rows
