@@ -243,6 +243,12 @@ typedef struct rk_lightgcn_desc {
                                                * gradient is applied in closed form (lambda / nb * count * E0) and the BPR kernel
                                                * scatters three rows per triplet instead of six; coef must then hold
                                                * 3 * RK_MAX_GRAPH_STEPS floats */
+    int32_t *row_blocks;                      /* optional (ABI 9, row-gather path, with row_bits and n_layers >= 3): int32[4 + number of
+                                               * schedule blocks], this handle's own: word 0 counts, words 4.. list the workgroups of
+                                               * the schedule that hold a row of the current minibatch, so that the row-filtered last
+                                               * forward layer starts min(n_blocks, 3 * batch + row_blocks_extra) workgroups instead of
+                                               * all of them (csrc/spmm.h SpmmArgs::blk_mode) */
+    int32_t row_blocks_extra, reserved4;      /* upper bound of the schedule's long-row pieces (scratch_words / dim is one) */
     int32_t *lds_sync;                        /* optional (ABI 8), int32[RK_LDS_SYNC_WORDS], zero-initialised, this handle's own: with
                                                * it the L propagation layers of a forward / backward pass run as ONE launch (<= 4
                                                * layers per launch) whose workgroups hand the layers over to each other per column

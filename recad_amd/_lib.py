@@ -67,6 +67,7 @@ class LightGCNDesc(C.Structure):
         ("row_bits", C.c_void_p),
         ("keep_prob", C.c_float), ("reserved3", C.c_int32), ("drop_seed", C.c_uint64), ("tpos", C.c_void_p),
         ("lds_plan", C.c_void_p), ("lds_info", LdsInfo), ("lsum", C.c_void_p), ("e0s", C.c_void_p), ("ms", C.c_void_p), ("vs", C.c_void_p), ("cnt", C.c_void_p),
+        ("row_blocks", C.c_void_p), ("row_blocks_extra", C.c_int32), ("reserved4", C.c_int32),
         ("lds_sync", C.c_void_p),
     ]
 

@@ -663,7 +663,8 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
 
 // forward: light = mean_l A^l E0 ; uses buf_a/buf_b as ping-pong
 struct BatchRef {
-    int k;   // step of the chunk (the triplets themselves are found through the state block)
+    int k;       // step of the chunk (the triplets themselves are found through the state block)
+    int batch;   // minibatch size the step was set up for (bounds the marked-block list: <= 3 * batch rows)
 };
 
 // forward: light = mean_l A^l E0.  With a BatchRef (training) the first layer marks the minibatch's
@@ -694,6 +695,13 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
                 a.mark_bits = d.row_bits; a.mark_U = d.n_users; a.mark_k = batch->k; a.mark_state = d.state;
             }
             if (l == L) a.row_filter = d.row_bits;
+            // L >= 3: the launch between marking and filtering lists the workgroups that hold a marked row, and the filtered
+            // launch starts only those (spmm.h, SpmmArgs::blk_mode)
+            if (d.row_blocks && L >= 3 && batch->batch > 0) {
+                a.blk_count = d.row_blocks; a.blk_list = d.row_blocks + 4; a.blk_bits = d.row_bits;
+                a.blk_cap = (int)std::min<long long>(0x7fffffff, 3LL * batch->batch + (long long)std::max(d.row_blocks_extra, 0));
+                a.blk_mode = l == 1 ? 1 : l == L - 1 ? 2 : l == L ? 3 : 0;
+            }
         }
         if (drop == 1) set_dropout(a, d, l == 1 ? 1 : 2, batch ? batch->k : 0, d.drop_seed, false);
         else if (drop == 3) set_dropout(a, d, 3, 0, rk_drop_step_seed(d.drop_seed, mask_seed), false);
@@ -764,9 +772,9 @@ struct OrderedRef {   // non-null keys: ordered scatter
     int batch;
 };
 
-static int launch_step(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s, const OrderedRef &ord = OrderedRef{nullptr, 0})
+static int launch_step(const rk_lightgcn_desc &d, int k, int apply_update, int bump, hipStream_t s, int batch, const OrderedRef &ord = OrderedRef{nullptr, 0})
 {
-    const BatchRef br{k};
+    const BatchRef br{k, batch};
     int rc = launch_forward(d, s, &br, d.keep_prob > 0.f ? 1 : 0);
     if (rc) return rc;
     BprArgs b;
@@ -823,7 +831,8 @@ static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update,
     for (int i = 0; i < rk_lightgcn::kExecSlots; ++i) {
         rk_lightgcn::Exec &e = h->exec[i];
         if (e.exec && e.n_steps == n_steps && e.whole == whole && e.update == apply_update && e.det == h->deterministic &&
-            (!h->deterministic || (e.plan == ord.keys && e.batch == batch))) {
+            e.batch == batch &&   // (the batch size is baked into a capture: the marked-block launch's grid, spmm.h blk_cap)
+            (!h->deterministic || e.plan == ord.keys)) {
             e.stamp = ++h->clock;
             *out = e.exec;
             return RK_OK;
@@ -841,7 +850,7 @@ static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update,
     int rc = RK_OK;
     if (whole) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
     for (int k = 0; k < n_steps && rc == RK_OK; ++k)
-        rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, ord);
+        rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, batch, ord);
     if (whole && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
     hipError_t err = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -985,7 +994,7 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
     }
     const OrderedRef ord = ordered_ref(h, batch);
     for (; done < n_steps; ++done) {
-        rc = launch_step(d, 0, apply_update, 1, s, ord);
+        rc = launch_step(d, 0, apply_update, 1, s, batch, ord);
         if (rc) return rc;
     }
     return launch_epilogue(d, apply_update, s);

@@ -13,6 +13,7 @@
 // each, so one global_load_dwordx4 gathers 64/G different X rows.  Summation order is fixed
 // by the schedule => bit-reproducible.
 #pragma once
+#include <algorithm>
 #include <stdlib.h>
 
 #include "common.h"
@@ -61,6 +62,15 @@ struct SpmmArgs {
     // stream but are dealt to the lane groups anew (gather_round takes entry t*NG+grp of the COMPACTED chunk), so a
     // filtered sum equals the unfiltered one up to summation order -- deterministic for a fixed bitmap, not bit-equal.
     const unsigned *src_filter;
+    // The row-filtered launch (last forward layer of a train step) used to start EVERY workgroup of the schedule to find the
+    // few that hold a minibatch row: at the yelp shape 22 K workgroups took 67 us to compute <= 3 072 rows (dispatch, one
+    // descriptor load, one bitmap test, exit).  With a block list the launch before it (blk_mode 2) appends the ids of the
+    // workgroups that hold a marked row (one __syncthreads_or + one atomic per marked workgroup), and the filtered launch
+    // (blk_mode 3) starts only min(n_blocks, blk_cap) workgroups that take their ids from the list.  blk_mode 1 (the
+    // marking launch) zeroes the count.  List order varies run to run; every workgroup's work is independent of it.
+    int blk_mode, blk_cap;
+    int *blk_count, *blk_list;
+    const unsigned *blk_bits;
     unsigned *mark_bits;         // set the bits of the current minibatch (first forward layer)
     unsigned *clear_bits;        // zero the bitmap (last backward layer)
     int n_words, mark_U, mark_k;
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
 {
     constexpr int G = D / 4;
     __shared__ float4 part[WAVES][G];
+    __shared__ int blk_flag[WAVES];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (a.e.bump && blockIdx.x == 0 && threadIdx.x == 0) {
         a.e.state[ST_STEP_BASE] += a.e.bump;
@@ -323,8 +334,33 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     }
     DropCtx dc{};
     if (DROP) dc = drop_ctx(a);
-    int4 ds = a.wave_desc[(size_t)blockIdx.x * WAVES + w];  // {row, eb, ee, nseg}
-    const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, blockIdx.x, a.scratch);  // scalar loads, in flight under the gather
+    int bid = blockIdx.x;   // the schedule block this workgroup runs
+    if (a.blk_mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) a.blk_count[0] = 0;
+    if (a.blk_mode == 3) {
+        if ((int)blockIdx.x >= a.blk_count[0]) return;
+        bid = a.blk_list[blockIdx.x];
+    }
+    int4 ds = a.wave_desc[(size_t)bid * WAVES + w];  // {row, eb, ee, nseg}
+    const PieceRef pr = piece_ref(a.wave_desc, a.n_blocks, WAVES, bid, a.scratch);  // scalar loads, in flight under the gather
+    if (a.blk_mode == 2) {   // does this workgroup hold a row of the minibatch?  (every piece of a long row names the row)
+        bool mk = false;
+        if (ds.w >= 0) { if (ds.x >= 0 && lane == 0) mk = (a.blk_bits[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u; }
+        else if (PACKED && ds.x >= 0) {
+            if (lane % G == 0 && lane / G < ds.y) { const int r = pr.packed[ds.x + lane / G].x; mk = (a.blk_bits[(unsigned)r >> 5] >> (r & 31)) & 1u; }
+        }
+        // (no barrier of its own -- that cost the launch 10 us at the yelp shape: the waves' flags ride on the workgroup's one
+        // existing barrier, blk_append() below)
+        const bool any = __ballot(mk) != 0ULL;
+        if (lane == 0) blk_flag[w] = any ? 1 : 0;
+    }
+    auto blk_append = [&]() {   // after the workgroup's barrier, by its first thread
+        if (a.blk_mode == 2 && threadIdx.x == 0) {
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) any |= blk_flag[k];
+            if (any) a.blk_list[atomicAdd(a.blk_count, 1)] = (int)blockIdx.x;
+        }
+    };
     if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PACKED && ds.w < 0) {
@@ -362,6 +398,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
             for (int j = 0; j < 8; ++j) acc = f4_fma(aw[j], xv[j], acc);
         }
         __syncthreads();  // keep the workgroup's barrier count uniform
+        blk_append();
         if (pk.x >= 0 && !(a.dbg & 2)) spmm_epilogue<D>(a.e, pk.x, sub, acc, addv, sumv);
         return;
     }
@@ -370,6 +407,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
     }
     if (lane < G) part[w][lane] = acc;
     __syncthreads();
+    blk_append();
     if (ds.w > 0 && !(a.dbg & 2)) {  // leader wave of a row (or of a long row's piece), whole wave
         if (lane < G)
             for (int k = 1; k < ds.w; ++k) acc = f4_add(acc, part[w + k][lane]);
@@ -472,7 +510,9 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     const int W = sched_waves(a.n_blocks);
     if ((a.n_blocks & kSchedLongFlag) && !a.scratch) return hipErrorInvalidValue;  // long rows need their scratch block
     a.n_blocks &= ~(kSchedPackedFlag | kSchedWavesMask | kSchedLongFlag);
-    const dim3 grid(a.n_blocks), block(W * 64);
+    const bool vec = a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256;
+    if (!vec || !a.blk_count || !a.blk_list) a.blk_mode = 0;   // (the generic kernel walks the whole schedule)
+    const dim3 grid(a.blk_mode == 3 ? std::max(1, std::min(a.n_blocks, a.blk_cap)) : a.n_blocks), block(W * 64);
     static const int variant = RK_TUNE_INT("RK_SPMM_VARIANT", 0);
     static const int dbg = RK_TUNE_INT("RK_SPMM_DEBUG", 0);
     a.dbg = dbg;

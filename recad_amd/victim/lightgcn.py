@@ -158,6 +158,12 @@ class LightGCN(BaseVictim):
         # the row-gather kernel's schedule (host-built) only when this handle will launch it
         wave_desc, n_blocks = (None, 0) if lds else g.schedule(d)
         ws["spmm_scratch"] = None if lds else g.new_scratch(d)  # this handle's own long-row counters / partial slots
+        # the row-filtered last forward layer starts only the schedule's workgroups that hold a minibatch row (listed here by the
+        # launch before it): int32[4 + blocks]; the long-row pieces bound the list beyond 3 * batch (scratch words / dim >= pieces)
+        n_sched_blocks = (int(n_blocks) & 0x07ffffff) if not lds else 0   # (bits 27-30 of the opaque launch parameter are flags)
+        use_list = (not lds) and ws["row_bits"] is not None and self.n_layers >= 3 and getattr(self, "use_block_list", True)
+        ws["row_blocks"] = torch.zeros(4 + n_sched_blocks, device=dev, dtype=torch.int32) if use_list else None
+        row_blocks_extra = (ws["spmm_scratch"].numel() // max(d, 1) + 1) if (use_list and ws["spmm_scratch"] is not None) else 0
         ws["lsum"] = torch.zeros(N, d, device=dev, dtype=torch.float32) if lds else None
         ws["cnt"] = torch.zeros(N, device=dev, dtype=torch.int32) if lds else None   # per-node incidence counts of a minibatch
         fuse = bool(lds) and bool(self.fuse_layers) and self.n_layers >= 2   # (bench.py --fuse-layers for A/B runs)
@@ -177,7 +183,7 @@ class LightGCN(BaseVictim):
             gprop=_lib.ptr(ws["gprop"]), gego=_lib.ptr(ws["gego"]), grad=_lib.ptr(ws["grad"]),
             state=_lib.ptr(ws["state"]), coef=_lib.ptr(ws["coef"]),
             spmm_scratch=_lib.ptr(ws["spmm_scratch"]),
-            row_bits=_lib.ptr(ws["row_bits"]),
+            row_bits=_lib.ptr(ws["row_bits"]), row_blocks=_lib.ptr(ws["row_blocks"]), row_blocks_extra=int(row_blocks_extra),
             keep_prob=float(self.keep_prob) if self.graph_dropout else 0.0,
             drop_seed=self._drop_seed if self.graph_dropout else 0, tpos=_lib.ptr(ws["tpos"]),
             lds_plan=_lib.ptr(lds[0]) if lds else None, lds_info=lds[1] if lds else _lib.LdsInfo(),

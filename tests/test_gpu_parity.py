@@ -464,6 +464,39 @@ def test_workflow_end_to_end_on_device(gpu_device):
             assert abs(rows[:, 2 + i].mean() - res[f"HR@{k}"]) < 1e-12, (name, k)
 
 
+def test_lightgcn_marked_block_list_same_bits(gpu_device):
+    """Row-gather path, L >= 3: the row-filtered last forward layer starts only the schedule's workgroups that hold a minibatch
+    row (listed by the launch before it: desc.row_blocks, spmm.h SpmmArgs::blk_mode) instead of every workgroup.  Which
+    workgroups run does not change any sum: with the ordered scatter the trained tables and losses are BIT-identical to a
+    victim without the list -- across epochs, a ragged last batch, plain launches and hipGraph replays, L = 3 and 4."""
+    from recad_amd import model
+    g = G.load("lightgcn_game_d64_tg")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    rng = np.random.default_rng(17)
+    B, n = 512, 512 * 5 + 77
+    cols = [torch.from_numpy(rng.integers(0, hi, n)).to(gpu_device) for hi in (U, I, I)]
+    for layers in (3, 4):
+        for graph_steps in (0, 32):
+            outs = []
+            for use_list in (True, False):
+                ds = ReplayDataset(g, LGN_KEYS, device=gpu_device, steps=[0])
+                m = model.from_config("victim", "lightgcn", latent_dim_rec=int(g["dim"]), lightGCN_n_layers=layers, deterministic=True).I(dataset=ds)
+                u0, i0 = G.lightgcn_init(g)
+                m.embedding_user.weight.data.copy_(torch.from_numpy(u0))
+                m.embedding_item.weight.data.copy_(torch.from_numpy(i0))
+                m = m.to(gpu_device)
+                m.use_lds, m.use_block_list, m.graph_steps = False, use_list, graph_steps
+                l1 = m._run_epoch(*cols, B).sum(dim=1).double().cpu().numpy().copy()
+                l2 = m._run_epoch(*(c[: 3 * B] for c in cols), B).sum(dim=1).double().cpu().numpy().copy()
+                assert (m._ws.get("row_blocks") is not None) == use_list
+                if use_list:   # the list was used: the last step's count is the number of workgroups that held a marked row
+                    cnt = int(m._ws["row_blocks"][0].item())
+                    assert 0 < cnt <= 3 * B + 64, cnt
+                outs.append((l1, l2, m.embedding_user.weight.detach().cpu().numpy().copy(), m.embedding_item.weight.detach().cpu().numpy().copy()))
+            for a_, b_ in zip(*outs):
+                assert np.array_equal(a_, b_), (layers, graph_steps)
+
+
 def test_eval_session_matches_full_catalog_topk(gpu_device):
     """evaluate.EvalSession (buffers and plan made once; from its second run on ONE hipGraph replay of propagation + GEMM +
     selection + HR@k counts) against full_catalog_topk + hit_counts: identical bits on the first (eager), second (captured) and

@@ -291,7 +291,7 @@ def test_ctypes_descriptors_match_the_header(tmp_path):
         pytest.skip("gcc not available")
     probes = {
         "rk_lightgcn_desc": ["n_users", "lambda", "rowptr", "n_blocks", "user_emb", "grad", "state", "coef", "spmm_scratch",
-                             "row_bits", "keep_prob", "drop_seed", "tpos"],
+                             "row_bits", "keep_prob", "drop_seed", "tpos", "row_blocks", "row_blocks_extra", "lds_sync"],
         "rk_ncf_desc": ["n_users", "lr", "ug", "pw", "grad", "m", "v", "acts", "d0", "max_batch", "gemm_scratch",
                         "gemm_scratch_floats", "wgrad_part"],
         "rk_spmm_epilogue": [],
