@@ -623,7 +623,14 @@ __device__ __forceinline__ float wide_operand(const float *base, int i, int st)
     return MODE == 1 ? base[i * 16 * kWLd + st * 4] : base[st * 4 * kWLdT + i * 16];
 }
 
-template <int MA, int MB>
+#ifndef GEMM_STAMP   // (scripts/gemm_probe.hip -DGEMM_STAMPS: wall-clock stamps per workgroup and tile)
+#define GEMM_STAMP(it, i) do { } while (0)
+#endif
+// PLAIN: C = A.B^T with no bias / ReLU / sigmoid / mask (the LightGCN scoring GEMM) as a separate instantiation.  With the
+// epilogue options tested at run time, every one of a tile's 64 stored elements walked a chain of scalar branches: per-tile
+// stamps (scripts/gemm_probe.hip -DGEMM_STAMPS, profiles/r05_gemm_stamps.txt) showed 4.7 us of "stores" after every 8 us MFMA
+// phase at 5 893 x 3 702 x 64 -- instruction issue, not memory (half the workgroups storing at a time took just as long).
+template <int MA, int MB, bool PLAIN = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_f32_wide_kernel(const GemmArgs g, const int gx, const int gy)
 {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
@@ -674,6 +681,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
     };
+    GEMM_STAMP(0, 0);
     tile_origin<128>(t_begin, gx, gy, m0, n0);
     m1 = m0; n1 = n0;
     row_offsets(m0, n0);
@@ -686,12 +694,14 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     __syncthreads();
     const float *pa = MA == 1 ? sA + (wr * 64 + l16) * kWLd + lq : sA + lq * kWLdT + wr * 64 + l16;
     const float *pb = MB == 1 ? sB + (wc * 64 + l16) * kWLd + lq : sB + lq * kWLdT + wc * 64 + l16;
-    const bool plain = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask;
+    const bool plain = PLAIN || (!g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask);
     // ONE software pipeline over all (tile, k-chunk) pairs of the run: the next pair's global loads fly under this chunk's
     // MFMAs, and a finished tile's stores drain under the next tile's MFMAs.
     int c = 0;
+    GEMM_STAMP(0, 1);
     for (int it = 0; it < total; ++it) {
         const bool more = it + 1 < total, last = c == n_chunks - 1;
+        GEMM_STAMP(it, 2);
         if (more) {
             if (last) {
                 tile_origin<128>(t_begin + (it + 1) / n_chunks, gx, gy, m1, n1);
@@ -724,6 +734,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][j], av[cur][i], acc[i][j], 0, 0, 0);   // the block TRANSPOSED
         }
         __builtin_amdgcn_s_setprio(0);
+        GEMM_STAMP(it, 3);
         if (last) {
             // tile finished.  The MFMAs took (B, A), so a 16x16 accumulator block holds C^T: register r of lane (l16, lq) is
             // C[row l16][column 4*lq + r] -- four consecutive columns per lane, one 16-byte store (a quarter of the store
@@ -735,12 +746,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                     const int m = m0 + wr * 64 + i * 16 + l16;
                     if (G && m >= g.M) continue;
                     float *crow = g.C + (size_t)m * g.ldc;
-                    const float rbias = (!plain && g.row_bias) ? g.row_bias[g.a_ridx ? g.a_ridx[m] : m] : 0.f;
+                    const float rbias = (!PLAIN && !plain && g.row_bias) ? g.row_bias[g.a_ridx ? g.a_ridx[m] : m] : 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int n = n0 + wc * 64 + j * 16 + 4 * lq;
                         f32x4 v = acc[i][j];
-                        if (!plain) {
+                        if (!PLAIN && !plain) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 if (G && n + r >= g.N) continue;
@@ -753,7 +764,13 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                                 v[r] = s;
                             }
                         }
-                        if (!G || n + 4 <= g.N) *reinterpret_cast<f32x4_u *>(crow + n) = v;
+                        if (!G || n + 4 <= g.N) {
+                            // the score matrix is written once and read by the NEXT kernel: streaming (nt) stores measured +1-2 % at
+                            // the ml1m / d = 256 shapes, +7 % at 54 617 x 34 474 x 128 (profiles/r05_gemm_nt.txt); the tower GEMMs'
+                            // outputs are re-read from L2 by the next layer and keep the default policy
+                            if (PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_u *>(crow + n));
+                            else *reinterpret_cast<f32x4_u *>(crow + n) = v;
+                        }
                         else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -768,12 +785,15 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             if (more) init_acc(m0, n0);
             c = 0;
         } else ++c;
+        GEMM_STAMP(it, 4);
         __syncthreads();
+        GEMM_STAMP(it, 5);
         if (more) {
             wide_store<MA>(ta, sA);
             wide_store<MB>(tb, sB);
         }
         __syncthreads();
+        GEMM_STAMP(it, 6);
     }
 }
 
@@ -845,7 +865,9 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
         if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
             (!g.acc_init || g.a_rmod > 0) && !g.drop_thresh24) {
-            const void *fn[2] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>)};
+            const bool plain_w = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask;
+            const void *fn[3] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
+                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1, true>)};
             static RkPerDeviceOnce wide_attr;
             int wide_attr_dev;
             if (wide_attr.need(&wide_attr_dev)) {
@@ -858,7 +880,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
             int gx = (Ni + 127) / 128, gy = (g.M + 127) / 128;
             const size_t lds = (size_t)(wide_floats<1>() + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);
             void *params[3] = {const_cast<GemmArgs *>(&g), &gx, &gy};
-            hipError_t e = hipLaunchKernel(fn[fb == 2 ? 1 : 0], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
+            hipError_t e = hipLaunchKernel(fn[fb == 2 ? 1 : plain_w ? 2 : 0], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
             if (e != hipSuccess) return e;
             if (Ni < g.N) {   // right strip: all rows, columns [Ni, N)
                 GemmArgs e1 = g;

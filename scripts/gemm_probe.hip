@@ -4,6 +4,10 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#ifdef GEMM_STAMPS   // per-workgroup, per-tile wall-clock stamps of gemm_f32_wide_kernel (100 MHz): [wg][8 iterations][8 stamps]
+__device__ unsigned long long *g_gemm_stamps;
+#define GEMM_STAMP(it, i) do { if (g_gemm_stamps && threadIdx.x == 0 && (it) < 8) g_gemm_stamps[((size_t)blockIdx.x * 8 + (it)) * 8 + (i)] = wall_clock64(); } while (0)
+#endif
 #include "../recad_amd/csrc/gemm.h"
 int main(int argc, char **argv)
 {
@@ -37,5 +41,28 @@ int main(int argc, char **argv)
     std::vector<float> c(16); hipMemcpy(c.data(), C, 64, hipMemcpyDeviceToHost);
     printf("M %d N %d K %d pad %d %d split %d form %d: %.2f us  %.1f TF/s  (c0 %g, err %d)\n", M, N, K, pa, pb, split, form, ms * 1e3 / it,
            2.0 * M * N * K / (ms * 1e-3 / it) / 1e12, c[0], (int)hipGetLastError());
+#ifdef GEMM_STAMPS
+    {
+        const int nwg = 512;
+        unsigned long long *dst; hipMalloc(&dst, (size_t)nwg * 64 * 8); hipMemset(dst, 0, (size_t)nwg * 64 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &dst, sizeof(dst));
+        hipDeviceSynchronize();
+        gemm_f32_launch(g, 0); hipDeviceSynchronize();
+        std::vector<unsigned long long> st((size_t)nwg * 64);
+        hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ULL, t1 = 0;
+        for (int w = 0; w < nwg; ++w) { if (st[(size_t)w * 64]) t0 = std::min(t0, st[(size_t)w * 64]); for (int k = 0; k < 64; ++k) t1 = std::max(t1, st[(size_t)w * 64 + k]); }
+        printf("stamps (us from the first workgroup's start; mean over workgroups that ran the tile):\n  kernel span %.2f us\n", (t1 - t0) / 100.0);
+        double s0 = 0, s1 = 0; int n0 = 0;
+        for (int w = 0; w < nwg; ++w) { const unsigned long long *p = &st[(size_t)w * 64]; if (!p[0]) continue; s0 += (p[0] - t0) / 100.0; s1 += (p[1] - p[0]) / 100.0; ++n0; }
+        printf("  workgroup start %.2f, prologue (index gather, first tile's loads, LDS image, barrier) %.2f\n", s0 / n0, s1 / n0);
+        for (int itn = 0; itn < 4; ++itn) {
+            double a[7] = {0}; int n = 0; double beg = 0;
+            for (int w = 0; w < nwg; ++w) { const unsigned long long *p = &st[((size_t)w * 8 + itn) * 8]; if (!p[6] || !p[2]) continue; ++n; beg += (p[2] - t0) / 100.0;
+                a[3] += (p[3] - p[2]) / 100.0; a[4] += (p[4] - p[3]) / 100.0; a[5] += (p[5] - p[4]) / 100.0; a[6] += (p[6] - p[5]) / 100.0; }
+            if (n) printf("  tile %d (%d workgroups): begins %.2f | prefetch + MFMA phase %.2f | epilogue stores %.2f | barrier %.2f | LDS image + barrier %.2f\n", itn, n, beg / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n);
+        }
+    }
+#endif
     return 0;
 }

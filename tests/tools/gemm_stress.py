@@ -26,13 +26,13 @@ def _run(seed, n_cases):
         sp = np.zeros(nu + 1, dtype=np.int32); si = np.zeros(1, dtype=np.int32)
         top_ids = torch.empty(nb, K, dtype=torch.int32, device=dev); top_sc = torch.empty(nb, K, device=dev)
         ts_ = torch.empty(nb, 1, device=dev); tr = torch.empty(nb, 1, dtype=torch.int32, device=dev)
-        scratch = torch.empty(nb * I, device=dev)
         plan = score_plan(nb, I, d, K, 1, {"path": "gemm"})
+        scratch = torch.empty(int(plan.scratch_floats), device=dev)   # [nb, plan.ld_scores]: rows padded to 128-byte lines
         tu, ti, tub, tib, tid, tsp, tsi, tg = t(utab, torch.float32), t(itab, torch.float32), t(ub, torch.float32), t(ib, torch.float32), t(ids, torch.int32), t(sp, torch.int32), t(si, torch.int32), t(np.zeros(1, dtype=np.int32), torch.int32)
         _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(tu), nb, _lib.ptr(tid), _lib.ptr(ti), I, _lib.ptr(tub), _lib.ptr(tib), 0.5 if bias else 0.0,
                                             _lib.ptr(tsp), _lib.ptr(tsi), K, _lib.ptr(top_ids), _lib.ptr(top_sc), _lib.ptr(tg), 1, _lib.ptr(ts_), _lib.ptr(tr),
                                             C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
-        got = scratch.view(nb, I).cpu().numpy()
+        got = scratch.view(nb, int(plan.ld_scores))[:, :I].cpu().numpy()
         ref = orc.score_rows(utab[ids], itab, ub[ids] if bias else None, ib, 0.5 if bias else 0.0)
         if not np.array_equal(got, ref):
             bad = np.argwhere(got != ref)
