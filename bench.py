@@ -830,12 +830,21 @@ def worker(args, traffic_live=None):
         wp = run_steps(victim, (users, pos, neg), B, 0, args.warmup)
         if want_parity:
             warm_losses = wp.sum(dim=1).double()   # device-side copy now (the loss buffer is reused by the timed call), read back after the timing
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev_a.record(stream)          # (two event records inside the timed region, ~2 us each: the GPU-side span of the call)
     partials = run_steps(victim, (users, pos, neg), B, args.warmup, args.steps)
+    t_enq = time.perf_counter()
+    ev_b.record(stream)
     wait_done(stream)
+    t_seen = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_region = {"host_total_us": elapsed * 1e6, "enqueue_returns_after_us": (t_enq - t0) * 1e6, "completion_seen_after_us": (t_seen - t0) * 1e6,
+                    "closing_barrier_us": (elapsed - (t_seen - t0)) * 1e6, "gpu_span_us": ev_a.elapsed_time(ev_b) * 1e3,
+                    "note": "the K timed steps are ONE call (one whole-call hipGraph replay for K <= 64): gpu_span = first to last kernel by HIP events on the "
+                            "launch stream; host_total - gpu_span = launch latency + completion detection + the contract's barrier / synchronize pair"}
     if args.fuse_layers:
         victim.check_handoffs()
     run_losses = run_tables = None
@@ -979,7 +988,7 @@ def worker(args, traffic_live=None):
                        "parallelism": par, "mode": "replicas" if world > 1 else "single",
                        "backend": args.backend if collectives else None,
                        "graph_steps": args.graph_steps, "scatter": "ordered" if args.deterministic else "float atomics"},
-            "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
+            "timed_region": timed_region, "epoch_with_sampler": epoch_obj, "topk": topk, "roofline": roofline, "cpu_baseline": cpu_aten,
             "cpu_baseline_port": cpu, "parity": parity, "also": also, "mfma_gemm": mfma, "ranks_seen": seen, "last_step_loss": last_loss,
         }
 
