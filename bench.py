@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--spmm", default="auto", choices=["auto", "lds", "csr"],
                     help="LightGCN propagation kernel: auto (the library's choice), lds (LDS-resident sliced SpMM where the graph qualifies), "
                          "csr (row gather) -- A/B of the two forms on one graph")
+    ap.add_argument("--no-block-list", action="store_true", help="row-gather path: start every workgroup in the row-filtered last forward layer (A/B of the marked-block list)")
     ap.add_argument("--fuse-layers", action="store_true", help="LDS path: the L layers of a pass as one multi-phase launch (opt-in form, measured slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle replay of the timed path (parity object, cpu_baseline_port)")
@@ -803,6 +804,7 @@ def worker(args, traffic_live=None):
     victim.graph_steps = args.graph_steps
     victim.use_lds = {"auto": "auto", "lds": True, "csr": False}[args.spmm]
     victim.fuse_layers = bool(args.fuse_layers)
+    victim.use_block_list = not args.no_block_list
     g = ds.graph_csr()
     N, nnz = g.n_rows, g.nnz
     users, pos, neg = resident_triplets(ds, (args.steps + args.warmup) * B)

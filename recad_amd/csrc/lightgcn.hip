@@ -697,9 +697,14 @@ static int launch_forward(const rk_lightgcn_desc &d, hipStream_t s, const BatchR
             if (l == L) a.row_filter = d.row_bits;
             // L >= 3: the launch between marking and filtering lists the workgroups that hold a marked row, and the filtered
             // launch starts only those (spmm.h, SpmmArgs::blk_mode)
-            if (d.row_blocks && L >= 3 && batch->batch > 0) {
+            // -- where that at least halves the filtered launch: on a small schedule (ml1m: 2 413 workgroups against 3 072 minibatch
+            // rows) nearly every workgroup holds a marked row, and the list's two dependent loads in front of the descriptor plus
+            // the appends cost the step 17-24 % (profiles/r05_bench_asis.json before / after)
+            const long long cap = 3LL * batch->batch + (long long)std::max(d.row_blocks_extra, 0);
+            const long long n_plain = (long long)(d.n_blocks & ~(kSchedPackedFlag | kSchedWavesMask | kSchedLongFlag));
+            if (d.row_blocks && L >= 3 && batch->batch > 0 && 2 * cap <= n_plain) {
                 a.blk_count = d.row_blocks; a.blk_list = d.row_blocks + 4; a.blk_bits = d.row_bits;
-                a.blk_cap = (int)std::min<long long>(0x7fffffff, 3LL * batch->batch + (long long)std::max(d.row_blocks_extra, 0));
+                a.blk_cap = (int)std::min<long long>(0x7fffffff, cap);
                 a.blk_mode = l == 1 ? 1 : l == L - 1 ? 2 : l == L ? 3 : 0;
             }
         }
