@@ -89,12 +89,23 @@ struct LdsArgs {
     LdsEpi e;
 };
 
-__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float4 f4_plus(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+typedef float lds_f4n __attribute__((ext_vector_type(4)));
+// (through the ext-vector type: two v_pk_add_f32 / v_pk_mul_f32 instead of four scalar operations, the same value per component)
+__device__ __forceinline__ float4 f4_scale(float4 a, float s)
+{
+    const lds_f4n x = {a.x, a.y, a.z, a.w};
+    const lds_f4n r = x * s;
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ float4 f4_plus(float4 a, float4 b)
+{
+    const lds_f4n x = {a.x, a.y, a.z, a.w}, y = {b.x, b.y, b.z, b.w};
+    const lds_f4n r = x + y;
+    return make_float4(r.x, r.y, r.z, r.w);
+}
 
 // LDS (address space 3) pointer to a float4: lets an absolute LDS byte address be dereferenced without a base add
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // (host pass only: LDS pointers are 32-bit on the device)
-typedef float lds_f4n __attribute__((ext_vector_type(4)));
 typedef const lds_f4n __attribute__((address_space(3))) *lds_f4_ptr;
 
 // ---- in-launch hand-off traffic (multi-phase launch): every byte a later phase reads was stored write-through (sc1) and
@@ -251,18 +262,19 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         }
         return (lds_f4_ptr)(tab + (w >> 16) * LP + pj);
     };
-    auto read8 = [&](float4 (&xv)[8], uint4 c) {
+    // (the sums stay ext-vector typed from the LDS read to the partial's store: the adds are v_pk_add_f32, two per table row
+    // instead of four v_add_f32 -- the gather phase is bound by VALU issue, not by the LDS array; same order per component)
+    auto read8 = [&](lds_f4n (&xv)[8], uint4 c) {
         const unsigned wv[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const lds_f4n lo = *row_lo(wv[k]), hi = *row_hi(wv[k]);
-            xv[2 * k] = make_float4(lo.x, lo.y, lo.z, lo.w);
-            xv[2 * k + 1] = make_float4(hi.x, hi.y, hi.z, hi.w);
+            xv[2 * k] = *row_lo(wv[k]);
+            xv[2 * k + 1] = *row_hi(wv[k]);
         }
     };
-    auto add8 = [&](float4 acc, const float4 (&xv)[8]) {
+    auto add8 = [&](lds_f4n acc, const lds_f4n (&xv)[8]) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = f4_plus(acc, xv[k]);
+        for (int k = 0; k < 8; ++k) acc = acc + xv[k];
         return acc;
     };
     int t = pop();
@@ -293,13 +305,13 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         // Two 8-entry blocks per round: all sixteen table reads are issued before the first add, so a wave keeps the LDS
         // pipe fed while it adds (with one block per round LDS-array and VALU time of the sixteen waves added up: the
         // array was busy 55 % of the gather phase).  The stream words of the next round are already in flight.
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds_f4n acc = {0.f, 0.f, 0.f, 0.f};
         int b = 0;
         for (; b + 2 <= tk.y; b += 2) {
             uint4 d0 = c0, d1 = c1;
             if (b + 2 < tk.y) d0 = st[(size_t)(b + 2) * SL];
             if (b + 3 < tk.y) d1 = st[(size_t)(b + 3) * SL];
-            float4 xa[8], xb[8];
+            lds_f4n xa[8], xb[8];
             read8(xa, c0);
             read8(xb, c1);
             acc = add8(acc, xa);
@@ -307,11 +319,11 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
             c0 = d0; c1 = d1;
         }
         if (b < tk.y) {
-            float4 xa[8];
+            lds_f4n xa[8];
             read8(xa, c0);
             acc = add8(acc, xa);
         }
-        if (my_dst >= 0) part[my_dst * LP + pj] = acc;
+        if (my_dst >= 0) part[my_dst * LP + pj] = make_float4(acc.x, acc.y, acc.z, acc.w);
         t = tn; tk = tkn; st = stn; my_dst = dstn; c0 = n0; c1 = n1;
     }
     lds_barrier();
