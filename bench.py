@@ -209,7 +209,7 @@ def relerr_max(a, b):
 
 def run_steps(victim, triplets, B, lo, n_steps):
     """Steps [lo, lo + n_steps) of the resident triplets through the victim's epoch call -- the timed call of this bench
-    (after victim.reserve(): one whole-call hipGraph replay for <= 64 steps, chunk graphs beyond)."""
+    (after victim.reserve(): the whole call replayed from captured hipGraphs for <= 64 steps -- a 3-step head graph, then the rest --, chunk graphs beyond)."""
     users, pos, neg = triplets
     sl = slice(lo * B, (lo + n_steps) * B)
     return victim._run_epoch(users[sl], pos[sl], neg[sl], B)
@@ -485,7 +485,8 @@ def spmm_roofline(args, victim, N, nnz, traffic_live=None):
             for _ in range(reps):
                 spmm_once()
         ev1.record(stream)
-        torch.cuda.synchronize()
+        wait_done(stream)   # (spinning, not the blocking wait: this probe ends at the timed region's opening barrier, and a host core that slept
+        #                      through seven 2 ms waits runs the timed call's Python ~4x slower -- 25 us per stage instead of 6)
         windows.append(ev0.elapsed_time(ev1) / (reps * per_call))
     spmm_ms = sorted(windows)[len(windows) // 2]
     spmm_bytes = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * args.dim  # A once, X once, Y once
@@ -770,7 +771,7 @@ def worker(args, traffic_live=None):
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import recad_amd  # noqa: F401
-    from recad_amd import model
+    from recad_amd import _lib, model
     from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 
     B = args.batch
@@ -821,12 +822,19 @@ def worker(args, traffic_live=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- dominant kernel first: the SpMM's per-launch time by HIP events on its stream.  It runs BEFORE the timed
-    # region on purpose: ~15 ms of the step's own dominant kernel bring the device to its working clocks, so the K timed steps
-    # are measured at the rate an epoch runs at (the driver's 20-step call used to run its kernels ~8 % slower than a
-    # 458-step epoch: profiles/r04_call_trace.txt).  It touches workspace buffers only, never the tables.
+    # ---------------- what runs in front of the timed region, and why in this order (profiles/r05e_call_clock.txt, r05g_host_path.txt):
+    # (1) the dominant-kernel probe: the SpMM's per-launch time by HIP events on its stream, ~13 ms of the step's own kernel
+    #     (workspace buffers only, never the tables) -- it also brings the device to its working clocks: the same 20-step call
+    #     takes 1 417 us of device time after 50 ms of idle, 1 350 us 5 ms after a busy period, 1 305-1 330 us right behind one;
+    # (2) the W warm-up steps, through the same call as the timed ones: five steps (0.3 ms) do not move the device's clocks,
+    #     but they leave the HOST path hot -- the first pass through that Python after 100 ms of other code ran every stage
+    #     ~4x slower (25 us instead of 6 for the handle check alone: 150 us of a 1.4 ms region with the device waiting);
+    # (3) nothing else: the reduction that copies the warm-up's losses is run once on a dummy BEFORE (1), so its code object
+    #     is loaded by then (loading it between warm-up and timed call left the device idle for milliseconds).
+    if want_parity and args.warmup > 0:
+        torch.zeros(args.warmup, _lib.RK_LOSS_PARTIALS, device=dev).sum(dim=1).double()
+        torch.cuda.synchronize()
     roofline = spmm_roofline(args, victim, N, nnz, traffic_live)
-
     warm_losses = None
     if args.warmup > 0:
         wp = run_steps(victim, (users, pos, neg), B, 0, args.warmup)
@@ -843,10 +851,16 @@ def worker(args, traffic_live=None):
     t_seen = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
-    timed_region = {"host_total_us": elapsed * 1e6, "enqueue_returns_after_us": (t_enq - t0) * 1e6, "completion_seen_after_us": (t_seen - t0) * 1e6,
+    tc = getattr(victim, "last_call_seconds", (t0,) * 4)
+    timed_region = {"host_total_us": elapsed * 1e6,
+                    "host_path_us": {"event_record_and_slices": (tc[0] - t0) * 1e6, "handle_check": (tc[1] - tc[0]) * 1e6, "argument_marshalling": (tc[2] - tc[1]) * 1e6,
+                                     "c_call": (tc[3] - tc[2]) * 1e6, "behind_the_c_call": (t_enq - tc[3]) * 1e6},
+                    "enqueue_returns_after_us": (t_enq - t0) * 1e6, "completion_seen_after_us": (t_seen - t0) * 1e6,
                     "closing_barrier_us": (elapsed - (t_seen - t0)) * 1e6, "gpu_span_us": ev_a.elapsed_time(ev_b) * 1e3,
-                    "note": "the K timed steps are ONE call (one whole-call hipGraph replay for K <= 64): gpu_span = first to last kernel by HIP events on the "
-                            "launch stream; host_total - gpu_span = launch latency + completion detection + the contract's barrier / synchronize pair"}
+                    "note": "the K timed steps are ONE call (K <= 64: replayed from captured hipGraphs, a 3-step head so that the device starts early, then the rest): gpu_span = first to last kernel by HIP events on the "
+                            "launch stream; host_total - gpu_span = launch latency + completion detection + the contract's barrier / synchronize pair",
+                    "in_front": "the roofline probe (~13 ms of the dominant kernel, workspace buffers only), then the W warm-up steps, then the opening barrier: "
+                                "the device is at its working clocks (the same call is 5-8 % slower behind an idle period, profiles/r05e_call_clock.txt) and the host path is hot"}
     if args.fuse_layers:
         victim.check_handoffs()
     run_losses = run_tables = None

@@ -4,6 +4,7 @@ forward/backward/Adam run in librecad_hip.so (recad_amd/csrc/lightgcn.hip); this
 orchestration only: parameter ownership (nn.Embedding, so .to()/state_dict() behave as in
 the reference), the optimizer object, and the C-ABI handle.
 """
+import time
 import ctypes as C
 
 import torch
@@ -278,17 +279,23 @@ class LightGCN(BaseVictim):
                        "rk_lightgcn_prepare")
 
     def _run_epoch(self, users, pos, neg, batch, apply_update=True, want_grad=False):
+        ta = time.perf_counter()
         h = self._ensure_handle(want_grad=want_grad)
+        tb = time.perf_counter()
         n = users.numel()
         n_steps = (n + batch - 1) // batch
         users, pos, neg = (t.contiguous() for t in (users, pos, neg))
         loss_partials = self._loss_buffer(n, batch, users.device)
         su = self._adam_state(self.embedding_user.weight)
         t0 = int(su["step"].item()) if apply_update else 0
-        _lib.check(_lib.lib().rk_lightgcn_train_epoch(
-            h, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch, t0, _lib.ptr(loss_partials),
-            1 if apply_update else 0, int(self.graph_steps) if apply_update else 0, _lib.stream_ptr()),
-            "rk_lightgcn_train_epoch")
+        args = (h, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch, t0, _lib.ptr(loss_partials),
+                1 if apply_update else 0, int(self.graph_steps) if apply_update else 0, _lib.stream_ptr())
+        fn = _lib.lib().rk_lightgcn_train_epoch
+        tc = time.perf_counter()
+        rc = fn(*args)
+        # host-side stamps of this call: entered, handle checked, C call entered / left (bench.py itemises its timed call with them)
+        self.last_call_seconds = (ta, tb, tc, time.perf_counter())
+        _lib.check(rc, "rk_lightgcn_train_epoch")
         self._ws["epoch_inputs"] = (users, pos, neg)   # alive until the next call: the stream may still be reading them
         if apply_update:
             for p in (self.embedding_user.weight, self.embedding_item.weight):

@@ -33,8 +33,15 @@ else:
         bench.run_steps(v, trip, B, 0, steps)
 torch.cuda.synchronize()
 rows = []
+prewarm_ms = float(os.environ.get("PROBE_PREWARM_MS", "0"))   # device kept busy (5-step calls back to back) right up to each timed call
+idle_ms = float(os.environ.get("PROBE_IDLE_MS", "0"))         # host sleep in front of each timed call (device idle)
 for rep in range(12):
+    if prewarm_ms > 0:
+        for _ in range(int(prewarm_ms * 1000 / (5 * 66)) + 1):
+            bench.run_steps(v, trip, B, 0, 5)
     torch.cuda.synchronize()
+    if idle_ms > 0:
+        time.sleep(idle_ms / 1e3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
@@ -47,7 +54,7 @@ for rep in range(12):
     rows.append(((t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (t3 - t0) * 1e6, e0.elapsed_time(e1) * 1e3))
 print("C call rk_lightgcn_train_epoch (us) per call:", " ".join("%.0f" % x for x in c_us[-14:]))
 if first:
-    for i, r in enumerate(rows[:4]):
+    for i, r in enumerate(rows[:12]):
         print("call %d after reserve: _run_epoch returns after %.1f us | total %.1f us = %.2f us/step | GPU span %.1f us" % (i, r[1], r[3], r[3] / steps, r[4]))
 a = np.median(np.array(rows[2:]), axis=0)
 print("steps %d: event record %.1f us | _run_epoch returns after %.1f us | completion seen %.1f us later | total %.1f us = %.2f us/step | GPU span by events %.1f us" % (steps, *a[:4], a[3] / steps, a[4]))
