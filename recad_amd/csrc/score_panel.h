@@ -34,6 +34,7 @@
 #include "common.h"
 
 typedef float sel_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sel_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned score_key(float s)
 {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
     extern __shared__ __attribute__((aligned(16))) unsigned char pan_smem[];
     unsigned long long *sList = reinterpret_cast<unsigned long long *>(pan_smem);                 // [R][kPanCap]
     unsigned *sMax = reinterpret_cast<unsigned *>(pan_smem);                                      // [R][256], first panel only (lists still empty)
-    float *sA = reinterpret_cast<float *>(pan_smem + (size_t)R * kPanCap * 8);                     // [DC][4][R] float4: the user rows, k-permuted
+    float *sA = reinterpret_cast<float *>(pan_smem + (size_t)R * kPanCap * 8);                     // the user rows, k-permuted, as float2 halves (a_pos below)
     unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)R * kPanCap * 8 + (size_t)DC * 1024 * RB);   // [2][R][BWP]
     __shared__ int sCnt[kPanMaxRows], sCnt0[kPanMaxRows], sUid[kPanMaxRows], sCur[kPanMaxRows], sEnd[kPanMaxRows], sRank[kPanMaxRows][kPanMaxT],
         sFlag[2], sStrict[kPanMaxRows], sTot[kPanMaxRows], sCLo[kPanMaxRows], sAct[2], sFail;
@@ -307,10 +308,22 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
         }
         return v;
     };
-    for (int i = tid; i < DC * 4 * R; i += kPanNT)
-        *reinterpret_cast<sel_f32x4 *>(sA + (size_t)i * 4) = load_a(sUid[i % R], i / (4 * R), (i / R) & 3);
+    // LDS layout of the user operand: float2 HALVES {x, y} / {z, w} of the float4 of (c, g, row) at [(c * 2 + h) * 4 + g][row'],
+    // row' = row ^ 16 for odd g at 32 rows -- an 8-byte read of 32 lanes (16 rows x two g) then covers all 64 banks.  The sweep
+    // reads the halves one MFMA pair ahead (below); the float4 readers (target tile, safe form) put them together.
+    auto a_pos = [&](int c, int h, int gg, int row) -> int { return (((c * 2 + h) * 4 + gg) * R + (row ^ ((R == 32 && (gg & 1)) ? 16 : 0))) * 2; };
+    for (int i = tid; i < DC * 4 * R; i += kPanNT) {
+        const int row = i % R, gg = (i / R) & 3, c = i / (4 * R);
+        const sel_f32x4 v = load_a(sUid[row], c, gg);
+        *reinterpret_cast<sel_f32x2 *>(sA + a_pos(c, 0, gg, row)) = sel_f32x2{v.x, v.y};
+        *reinterpret_cast<sel_f32x2 *>(sA + a_pos(c, 1, gg, row)) = sel_f32x2{v.z, v.w};
+    }
     __syncthreads();
-    auto a_op = [&](int c, int rb) -> sel_f32x4 { return *reinterpret_cast<const sel_f32x4 *>(sA + (size_t)((c * 4 + g) * R + rb * 16 + u) * 4); };
+    auto a_half = [&](int c, int rb, int h) -> sel_f32x2 { return *reinterpret_cast<const sel_f32x2 *>(sA + a_pos(c, h, g, rb * 16 + u)); };
+    auto a_op = [&](int c, int rb) -> sel_f32x4 {
+        const sel_f32x2 lo = a_half(c, rb, 0), hi = a_half(c, rb, 1);
+        return sel_f32x4{lo.x, lo.y, hi.x, hi.y};
+    };
     // target scores before masking (normal.py:83-85): one extra MFMA tile whose "items" are the targets -- the same k-ordered
     // chain as every other score; every wave computes it (no LDS hand-off), lanes 0..15 of wave 0 write it out
     float ts[RB][NTG], ub[RB];
@@ -384,17 +397,33 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
             sel_f32x4 bq[PF];
 #pragma unroll
             for (int n = 0; n < PF; ++n) bq[n] = *b_ptr(n < NIT ? n : NIT - 1);
+            // The user operand comes from LDS one MFMA PAIR ahead: the {z, w} halves of chunk n are requested in front of its
+            // {x, y} MFMAs and the {x, y} halves of chunk n + 1 in front of its {z, w} MFMAs, into the registers the pair before
+            // has just released -- 64 cycles of MFMAs per row block cover each read.  (Read as one float4 right in front of its
+            // four MFMAs, every chunk waited out an LDS round trip: one s_waitcnt per four MFMAs, the pipe 0.69 busy.)
+            sel_f32x2 axy[RB], azw[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) axy[rb] = a_half(0, rb, 0);
 #pragma unroll
             for (int n = 0; n < NIT; ++n) {
                 const int i = n / DC, c = n % DC;
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const sel_f32x4 av = a_op(c, rb);
-                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].x, av.x, acc[rb][i], 0, 0, 0);
-                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].y, av.y, acc[rb][i], 0, 0, 0);
-                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].z, av.z, acc[rb][i], 0, 0, 0);
-                    acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].w, av.w, acc[rb][i], 0, 0, 0);
+                for (int rb = 0; rb < RB; ++rb) azw[rb] = a_half(c, rb, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].x, axy[rb].x, acc[rb][i], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].y, axy[rb].y, acc[rb][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + 1 < NIT) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) axy[rb] = a_half((n + 1) % DC, rb, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].z, azw[rb].x, acc[rb][i], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[n % PF].w, azw[rb].y, acc[rb][i], 0, 0, 0);
                 // the slot just consumed takes the operands of PF chunks ahead; the fences keep the compiler from sinking the
                 // load down to its use (it does, to save registers, and then every chunk waits for its own load)
                 __builtin_amdgcn_sched_barrier(0);

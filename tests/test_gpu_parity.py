@@ -1373,6 +1373,42 @@ def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source, lds):
     assert np.allclose(out, ref, rtol=2e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("lds", [False, True])
+@pytest.mark.parametrize("n_steps", [8, 9, 11, 21, 25, 64])
+def test_lightgcn_whole_call_chain_same_bits(gpu_device, n_steps, lds):
+    """An epoch call of <= RK_MAX_GRAPH_STEPS steps is replayed as a CHAIN of graphs from nine steps on (csrc/lightgcn.hip
+    cut_whole_call: 3-step head, pieces growing 6x, the call's prologue in the first graph and its epilogue in the last).  With
+    the ordered scatter the step has no float atomics, so the chain, and a second call replaying the cached pieces, must end in
+    exactly the tables and losses of plain kernel-by-kernel launches (ragged last step included)."""
+    from recad_amd import dataset, model, synth
+    dd = synth.make("tiny")
+    B = 128
+
+    def run(graph_steps):
+        ds = dataset.from_config("implicit", "tiny", train_csr=dd["train"], valid_csr=dd["valid"], test_csr=dd["test"],
+                                 device=gpu_device, seed=5, pairwise_batch_size=B)
+        torch.manual_seed(77)
+        m = model.from_config("victim", "lightgcn", latent_dim_rec=64, lightGCN_n_layers=2, deterministic=True).I(dataset=ds).to(gpu_device)
+        m.graph_steps, m.use_lds = graph_steps, lds
+        e = ds.generate_epoch()
+        users, pos, neg = (e[k] for k in LGN_KEYS)
+        reps = -(-(n_steps * B) // users.numel())
+        users, pos, neg = (t.repeat(reps)[: n_steps * B - 19].contiguous() for t in (users, pos, neg))
+        out = []
+        for _ in range(2):   # the second call replays the cached pieces
+            out.append(m._run_epoch(users, pos, neg, B).sum(1).cpu().numpy().copy())
+        return m, out
+
+    m_plain, l_plain = run(0)
+    m_chain, l_chain = run(64)
+    for a, b in zip(l_plain, l_chain):
+        assert a.shape == (n_steps,) and np.array_equal(a, b)
+    assert torch.equal(m_plain.embedding_user.weight, m_chain.embedding_user.weight)
+    assert torch.equal(m_plain.embedding_item.weight, m_chain.embedding_item.weight)
+    st_p, st_c = (m_.optimizer.state[m_.embedding_user.weight] for m_ in (m_plain, m_chain))
+    assert int(st_p["step"]) == int(st_c["step"]) == 2 * n_steps and torch.equal(st_p["exp_avg_sq"], st_c["exp_avg_sq"])
+
+
 @pytest.mark.parametrize("d,L,graph_steps,lds", [(64, 3, 8, False), (32, 1, 0, False), (256, 2, 8, False), (100, 2, 8, False), (50, 2, 4, False),
                                                  (64, 3, 8, True), (32, 1, 0, True), (128, 2, 8, True)])
 def test_lightgcn_deterministic_scatter(gpu_device, d, L, graph_steps, lds):
