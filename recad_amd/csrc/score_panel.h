@@ -29,6 +29,7 @@
 #include <float.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -235,15 +236,17 @@ __device__ __noinline__ int pan_prune(unsigned long long *row, int n, int K, int
 template <int NTW>
 struct PanGeom {
     static constexpr int PI = 128 * NTW;                                  // items per panel
-    static constexpr int BW = 4 * NTW;                                    // bitmap words per row
-    static constexpr int BWP = (BW % 8 == 4) ? BW : BW + 4;               // row stride: 16 rows land on 16 distinct banks (stride = 4 mod 8)
+    // The seen bitmap of a panel is kept TRANSPOSED: the 4 * NTW bits a lane tests (its four columns of each of its wave's tiles)
+    // are the two dwords [row][wave slot wq][g]: bit 4 * i + r of the pair = column 16 * (wq + 8 i) + 4 g + r.  One 8-byte read per
+    // row block and panel, immediate bit offsets per tile (a dword per tile read where it was used cost every tile an LDS round trip).
+    static constexpr int RS = 68;                                         // row stride in dwords (64 + 4: the 16 rows x two g of a half-wave read 64 distinct banks)
     static constexpr int TPG = (NTW + 7) / 8;                             // tiles per maxima group (8 groups per lane)
 };
 
 template <int NTW, int DC, int RB>
 inline size_t pan_lds_bytes()
 {
-    return (size_t)(16 * RB) * kPanCap * 8 + (size_t)DC * 1024 * RB + 2 * (size_t)(16 * RB) * PanGeom<NTW>::BWP * 4;
+    return (size_t)(16 * RB) * kPanCap * 8 + (size_t)DC * 1024 * RB + 2 * (size_t)(16 * RB) * PanGeom<NTW>::RS * 4;
 }
 
 // RB: blocks of 16 user rows per workgroup.  RB == 1: 128 registers per wave, two workgroups per CU (small user blocks: more
@@ -254,12 +257,12 @@ template <int NTW, int DC, int NTG, int RB>
 __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(const PanArgs a)
 {
     using G = PanGeom<NTW>;
-    constexpr int PI = G::PI, BWP = G::BWP, TPG = G::TPG, NIT = NTW * DC, PF = RB == 1 ? 3 : 4, R = 16 * RB;
+    constexpr int PI = G::PI, RS = G::RS, TPG = G::TPG, NIT = NTW * DC, PF = RB == 1 ? 3 : 4, R = 16 * RB;
     extern __shared__ __attribute__((aligned(16))) unsigned char pan_smem[];
     unsigned long long *sList = reinterpret_cast<unsigned long long *>(pan_smem);                 // [R][kPanCap]
     unsigned *sMax = reinterpret_cast<unsigned *>(pan_smem);                                      // [R][256], first panel only (lists still empty)
     float *sA = reinterpret_cast<float *>(pan_smem + (size_t)R * kPanCap * 8);                     // the user rows, k-permuted, as float2 halves (a_pos below)
-    unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)R * kPanCap * 8 + (size_t)DC * 1024 * RB);   // [2][R][BWP]
+    unsigned *sBits = reinterpret_cast<unsigned *>(pan_smem + (size_t)R * kPanCap * 8 + (size_t)DC * 1024 * RB);   // [2][R][RS]
     __shared__ int sCnt[kPanMaxRows], sCnt0[kPanMaxRows], sUid[kPanMaxRows], sCur[kPanMaxRows], sEnd[kPanMaxRows], sRank[kPanMaxRows][kPanMaxT],
         sFlag[2], sStrict[kPanMaxRows], sTot[kPanMaxRows], sCLo[kPanMaxRows], sAct[2], sFail;
     __shared__ unsigned sLo[kPanMaxRows], sHi[kPanMaxRows];
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
         for (int t = 0; t < kPanMaxT; ++t) sRank[tid][t] = 0;
     }
     if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
-    for (int i = tid; i < 2 * R * BWP; i += kPanNT) sBits[i] = 0u;
+    for (int i = tid; i < 2 * R * RS; i += kPanNT) sBits[i] = 0u;
     __syncthreads();
     // the user rows, k-permuted, into LDS: A[row][16c + 4s + g], s = 0..3, as the float4 of (c, g, row)
     const bool full_k = a.d == 16 * DC;   // no k padding: unguarded loads
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
         //  hoisted out of the panel loop -- 15 tiles' worth of invariants do not fit the register budget)
         w = w0; u = u0; g = g0;
         asm volatile("" : "+s"(w), "+v"(u), "+v"(g));
-        unsigned *bits = sBits + (p & 1) * (R * BWP), *bits_next = sBits + ((p + 1) & 1) * (R * BWP);
+        unsigned *bits = sBits + (p & 1) * (R * RS), *bits_next = sBits + ((p + 1) & 1) * (R * RS);
         // seen ids of this panel: first loads issued before the MFMAs, consumed after them (32 lanes per row, 16 rows per round)
         const int sj = tid & 31;
         int seen_cur[RB], seen_id[RB];
@@ -444,7 +447,10 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
                 int cur = seen_cur[rb], id = seen_id[rb];
                 for (;;) {
                     const bool in = id < pbase + PI;
-                    if (in) atomicOr(&bits[sr * BWP + ((id - pbase) >> 5)], 1u << ((id - pbase) & 31));
+                    if (in) {
+                        const int col = id - pbase, tile = col >> 4, bit = ((tile >> 3) << 2) | (col & 3);
+                        atomicOr(&bits[sr * RS + ((((tile & 7) << 2) | ((col >> 2) & 3)) << 1) + (bit >> 5)], 1u << (bit & 31));
+                    }
                     const int c32 = __popc((unsigned)(__ballot(in) >> sub));
                     cur += c32;
                     if (c32 < 32) break;
@@ -453,20 +459,25 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
                 if (sj == 0) sCur[sr] = cur;
             }
             if (pbase + PI > a.n_items || row0 + R > a.nb) {   // (workgroup-uniform)
-                for (int i = tid; i < R * G::BW; i += kPanNT) {
-                    const int r = i / G::BW, wd = i % G::BW;
-                    const int lo = pbase + wd * 32;
+                for (int i = tid; i < R * 64; i += kPanNT) {
+                    const int r = i >> 6, e = i & 63, wq = e >> 3, gg = (e >> 1) & 3, half = e & 1;
                     unsigned m = 0u;
-                    if (sUid[r] < 0 || lo >= a.n_items) m = 0xffffffffu;
-                    else if (lo + 32 > a.n_items) m = 0xffffffffu << (a.n_items - lo);
-                    if (m) atomicOr(&bits[r * BWP + wd], m);
+                    if (sUid[r] < 0) m = 0xffffffffu;
+                    else {
+#pragma unroll
+                        for (int ii = 0; ii < 8; ++ii) {
+                            const int lo = pbase + 16 * (wq + 8 * (half * 8 + ii)) + 4 * gg;   // first of the four columns of bits 4 ii .. 4 ii + 3
+                            if (lo + 4 > a.n_items) m |= (lo >= a.n_items ? 0xfu : (0xfu << (a.n_items - lo)) & 0xfu) << (4 * ii);
+                        }
+                    }
+                    if (m) atomicOr(&bits[r * RS + e], m);
                 }
             }
         }
         __syncthreads();   // ---- barrier A
 
         PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 1)
-        for (int i = tid; i < R * BWP; i += kPanNT) bits_next[i] = 0u;   // (last read before barrier B of the panel before)
+        for (int i = tid; i < R * RS; i += kPanNT) bits_next[i] = 0u;   // (last read before barrier B of the panel before)
         if (tid == 0) sFlag[(p + 1) & 1] = 0;
         bool safe = force_safe, counted = false;   // counted: this panel's target counts are in
         const bool first = p == 0;
@@ -475,59 +486,94 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
             //      stored to LDS as a key when its group of TPG tiles is complete), hits against tau in the others
             float tau[RB];
             int nh[RB];
+            // The pass is specialised per PANEL, not per tile: the tile loop of the common panels (not the first, the single
+            // target wholly behind or wholly in front of the panel) is straight-line code -- mask, four compares against the
+            // target score, four against tau.  Decided per tile, the same work walked six scalar branches per tile and row block
+            // (first panel? biases? target before / inside / behind the tile?) and took 5.8 us per panel instead of the ~2.5 us its
+            // vector instructions need.  TM: 0 = decide per tile (first panel, several targets, the panel that holds the target),
+            // 1 = every tile lies in front of the target (ties count: >=), 2 = every tile lies behind it (>).
+            // (the masking, which rewrites the accumulators, is ONE loop in front of the specialised ones: four copies of a loop that
+            //  writes 120 registers met in 120 phi copies and spilled 200 of them)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int row = rb * 16 + u;
-                float gm = -INFINITY;
-                if (first) {   // groups that do not exist (NTW < 8 * TPG)
-#pragma unroll
-                    for (int q = (NTW + TPG - 1) / TPG; q < 8; ++q) sMax[row * 256 + (w * 4 + g) * 8 + q] = 0u;
-                }
-                tau[rb] = first ? INFINITY : sTau[row];
-                nh[rb] = 0;
+                const uint2 seen = *reinterpret_cast<const uint2 *>(bits + (rb * 16 + u) * RS + ((w * 4 + g) << 1));   // this lane's 4 * NTW bits
 #pragma unroll
                 for (int i = 0; i < NTW; ++i) {
-                    const int col0 = 16 * (w + 8 * i) + 4 * g;            // panel-relative column of register 0
-                    const int id0 = pbase + col0;
-                    if (a.ubias) {
+                    if (a.ubias) {   // (workgroup-uniform, decided per tile: a loop of its own over all tiles merged 120 registers at its end)
+                        const int id0 = pbase + 16 * (w + 8 * i) + 4 * g;
                         float ib[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ib[r] = id0 + r < a.n_items ? a.ibias[id0 + r] : 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[rb][i][r] = ((acc[rb][i][r] + ub[rb]) + ib[r]) + a.mean;
                     }
-                    const unsigned nib = bits[row * BWP + (col0 >> 5)] >> (col0 & 28);
+                    const unsigned sw = i < 8 ? seen.x : seen.y;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)   // seen / out of range: all ones = a NaN, which loses every comparison and every fmaxf below
-                        acc[rb][i][r] = __uint_as_float(__float_as_uint(acc[rb][i][r]) | (unsigned)(((int)(nib << (31 - r))) >> 31));
-#pragma unroll
-                    for (int t = 0; t < NTG; ++t) {
-                        const int tile0 = pbase + 16 * (w + 8 * i);       // wave-uniform
-                        if (tile0 + 16 <= tgt[t]) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] >= ts[rb][t] ? 1 : 0;
-                        } else if (tile0 > tgt[t]) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] > ts[rb][t] ? 1 : 0;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                cntr[rb][t] += (id0 + r != tgt[t] && (acc[rb][i][r] > ts[rb][t] || (acc[rb][i][r] == ts[rb][t] && id0 + r < tgt[t]))) ? 1 : 0;
-                        }
-                    }
-                    if (first) {
-                        gm = fmaxf(gm, fmaxf(fmaxf(acc[rb][i][0], acc[rb][i][1]), fmaxf(acc[rb][i][2], acc[rb][i][3])));   // (masked scores are NaNs: ignored)
-                        if ((i + 1) % TPG == 0 || i + 1 == NTW) {
-                            sMax[row * 256 + (w * 4 + g) * 8 + i / TPG] = gm == -INFINITY ? 0u : score_key(gm);   // (a group of masked scores only: no maximum)
-                            gm = -INFINITY;
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) nh[rb] += acc[rb][i][r] >= tau[rb] ? 1 : 0;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // (keeps the tiles' work from being interleaved: 15 tiles of temporaries do not fit)
+                        acc[rb][i][r] = __uint_as_float(__float_as_uint(acc[rb][i][r]) | (unsigned)(((int)(sw << (31 - 4 * (i & 7) - r))) >> 31));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            auto pass1 = [&](auto tm_c, auto first_c) __attribute__((always_inline)) {
+                constexpr int TM = decltype(tm_c)::value;
+                constexpr bool FIRST = decltype(first_c)::value;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = rb * 16 + u;
+                    float gm = -INFINITY;
+                    if (FIRST) {   // groups that do not exist (NTW < 8 * TPG)
+#pragma unroll
+                        for (int q = (NTW + TPG - 1) / TPG; q < 8; ++q) sMax[row * 256 + (w * 4 + g) * 8 + q] = 0u;
+                    }
+                    tau[rb] = FIRST ? INFINITY : sTau[row];
+                    nh[rb] = 0;
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) {
+                        if (TM == 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cntr[rb][0] += acc[rb][i][r] >= ts[rb][0] ? 1 : 0;
+                        } else if (TM == 2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cntr[rb][0] += acc[rb][i][r] > ts[rb][0] ? 1 : 0;
+                        } else {
+                            const int id0 = pbase + 16 * (w + 8 * i) + 4 * g;
+#pragma unroll
+                            for (int t = 0; t < NTG; ++t) {
+                                const int tile0 = pbase + 16 * (w + 8 * i);       // wave-uniform
+                                if (tile0 + 16 <= tgt[t]) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] >= ts[rb][t] ? 1 : 0;
+                                } else if (tile0 > tgt[t]) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) cntr[rb][t] += acc[rb][i][r] > ts[rb][t] ? 1 : 0;
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        cntr[rb][t] += (id0 + r != tgt[t] && (acc[rb][i][r] > ts[rb][t] || (acc[rb][i][r] == ts[rb][t] && id0 + r < tgt[t]))) ? 1 : 0;
+                                }
+                            }
+                        }
+                        if (FIRST) {
+                            gm = fmaxf(gm, fmaxf(fmaxf(acc[rb][i][0], acc[rb][i][1]), fmaxf(acc[rb][i][2], acc[rb][i][3])));   // (masked scores are NaNs: ignored)
+                            if ((i + 1) % TPG == 0 || i + 1 == NTW) {
+                                sMax[row * 256 + (w * 4 + g) * 8 + i / TPG] = gm == -INFINITY ? 0u : score_key(gm);   // (a group of masked scores only: no maximum)
+                                gm = -INFINITY;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) nh[rb] += acc[rb][i][r] >= tau[rb] ? 1 : 0;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // (keeps the tiles' work from being interleaved: 15 tiles of temporaries do not fit)
+                    }
+                }
+            };
+            using pan_c0 = std::integral_constant<int, 0>;
+            using pan_c1 = std::integral_constant<int, 1>;
+            using pan_c2 = std::integral_constant<int, 2>;
+            if (first) pass1(pan_c0{}, std::true_type{});
+            else if (NTG == 1 && tgt[0] >= pbase + PI) pass1(pan_c1{}, std::false_type{});
+            else if (NTG == 1 && tgt[0] < pbase) pass1(pan_c2{}, std::false_type{});
+            else pass1(pan_c0{}, std::false_type{});
             counted = true;
             PAN_STAMP(2 + 8 * (p < 3 ? p : 3) + 2)
             if (first) {
@@ -761,7 +807,7 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
                         t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, av.z, t, 0, 0, 0);
                         t = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, av.w, t, 0, 0, 0);
                     }
-                    const unsigned nib = bits[row * BWP + (col0 >> 5)] >> (col0 & 28);
+                    const unsigned nib = bits[row * RS + ((w * 4 + g) << 1) + (i >> 3)] >> (4 * (i & 7));
                     // exact: once K entries are held (tau = the K-th key) a later id with s == tau loses the tie -> strict compare;
                     // with fewer than K held everything unmasked so far is in the list and everything unmasked enters
                     const float tau = sTau[row];
