@@ -929,8 +929,9 @@ inline long long pan_scratch_floats(int n_items, int d) { return (long long)n_it
 // user rows per workgroup: 32 (one workgroup per CU, every item operand feeds 8 MFMAs) pays from 8192 users on when the sweep is
 // operand-bound -- dim > 64 or catalogues of >= 65 536 items; measured 8 192 x 34 474 x 128 1.05 vs 1.18 ms, 16 384 x 131 072 x 64
 // 4.43 vs 4.72, but 4 096 x 34 474 x 64 0.69 vs 0.47 and 8 192 x 34 474 x 64 0.73 vs 0.70 (rk_score_plan.panel_rows overrides)
-inline int pan_rows(int nb, int n_items, int d)
+inline int pan_rows(int nb, int n_items, int d, int n_targets = 1)
 {
+    if (n_targets > 1) return 16;   // (the multi-target instantiation spills at 32 rows: 2.3 vs 1.6 ms at 16384 x 34474 x 64)
     return nb >= 8192 && (d > 64 || n_items >= 65536) ? 32 : 16;
 }
 // 16-item tiles per wave and panel: the narrow form (8: 1024-item panels) while the catalogue fits one or two narrow panels

@@ -684,7 +684,13 @@ static inline long long score_ld(int n_items) { return ((long long)n_items + 31)
 static bool panel_by_default(int nb, int n_items, int dim, int K, int n_targets)
 {
     if (!pan_supported(n_items, dim, K, n_targets)) return false;
-    return n_items >= kPanDefaultMinItems && (nb >= 8192 || (nb >= 4096 && dim <= 64));
+    // measured (profiles/r05i_score_thresholds.txt): with a full machine of workgroups (>= 8192 user rows) the panel form wins from 8192
+    // items on (8192 x 8192 x 64: 219 vs 241 us; 8192 x 6144 x 64: 181 vs 161); with 4096 rows it only ties at dim <= 64 from 16384 items on
+    // several targets: the per-target counters push the 32-row form over its register budget (r05i_score_targets.txt: 4 targets,
+    // 8192 x 34474 x 256 1.97 ms against 1.83 for GEMM + selection; 16384 x 34474 x 64 with 16-row workgroups 1.63 against 1.92)
+    if (n_targets > 1 && dim > 64) return false;
+    if (nb >= 8192) return n_items >= kPanDefaultMinItems / 2;
+    return n_items >= kPanDefaultMinItems && nb >= 4096 && dim <= 64;
 }
 
 RK_EXPORT int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32_t K, int32_t n_targets, const rk_score_plan *request,
@@ -705,7 +711,7 @@ RK_EXPORT int rk_score_topk_plan(int32_t nb, int32_t n_items, int32_t dim, int32
         const int rows = request ? request->panel_rows : 0, ntw = request ? request->panel_ntw : 0;
         if ((rows != 0 && rows != 16 && rows != 32) || (ntw != 0 && ntw != 8 && ntw != 15)) RK_FAIL(RK_EINVAL, "rk_score_topk_plan: panel_rows in {16, 32}, panel_ntw in {8, 15}");
         pl.panel_ntw = ntw ? ntw : pan_ntw(n_items);
-        pl.panel_rows = pl.panel_ntw == 8 ? 16 : (rows ? rows : pan_rows(nb, n_items, dim));
+        pl.panel_rows = pl.panel_ntw == 8 ? 16 : (rows ? rows : pan_rows(nb, n_items, dim, n_targets));
         pl.panel_safe = request && request->panel_safe ? 1 : 0;
         pl.scratch_floats = (int64_t)pan_scratch_floats(n_items, dim);   // the k-permuted item table
     } else {

@@ -24,25 +24,26 @@ ptr[1:] = np.cumsum(deg)
 idx = np.concatenate([np.sort(rng.choice(I, size=k, replace=False)) for k in deg]).astype(np.int32)
 ids = torch.arange(nu, dtype=torch.int32, device=dev)
 sp, si = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
-tg = torch.tensor([0], dtype=torch.int32, device=dev)
+NT = int(os.environ.get("PROBE_TARGETS", "1"))   # target items per user block (the panel form's multi-target instantiation from 2 on)
+tg = torch.tensor([(7 * t * t + 3 * t) % I for t in range(NT)], dtype=torch.int32, device=dev)
 K = 100
 top_ids = torch.empty(nu, K, dtype=torch.int32, device=dev)
 top_sc = torch.empty(nu, K, device=dev)
-ts = torch.empty(nu, 1, device=dev)
-tr = torch.empty(nu, 1, dtype=torch.int32, device=dev)
+ts = torch.empty(nu, NT, device=dev)
+tr = torch.empty(nu, NT, dtype=torch.int32, device=dev)
 out = {}
 modes = os.environ.get("PROBE_MODES", "panel,unfused").split(",")
 for mode in modes:
     chunk = nu if mode != "unfused" else max(256, min(8192, (1 << 31) // I))
     req = {"path": "gemm"} if mode == "unfused" else dict({"path": "panel"}, **({"panel_rows": int(os.environ["PROBE_ROWS"])} if os.environ.get("PROBE_ROWS") else {}))
-    plan = score_plan(min(chunk, nu), I, d, K, 1, req)
+    plan = score_plan(min(chunk, nu), I, d, K, NT, req)
     scratch = torch.empty(int(plan.scratch_floats) + 16384, device=dev)
 
     def once():
         for s in range(0, nu, chunk):
             e = min(nu, s + chunk)
             _lib.check(_lib.lib().rk_score_topk(d, _lib.ptr(utab), e - s, _lib.ptr(ids[s:e]), _lib.ptr(itab), I, None, None, 0.0, _lib.ptr(sp), _lib.ptr(si),
-                                                K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_sc[s:e]), _lib.ptr(tg), 1, _lib.ptr(ts[s:e]), _lib.ptr(tr[s:e]),
+                                                K, _lib.ptr(top_ids[s:e]), _lib.ptr(top_sc[s:e]), _lib.ptr(tg), NT, _lib.ptr(ts[s:e]), _lib.ptr(tr[s:e]),
                                                 C.byref(plan), _lib.ptr(scratch), _lib.stream_ptr()), "rk_score_topk")
     once(); once()
     torch.cuda.synchronize()

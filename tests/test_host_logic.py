@@ -319,7 +319,7 @@ def test_ctypes_descriptors_match_the_header(tmp_path):
 
 def test_score_topk_plan_names_the_path():
     """rk_score_topk_plan (host code of the C ABI, no GPU needed) names the path rk_score_topk will take and sizes its scratch:
-    GEMM + selection (a [nb, n_items] matrix) below 16 384 items or for user blocks too small to fill the chip, the
+    GEMM + selection (a [nb, n_items] matrix) below 8 192 items or for user blocks too small to fill the chip, the
     register-resident panel form (a k-permuted copy of the item table) otherwise; a request forces a path and the panel form's
     shape knobs, and a path that cannot take the request is refused.  No environment variable is consulted."""
     import os
@@ -336,6 +336,12 @@ def test_score_topk_plan_names_the_path():
         gemm = lambda nb, I: (_lib.RK_SCORE_GEMM, nb * ((I + 31) // 32 * 32))   # rows padded to 128-byte lines (plan.ld_scores)
         assert f(5893, 3702, 64) == gemm(5893, 3702)                  # ml1m: GEMM + selection
         assert f(16384, 34474, 64) == panel(34474, 64)
+        assert f(8192, 8192, 64) == panel(8192, 64)                   # a full machine of workgroups: from 8 192 items on (219 vs 241 us measured)
+        assert f(8192, 6144, 64) == gemm(8192, 6144)                  # (181 vs 161 us)
+        assert f(4096, 8192, 64) == gemm(4096, 8192)
+        assert f(8192, 34474, 256, 100, 4) == gemm(8192, 34474)       # several targets: the panel form only at dim <= 64 ...
+        assert f(16384, 34474, 64, 100, 4) == panel(34474, 64)
+        assert score_plan(16384, 131072, 64, 100, 4, None).panel_rows == 16   # ... and in 16-row workgroups
         assert f(54617, 34474, 128) == panel(34474, 128)
         assert f(8192, 34474, 100) == panel(34474, 100)               # k padded to a multiple of 16
         assert f(8192, 34474, 256) == panel(34474, 256)
