@@ -927,7 +927,7 @@ static constexpr int kHeadSteps = 3, kPieceGrowth = 6, kMaxPieces = 4;
 static int cut_whole_call(int n_steps, int (&piece)[kMaxPieces])
 {
     int n = 0, left = n_steps, len = kHeadSteps;
-    if (n_steps < 3 * kHeadSteps) { piece[0] = n_steps; return 1; }
+    if (n_steps < 3 * kHeadSteps || RK_TUNE_INT("RK_NO_CHAIN", 0)) { piece[0] = n_steps; return 1; }   // (knob: tuning builds only, the A/B of r05j_chain_ab.txt)
     while (left > 0) {
         int take = (n == kMaxPieces - 1 || left - len < kHeadSteps) ? left : len;
         piece[n++] = take;
