@@ -209,7 +209,7 @@ def relerr_max(a, b):
 
 def run_steps(victim, triplets, B, lo, n_steps):
     """Steps [lo, lo + n_steps) of the resident triplets through the victim's epoch call -- the timed call of this bench
-    (after victim.reserve(): the whole call replayed from captured hipGraphs for <= 64 steps -- a 3-step head graph, then the rest --, chunk graphs beyond)."""
+    (after victim.reserve(): one whole-call hipGraph replay for <= 64 steps, chunk graphs beyond)."""
     users, pos, neg = triplets
     sl = slice(lo * B, (lo + n_steps) * B)
     return victim._run_epoch(users[sl], pos[sl], neg[sl], B)
@@ -860,7 +860,7 @@ def worker(args, traffic_live=None):
                                      "c_call": (tc[3] - tc[2]) * 1e6, "behind_the_c_call": (t_enq - tc[3]) * 1e6},
                     "enqueue_returns_after_us": (t_enq - t0) * 1e6, "completion_seen_after_us": (t_seen - t0) * 1e6,
                     "closing_barrier_us": (elapsed - (t_seen - t0)) * 1e6, "gpu_span_us": ev_a.elapsed_time(ev_b) * 1e3,
-                    "note": "the K timed steps are ONE call (K <= 64: replayed from captured hipGraphs, a 3-step head so that the device starts early, then the rest): gpu_span = first to last kernel by HIP events on the "
+                    "note": "the K timed steps are ONE call (one whole-call hipGraph replay for K <= 64): gpu_span = first to last kernel by HIP events on the "
                             "launch stream; host_total - gpu_span = launch latency + completion detection + the contract's barrier / synchronize pair",
                     "in_front": "the roofline probe (~13 ms of the dominant kernel, workspace buffers only), then the W warm-up steps, then the opening barrier: "
                                 "the device is at its working clocks (the same call is 5-8 % slower behind an idle period, profiles/r05e_call_clock.txt) and the host path is hot"}

@@ -284,11 +284,10 @@ int rk_lightgcn_propagate_dropout(rk_lightgcn_t h, uint64_t mask_seed, void *str
  * float[ceil(n/batch)*RK_LOSS_PARTIALS]; step s's loss is the sum of its RK_LOSS_PARTIALS
  * entries (fixed order => reproducible).  apply_update=0 leaves parameters untouched and
  * only fills desc.grad (testing).
- * graph_steps > 1 replays captured hipGraphs: an epoch of <= RK_MAX_GRAPH_STEPS steps is replayed whole (scatter-target
- * zeroing and, on the LDS path, the layout conversions included) -- from 9 steps on as a chain of graphs, a 3-step head first
- * so that the device starts while the host is still enqueueing the rest; a longer one is replayed in chunks of
+ * graph_steps > 1 replays captured hipGraphs: an epoch of <= RK_MAX_GRAPH_STEPS steps is ONE replay of a whole-call graph
+ * (scatter-target zeroing and, on the LDS path, the layout conversions included); a longer one is replayed in chunks of
  * graph_steps steps plus one remainder graph (a single trailing step is launched kernel by kernel).  The triplet and loss
- * pointers reach the kernels through desc.state, not through the captured launches, so the graphs (cached per handle, 12
+ * pointers reach the kernels through desc.state, not through the captured launches, so the graphs (cached per handle, 8
  * LRU slots) serve any buffers; they must stay valid until the stream has run the call. */
 int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, const int64_t *pos, const int64_t *neg,
                             int64_t n, int32_t batch, int32_t adam_t0, float *loss_partials,

@@ -15,10 +15,10 @@ struct rk_lightgcn {
     rk_lightgcn_desc d;
     hipStream_t cap_stream = nullptr;
     // Captured train steps.  Nothing the caller passes per epoch is baked in (the triplet / loss pointers travel through the
-    // device state block), so an exec stays valid for the life of the handle.  `whole` says what of a complete
-    // rk_lightgcn_train_epoch call a graph holds besides its n_steps steps: bit 0 the call's prologue (zeroing of the scatter
-    // targets and -- LDS path -- the layout conversions), bit 1 its epilogue; 0: a chunk of a longer epoch.  LRU over kExecSlots.
-    static constexpr int kExecSlots = 12;
+    // device state block), so an exec stays valid for the life of the handle.  `whole` graphs are one complete
+    // rk_lightgcn_train_epoch call of n_steps steps (zeroing of the scatter targets and -- LDS path -- the layout
+    // conversions included); the others are chunks of a longer epoch.  LRU over kExecSlots.
+    static constexpr int kExecSlots = 8;
     struct Exec {
         hipGraphExec_t exec = nullptr;
         int n_steps = 0, whole = 0, update = 0, det = 0, batch = 0;
@@ -827,7 +827,7 @@ static int launch_epilogue(const rk_lightgcn_desc &d, int apply_update, hipStrea
     return RK_OK;
 }
 
-// hipGraph of n_steps train steps (whole & 1: behind the call's prologue, whole & 2: followed by its epilogue)
+// hipGraph of n_steps train steps (whole: a complete epoch call, prologue and epilogue included)
 static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update, int batch, hipStream_t upload_stream, hipGraphExec_t *out)
 {
     const rk_lightgcn_desc &d = h->d;
@@ -853,10 +853,10 @@ static int ensure_exec(rk_lightgcn *h, int n_steps, int whole, int apply_update,
     hipGraph_t g = nullptr;
     RK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = RK_OK;
-    if (whole & 1) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
+    if (whole) rc = launch_prologue(d, apply_update, h->cap_stream, h->deterministic != 0);
     for (int k = 0; k < n_steps && rc == RK_OK; ++k)
         rc = launch_step(d, k, apply_update, k == n_steps - 1 ? n_steps : 0, h->cap_stream, batch, ord);
-    if ((whole & 2) && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
+    if (whole && rc == RK_OK) rc = launch_epilogue(d, apply_update, h->cap_stream);
     hipError_t err = hipStreamEndCapture(h->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     RK_HIP(err);
@@ -915,28 +915,9 @@ RK_EXPORT int rk_lightgcn_set_deterministic(rk_lightgcn_t h, int32_t on)
     return RK_OK;
 }
 
-// How an epoch of n_steps is cut: n_steps <= RK_MAX_GRAPH_STEPS (and graph replay wanted): the whole call is replayed from
-// captured graphs, prologue and epilogue included; otherwise chunks of graph_steps steps and one remainder graph.
+// How an epoch of n_steps is cut: n_steps <= RK_MAX_GRAPH_STEPS (and graph replay wanted): ONE whole-call graph;
+// otherwise chunks of graph_steps steps and one remainder graph.
 static bool whole_call(int n_steps, int graph_steps) { return graph_steps > 1 && n_steps >= 1 && n_steps <= RK_MAX_GRAPH_STEPS; }
-
-// A whole call as a CHAIN of graphs: hipGraphLaunch costs the host ~0.7-1.2 us per kernel node and the device idles until the
-// launch has been processed (a 20-step call = 143 nodes: 100-180 us before the first kernel, 5-9 us per step of the call).  A
-// short head (kHeadSteps steps) starts the device after ~20 us; every next piece is up to kPieceGrowth times as long as the one
-// that is running while it is enqueued (a step takes the device ~10x as long as the host needs to enqueue it).
-static constexpr int kHeadSteps = 3, kPieceGrowth = 6, kMaxPieces = 4;
-static int cut_whole_call(int n_steps, int (&piece)[kMaxPieces])
-{
-    int n = 0, left = n_steps, len = kHeadSteps;
-    if (n_steps < 3 * kHeadSteps || RK_TUNE_INT("RK_NO_CHAIN", 0)) { piece[0] = n_steps; return 1; }   // (knob: tuning builds only, the A/B of r05j_chain_ab.txt)
-    while (left > 0) {
-        int take = (n == kMaxPieces - 1 || left - len < kHeadSteps) ? left : len;
-        piece[n++] = take;
-        left -= take;
-        len *= kPieceGrowth;
-    }
-    return n;
-}
-static int piece_flags(int i, int n) { return (i == 0 ? 1 : 0) | (i == n - 1 ? 2 : 0); }
 
 RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, int64_t n, int32_t batch, int32_t apply_update, int32_t graph_steps, void *stream)
 {
@@ -951,15 +932,7 @@ RK_EXPORT int rk_lightgcn_prepare(rk_lightgcn_t h, int64_t n, int32_t batch, int
     if (!s) { if (!h->cap_stream) RK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)); up = h->cap_stream; } else up = s;
     const int n_steps = (int)std::min<long long>((n + batch - 1) / batch, 1LL << 30);
     hipGraphExec_t ex = nullptr;
-    if (whole_call(n_steps, graph_steps)) {
-        int piece[kMaxPieces];
-        const int np = cut_whole_call(n_steps, piece);
-        for (int i = 0; i < np; ++i) {
-            const int rc = ensure_exec(h, piece[i], piece_flags(i, np), apply_update, batch, up, &ex);
-            if (rc) return rc;
-        }
-        return RK_OK;
-    }
+    if (whole_call(n_steps, graph_steps)) return ensure_exec(h, n_steps, 1, apply_update, batch, up, &ex);
     int rc = ensure_exec(h, graph_steps, 0, apply_update, batch, up, &ex);
     if (rc) return rc;
     const int rem = n_steps % graph_steps;
@@ -999,15 +972,11 @@ RK_EXPORT int rk_lightgcn_train_epoch(rk_lightgcn_t h, const int64_t *users, con
         if (rc) return rc;
     }
     if (graph_steps > RK_MAX_GRAPH_STEPS) graph_steps = RK_MAX_GRAPH_STEPS;
-    if (whole_call(n_steps, graph_steps)) {   // the whole call is replayed: a short head graph, then the rest behind it
-        int piece[kMaxPieces];
-        const int np = cut_whole_call(n_steps, piece);
-        hipGraphExec_t ex[kMaxPieces];
-        for (int i = 0; i < np; ++i) {   // (captures, if any, before the first launch: nothing is enqueued behind a half-built call)
-            const int rc = ensure_exec(h, piece[i], piece_flags(i, np), apply_update, batch, nullptr, &ex[i]);
-            if (rc) return rc;
-        }
-        for (int i = 0; i < np; ++i) RK_HIP(hipGraphLaunch(ex[i], s));
+    if (whole_call(n_steps, graph_steps)) {   // the whole call is one replay
+        hipGraphExec_t ex = nullptr;
+        int rc = ensure_exec(h, n_steps, 1, apply_update, batch, nullptr, &ex);
+        if (rc) return rc;
+        RK_HIP(hipGraphLaunch(ex, s));
         return RK_OK;
     }
     int rc = launch_prologue(d, apply_update, s, h->deterministic != 0);

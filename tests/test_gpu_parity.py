@@ -1375,11 +1375,12 @@ def test_lightgcn_vs_oracle_shapes(gpu_device, d, L, graph_source, lds):
 
 @pytest.mark.parametrize("lds", [False, True])
 @pytest.mark.parametrize("n_steps", [8, 9, 11, 21, 25, 64])
-def test_lightgcn_whole_call_chain_same_bits(gpu_device, n_steps, lds):
-    """An epoch call of <= RK_MAX_GRAPH_STEPS steps is replayed as a CHAIN of graphs from nine steps on (csrc/lightgcn.hip
-    cut_whole_call: 3-step head, pieces growing 6x, the call's prologue in the first graph and its epilogue in the last).  With
-    the ordered scatter the step has no float atomics, so the chain, and a second call replaying the cached pieces, must end in
-    exactly the tables and losses of plain kernel-by-kernel launches (ragged last step included)."""
+def test_lightgcn_whole_call_replay_same_bits(gpu_device, n_steps, lds):
+    """An epoch call of <= RK_MAX_GRAPH_STEPS steps is ONE replay of a whole-call hipGraph (prologue, steps, epilogue:
+    csrc/lightgcn.hip ensure_exec).  With the ordered scatter the step has no float atomics, so the replay, and a second call
+    replaying the cached graph, must end in exactly the tables and losses of plain kernel-by-kernel launches (ragged last step
+    included).  (Round 5 also ran this against a CHAIN of graphs -- 3-step head, then the rest -- which was bit-identical and, on one
+    box alternating, no faster: profiles/r05j_chain_ab.txt; reverted.)"""
     from recad_amd import dataset, model, synth
     dd = synth.make("tiny")
     B = 128
@@ -1395,7 +1396,7 @@ def test_lightgcn_whole_call_chain_same_bits(gpu_device, n_steps, lds):
         reps = -(-(n_steps * B) // users.numel())
         users, pos, neg = (t.repeat(reps)[: n_steps * B - 19].contiguous() for t in (users, pos, neg))
         out = []
-        for _ in range(2):   # the second call replays the cached pieces
+        for _ in range(2):   # the second call replays the cached graph
             out.append(m._run_epoch(users, pos, neg, B).sum(1).cpu().numpy().copy())
         return m, out
 
