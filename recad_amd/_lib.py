@@ -214,7 +214,21 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None):
+    """The current HIP stream of `device` (default: the current device) as a pointer argument.  Through torch's raw accessor when it
+    exists (0.3 us; torch.cuda.current_stream() builds a Stream object and resolves the device index in Python: 4 us, on every call
+    of the C ABI)."""
+    if _raw_stream is not None:
+        if device is None:
+            idx = torch.cuda.current_device()
+        else:
+            idx = device if isinstance(device, int) else torch.device(device).index
+            if idx is None:
+                idx = torch.cuda.current_device()
+        return C.c_void_p(_raw_stream(idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

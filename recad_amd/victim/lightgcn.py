@@ -58,6 +58,7 @@ class LightGCN(BaseVictim):
         self._fused_adam = self._adam_is_fused()
         self._handle = None
         self._handle_key = None
+        self._fingerprint = None
         self._ws = None
         self.graph_steps = 32  # steps per hipGraph replay of a long epoch (<= 64-step epochs are one replay); 0/1 = plain launches
         # last forward layer only on the minibatch's rows (-4 us of 18 on ml1m)
@@ -121,7 +122,30 @@ class LightGCN(BaseVictim):
             self.Graph = CsrGraph.from_torch_coo(self.Graph, device, class_split=self.num_users)
         return self.Graph.to(device)
 
+    def _handle_fingerprint(self, want_grad):
+        """What a live handle depends on, read the cheap way (no storage checks): the four base pointers the kernels were given
+        and every value the handle copied.  Equal to the one taken when the handle was built <=> the slow path's key is equal
+        (a Parameter or moment that was re-homed, moved or replaced has a new data_ptr)."""
+        wu, wi = self.embedding_user.weight, self.embedding_item.weight
+        st = self.optimizer.state if self._fused_adam else None
+        su = st.get(wu) if st is not None else None
+        si = st.get(wi) if st is not None else None
+        if st is not None and (not su or not si or "exp_avg" not in su or "exp_avg" not in si):
+            return None
+        grp = self.optimizer.param_groups[0]
+        betas = grp.get("betas", (0.9, 0.999))
+        return (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr() if su else 0, si["exp_avg"].data_ptr() if si else 0,
+                su["exp_avg_sq"].data_ptr() if su else 0, si["exp_avg_sq"].data_ptr() if si else 0, bool(want_grad),
+                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
+                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
+                bool(self.deterministic), str(self.use_lds), bool(self.fuse_layers))
+
     def _ensure_handle(self, want_grad=False):
+        # fast path of a live handle (every epoch call, every evaluation): one tuple of pointers and scalars against the one taken
+        # when the handle was built -- the full check below re-walks the storages (adjacency, devices) and costs 3x as much,
+        # with the device waiting behind the caller's synchronize in a short epoch
+        if self._handle is not None and self._fingerprint is not None and self._fingerprint == self._handle_fingerprint(want_grad):
+            return self._handle
         _lib.require_gpu()
         dev = self.embedding_user.weight.device
         if dev.type != "cuda":
@@ -137,6 +161,7 @@ class LightGCN(BaseVictim):
                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
                bool(self.deterministic), str(self.use_lds), bool(self.fuse_layers))
         if self._handle is not None and self._handle_key == key:
+            self._fingerprint = self._handle_fingerprint(want_grad)
             return self._handle
         self._drop_handle()
         g = self._csr(dev)
@@ -195,6 +220,7 @@ class LightGCN(BaseVictim):
         if self.deterministic:
             _lib.check(_lib.lib().rk_lightgcn_set_deterministic(h, 1), "rk_lightgcn_set_deterministic")
         self._handle, self._handle_key, self._ws = h, key, ws
+        self._fingerprint = self._handle_fingerprint(want_grad)
         return h
 
     def check_handoffs(self):
@@ -211,6 +237,7 @@ class LightGCN(BaseVictim):
             _lib.lib().rk_lightgcn_destroy(self._handle)
             self._handle = None
             self._handle_key = None
+            self._fingerprint = None
 
     def __del__(self):
         try:
