@@ -516,6 +516,11 @@ def spmm_roofline(args, victim, N, nnz, traffic_live=None):
                 "timed_as": timed_as + (f"; median of {rounds} windows ({min(windows) * 1e3:.2f} - {max(windows) * 1e3:.2f} us)" if rounds > 1 else ""),
                 "note": "per-launch time from HIP events on the launch stream around back-to-back launches (includes the "
                         "inter-kernel boundary); algorithmic bytes = SURVEY 8d's 8 nnz + 4 (N+1) + 8 N d"}
+    if traffic:
+        # the bytes the launch actually MOVED against the same peak: a row gather on a graph without reuse (every nonzero fetches its
+        # d-float row: i.i.d. synthetic graphs) sits at the fabric's rate here while `frac`, priced on each operand being read once, is small
+        roofline["traffic_frac"] = traffic / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roofline["traffic_frac_note"] = "counter traffic / launch time / peak (fabric side, Infinity-Cache hits included): how busy the memory system is, not a quality claim"
     if traffic_live and traffic_live.get("detail"):
         roofline["traffic_detail"] = traffic_live["detail"]
     if lds is not None:
