@@ -156,7 +156,8 @@ class LightGCN(BaseVictim):
         # everything the handle (and the hipGraph captured inside it) copies BY VALUE is part of the key: a later
         # change of lr / betas / eps (a scheduler, a manual decay) or of config["lambda"] rebuilds the handle, as
         # the reference re-reads them every step
-        key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(), bool(want_grad),
+        key = (wu.data_ptr(), wi.data_ptr(), su["exp_avg"].data_ptr(), si["exp_avg"].data_ptr(),
+               su["exp_avg_sq"].data_ptr(), si["exp_avg_sq"].data_ptr(), bool(want_grad),   # (every base pointer the descriptor holds)
                self.graph_dropout, float(self.keep_prob) if self.graph_dropout else 0.0,
                float(grp["lr"]), float(betas[0]), float(betas[1]), float(grp.get("eps", 1e-8)), float(self.config["lambda"]),
                bool(self.deterministic), str(self.use_lds), bool(self.fuse_layers))

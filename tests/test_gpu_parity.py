@@ -1818,6 +1818,48 @@ def test_lightgcn_adam_options_and_live_lr(gpu_device):
     assert G.relerr(m.embedding_item.weight.detach().cpu().numpy(), i) < 1e-5
 
 
+def test_lightgcn_handle_fingerprint(gpu_device):
+    """The live-handle fast path (victim/lightgcn.py _handle_fingerprint): an unchanged model reuses its handle without the
+    storage walk; everything the handle copied or points at -- lr, lambda, a re-homed moment (optimizer.load_state_dict makes new
+    tensors), the gradient buffer request -- makes the next call rebuild it, exactly as the full key does."""
+    g = G.load("lightgcn_dev_d128_l2_tg")
+    m, ds = _make_lgn(g, gpu_device, steps=[0])
+    m.train_step()
+    drops = []
+    real_drop = m._drop_handle
+    m._drop_handle = lambda: (drops.append(1), real_drop())[1]
+    fp = m._fingerprint
+    assert fp is not None and m._handle_fingerprint(False) == fp
+    h = m._ensure_handle()
+    assert h is m._handle and not drops                      # fast path: same handle, nothing rebuilt
+    m.computer()
+    assert not drops
+    m.optimizer.param_groups[0]["lr"] = 2e-3                 # a copied scalar
+    m._ensure_handle()
+    assert len(drops) == 1 and m._fingerprint != fp
+    m.config["lambda"] = float(m.config["lambda"]) * 2
+    m._ensure_handle()
+    assert len(drops) == 2
+    st_u = m.optimizer.state[m.embedding_user.weight]
+    before = {k: v.clone() for k, v in st_u.items() if torch.is_tensor(v)}
+    m.optimizer.load_state_dict(m.optimizer.state_dict())   # (torch keeps tensors that already sit on the right device: nothing to rebuild)
+    m._ensure_handle()
+    assert len(drops) == 2
+    st_u = m.optimizer.state[m.embedding_user.weight]
+    st_u["exp_avg_sq"] = st_u["exp_avg_sq"].clone()          # a moment in a new tensor (what a state_dict loaded from a file brings): same values
+    m._ensure_handle()
+    assert len(drops) == 3
+    after = m.optimizer.state[m.embedding_user.weight]
+    assert torch.equal(after["exp_avg"], before["exp_avg"]) and torch.equal(after["exp_avg_sq"], before["exp_avg_sq"])
+    m._ensure_handle(want_grad=True)                         # the gradient buffer is part of the handle
+    assert len(drops) == 4
+    m._ensure_handle(want_grad=True)
+    assert len(drops) == 4
+    ds.steps = [0]
+    m.train_step()                                           # (want_grad False again: one more rebuild, and the step still runs)
+    assert len(drops) == 5 and torch.isfinite(m.embedding_user.weight).all()
+
+
 @pytest.mark.parametrize("graph_steps", [0, 4])
 def test_lightgcn_zero_layers(gpu_device, graph_steps):
     """lightGCN_n_layers=0 is valid in the reference (light = E0): train and score against the oracle."""
