@@ -612,6 +612,7 @@ static int launch_forward_lds(const rk_lightgcn_desc &d, hipStream_t s, bool tra
         a.e.sum_rm = (l == L) ? 1 : 0;
         a.e.sum_scale = (l == L) ? 1.0f / (float)(L + 1) : 1.0f;
         if (training && l == 1) a.e.zero_cnt = d.cnt;   // (nullable) the incidence counts of the previous step
+        if (!lds_fused(d)) { a.e.y_staged = (l < L) ? 1 : 0; a.e.x_staged = (l > 1) ? 1 : 0; }   // (the intermediate layers: spmm_lds.h LdsEpi)
     }
     if (lds_fused(d)) return launch_lds_multi(d, li, ph.data(), L, s);
     for (int l = 0; l < L; ++l) RK_HIP(spmm_lds_launch(li, ph[(size_t)l], s));
@@ -648,7 +649,9 @@ static int launch_backward_lds(const rk_lightgcn_desc &d, int k, int apply_updat
             a.e.bump = bump;
         } else {
             a.e.y = bufs[(j + 1) & 1];
+            if (!lds_fused(d)) a.e.y_staged = 1;
         }
+        if (!lds_fused(d) && j > 1) a.e.x_staged = 1;
     }
     if (lds_fused(d)) { int rc = launch_lds_multi(d, li, ph.data(), L, s); if (rc) return rc; }
     else for (int j = 0; j < L; ++j) RK_HIP(spmm_lds_launch(li, ph[(size_t)j], s));

@@ -57,6 +57,12 @@ struct LdsEpi {
     // multi-phase launch (spmm_lds_multi_kernel): a later phase of the SAME launch gathers / reads y and sum_out -- they are
     // stored write-through (sc1) and the workgroup's arrival is counted
     int publish;
+    // Between two launches of a layer chain the intermediate y needs no natural order: y_staged -- y is written the way its ONLY
+    // consumer stages it, row r at the LDS-table position perm[r] of the other half and already multiplied by dinv[r]; x_staged --
+    // x was written like that, so staging is a plain copy: one 16-byte load per row instead of three loads (row, permutation,
+    // dinv).  The stage phase runs at the 64 B/clk a CU reads from L2 (1.04 us + 40 B/clk of table by the stamps), a third of
+    // its bytes were those two words per row.  Same products (dinv[c] * x[c], one rounding each), same bits.  Sliced y only.
+    int y_staged, x_staged;
 };
 
 // what the plan's header words say, as KERNEL ARGUMENTS (the host knows them: rk_lds_info): a workgroup's only dependent load
@@ -146,6 +152,7 @@ struct LdsRowOps {
     float dr;
     float4 addv, sumv;
     size_t so, ro;
+    int rp;   // y_staged: the row's LDS-table position in the half that stages this class (else the row itself)
 };
 
 // HAND: a phase of the multi-phase launch -- x / add / sum_in may have been written by OTHER workgroups of this launch (sc1
@@ -196,6 +203,8 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
         const int r = row0 + lr;            // class-local output row
         const int k0 = slice * S + 4 * j;   // first of this thread's four columns
         o.so = cls_base + ((((size_t)(k0 >> lso)) * (size_t)n_dst + (size_t)r) << lso) + (size_t)(k0 & ((1 << lso) - 1));
+        o.rp = r;
+        if (!HAND && e.y_staged) o.rp = (plan + (half ? hd.perm0 : hd.perm1))[r];   // (the other half stages this class)
         o.ro = (size_t)(node0 + r) * d + k0;
         o.p0 = pp[lr]; o.p1 = pp[lr + 1];
         o.dr = ddst[r];
@@ -211,6 +220,22 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
     };
     // ---- phase 1: stage the slice table, pre-scaled by dinv of the source rows
     constexpr int UN = 8;
+    if (!HAND && e.x_staged) {   // (workgroup-uniform) the producer wrote the table: a copy
+        for (int i0 = tid; i0 < n4; i0 += kLdsThreads * UN) {
+            float4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * kLdsThreads;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // (defined on both paths: left undefined the array went to scratch)
+                if (i < n4) v[u] = s4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * kLdsThreads;
+                if (i < n4) tab[i] = v[u];
+            }
+        }
+    } else
     for (int i0 = tid; i0 < n4; i0 += kLdsThreads * UN) {
         float4 v[UN];
         float s[UN];
@@ -369,7 +394,15 @@ __device__ __forceinline__ void lds_body(const float *ax, const LdsEpi &e, const
                 if (e.sum_rm) *reinterpret_cast<float4 *>(e.sum_out + o.ro) = sv; else st16_sc1(lds_rsrc(e.sum_out, nd), o.so, sv);
             }
         } else {
-            if (e.y) *reinterpret_cast<float4 *>(e.y + (e.y_rm ? o.ro : o.so)) = v;
+            if (e.y) {
+                if (e.y_staged) {   // so with the row replaced by its table position
+                    const int lr = i / LP, j2 = i % LP, k0 = slice * S + 4 * j2;
+                    const size_t sy = o.so + (((size_t)o.rp - (size_t)(row0 + lr)) << lso);
+                    (void)k0;
+                    *reinterpret_cast<float4 *>(e.y + sy) = f4_scale(v, o.dr);
+                }
+                else *reinterpret_cast<float4 *>(e.y + (e.y_rm ? o.ro : o.so)) = v;
+            }
             if (e.sum_out) *reinterpret_cast<float4 *>(e.sum_out + (e.sum_rm ? o.ro : o.so)) = f4_scale(f4_plus(o.sumv, v), e.sum_scale);
         }
         if (e.adam) {
