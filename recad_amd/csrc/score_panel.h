@@ -793,7 +793,6 @@ __global__ __launch_bounds__(kPanNT, RB == 1 ? 4 : 2) void score_panel_kernel(co
                 int item = pbase + 16 * (w + 8 * i) + u;
                 item = item < a.n_items ? item : a.n_items - 1;
                 const float *brow = a.itabp + (size_t)item * dp + 4 * g;
-                const int col0 = 16 * (w + 8 * i) + 4 * g;
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
                     const int row = rb * 16 + u;
