@@ -668,7 +668,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float *src = nullptr;
-            if (g.acc_init) {
+            // (never in the PLAIN instantiation -- the launcher takes it only without acc_init: a POSSIBLE global load into the
+            //  accumulators makes the compiler drain every memory operation (s_waitcnt vmcnt(0)) in front of a tile's first MFMA --
+            //  the prefetch of the next chunk's operands and the stores of the tile before included: nothing overlapped, the
+            //  lock step of r05_gemm_stamps.txt)
+            if (!PLAIN && g.acc_init) {
                 const int m = min(mt + wr * 64 + i * 16 + l16, g.M - 1);
                 src = g.acc_init + (size_t)((m + g.a_roff) / g.a_rmod - g.init_base) * g.ld_init;
             }
@@ -779,7 +783,28 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                     }
                 }
             };
-            if (m0 + 128 <= g.M && n0 + 128 <= g.N) emit(std::false_type{});
+            // The iteration's tail -- barrier, the prefetched operands into LDS, barrier -- stands once per path on purpose: the
+            // operand loads were issued in front of this chunk's MFMAs and are OLDER than the tile's stores, so waiting for them
+            // is `s_waitcnt vmcnt(stores + younger loads)` -- which the compiler can only count where the number of stores behind
+            // the loads is known.  With one shared tail it merged "16 stores", "some stores" (partial tile) and "none" (chunk
+            // inside a tile) into vmcnt(15 .. 0): every finished tile's stores were drained before the next operands went to LDS.
+            if (PLAIN && m0 + 128 <= g.M && n0 + 128 <= g.N) {   // (the score-matrix instantiation: the others keep one tail and their register budget)
+                emit(std::false_type{});
+                m0 = m1; n0 = n1;
+                if (more) init_acc(m0, n0);
+                c = 0;
+                GEMM_STAMP(it, 4);
+                __syncthreads();
+                GEMM_STAMP(it, 5);
+                if (more) {
+                    wide_store<MA>(ta, sA);
+                    wide_store<MB>(tb, sB);
+                }
+                __syncthreads();
+                GEMM_STAMP(it, 6);
+                continue;
+            }
+            if (!PLAIN && m0 + 128 <= g.M && n0 + 128 <= g.N) emit(std::false_type{});
             else emit(std::true_type{});
             m0 = m1; n0 = n1;
             if (more) init_acc(m0, n0);
@@ -865,7 +890,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         const int Ni = fb == 1 && !strips ? g.N : g.N / 128 * 128;
         if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
             (!g.acc_init || g.a_rmod > 0) && !g.drop_thresh24) {
-            const bool plain_w = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask;
+            const bool plain_w = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask && !g.acc_init;
             const void *fn[3] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
                                  reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1, true>)};
             static RkPerDeviceOnce wide_attr;
