@@ -10,8 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RECAD_HIP_LIB: A/B runs against a variant build of the same ABI (tuning only)
-LIB_PATH = os.environ.get("RECAD_HIP_LIB") or os.path.join(_HERE, "lib", "librecad_hip.so")
+# The product reads no environment variable.  A/B work against a variant build of the same ABI (scripts/ only) calls
+# load(path) explicitly BEFORE anything else touches the library.
+LIB_PATH = os.path.join(_HERE, "lib", "librecad_hip.so")
 RK_LOSS_PARTIALS = 256
 RK_MAX_GRAPH_STEPS = 64
 ABI_VERSION = 9
@@ -172,6 +173,16 @@ _SIGNATURES = {
 }
 _RESTYPES = {"rk_last_error": C.c_char_p}
 EXPORTS = tuple(_SIGNATURES)
+
+
+def load(path):
+    """Tuning scripts only: bind a variant build of the same ABI (e.g. lib/librecad_hip_tuning.so, or its bare file name
+    under recad_amd/lib/) instead of the product library.  Must be called before the first lib(); the product never calls it."""
+    global _lib, LIB_PATH
+    if _lib is not None:
+        raise HipCallError(f"_lib.load({path!r}): {LIB_PATH} is already loaded")
+    LIB_PATH = path if os.path.isabs(path) or os.path.exists(path) else os.path.join(_HERE, "lib", path)
+    return lib()
 
 
 def lib():

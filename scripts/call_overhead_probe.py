@@ -3,6 +3,7 @@ span by events, completion detection.  usage: python scripts/call_overhead_probe
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 import bench
 from recad_amd import dataset, model, synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

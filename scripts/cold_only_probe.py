@@ -2,6 +2,7 @@
 (what the gather kernel would be left with if a dense bit-panel product covered those edges)."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import synth, _lib
 from recad_amd.graph import CsrGraph
 dev = torch.device('cuda:0')

@@ -2,6 +2,7 @@
 import cProfile, pstats, sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import dataset, model, synth
 from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts
 dev = torch.device('cuda:0')

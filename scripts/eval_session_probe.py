@@ -3,6 +3,7 @@ usage: rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 scripts/ev
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 import bench
 from recad_amd import dataset, model, synth
 from recad_amd.evaluate import EvalSession, eligible_users

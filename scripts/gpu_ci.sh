@@ -7,7 +7,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py 2>&1 | tail -1 > gpurun_out/bench_${tag}.json
 python bench.py --graph reference --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_${tag}_asis.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_${tag}_profiled.json 2>gpurun_out/prof_${tag}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --no-live-traffic --no-cpu-baseline > gpurun_out/bench_${tag}_profiled.json 2>gpurun_out/prof_${tag}.err
 f=$(ls gpurun_out/prof_${tag}/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${tag}_kernel_stats.csv; rm -rf gpurun_out/prof_${tag}
 python - <<PY
 import json

@@ -19,7 +19,7 @@ timeout 300 python bench.py --fuse-layers --no-cpu-baseline --no-also --no-topk 
 timeout 300 python bench.py --workload yelp --no-cpu-baseline 2>/dev/null | grep "^{" > $o/${tag}_bench_yelp_d128.json
 timeout 400 python bench.py --workload c4s --no-cpu-baseline 2>/dev/null | grep "^{" > $o/${tag}_bench_c4s.json
 timeout 600 python bench.py --workload config4 --no-cpu-baseline --eval-users 65536 2>/dev/null | grep "^{" > $o/${tag}_bench_config4.json
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_${tag} -- python3 bench.py --no-cpu-baseline --no-also > $o/${tag}_bench_profiled.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_${tag} -- python3 bench.py --no-live-traffic --no-cpu-baseline --no-also > $o/${tag}_bench_profiled.json 2>/dev/null
 f=$(ls $o/prof_${tag}/*/*kernel_stats.csv | head -1); cp $f $o/${tag}_bench_kernel_stats.csv; rm -rf $o/prof_${tag}
 # PMC traffic of spmm_lds_kernel: one counter per pass (MI355X_MICROARCH.md "HBM": FETCH_SIZE x2 on gfx950, WRITE_SIZE as is)
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do

@@ -19,4 +19,4 @@ for n in ("bench_fused_1", "bench_unfused_1", "bench_fused_2", "bench_unfused_2"
     except Exception as e:
         print(n, "missing", e)
 PY
-RECAD_HIP_LIB=$PWD/recad_amd/lib/librecad_hip_tuning.so RK_LDS_MSTAMPS=1 timeout 100 python scripts/lds_multi_stamps.py 2>&1 | grep -v amdgpu.ids | tail -12 > $o/${tag}_multi_stamps.txt; cat $o/${tag}_multi_stamps.txt
+RECAD_TUNING_LIB=$PWD/recad_amd/lib/librecad_hip_tuning.so RK_LDS_MSTAMPS=1 timeout 100 python scripts/lds_multi_stamps.py 2>&1 | grep -v amdgpu.ids | tail -12 > $o/${tag}_multi_stamps.txt; cat $o/${tag}_multi_stamps.txt

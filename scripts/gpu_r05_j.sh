@@ -2,7 +2,7 @@
 # round 5: whole-call replay as ONE graph (RK_NO_CHAIN=1, tuning build) against the chain of graphs, same box, alternating
 o=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export RECAD_HIP_LIB=$PWD/recad_amd/lib/librecad_hip_tuning.so
+export RECAD_TUNING_LIB=$PWD/recad_amd/lib/librecad_hip_tuning.so
 ( for i in 1 2 3; do
     echo "== chain (default)"; timeout 200 python scripts/call_overhead_probe.py 20 2>&1 | grep "^steps"
     echo "== one graph (RK_NO_CHAIN=1)"; RK_NO_CHAIN=1 timeout 200 python scripts/call_overhead_probe.py 20 2>&1 | grep "^steps"

@@ -7,6 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import dataset, model, synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ml1m"

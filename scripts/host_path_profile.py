@@ -3,6 +3,7 @@ usage: python scripts/host_path_profile.py"""
 import cProfile, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 import bench
 from recad_amd import dataset, model, synth
 dev = torch.device("cuda:0")

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib, model  # noqa: E402
 from tests import _golden as G  # noqa: E402
 from tests._stub import LGN_KEYS, ReplayDataset  # noqa: E402
@@ -32,7 +33,7 @@ def main():
         m = m.to(dev)
         t0 = time.perf_counter()
         if fuse and "--watch" in sys.argv:
-            # debug build (-DRK_LDS_DEBUG through RECAD_HIP_LIB): launch on a side stream, watch it from the host, dump the markers if it hangs
+            # debug build (-DRK_LDS_DEBUG through RECAD_TUNING_LIB): launch on a side stream, watch it from the host, dump the markers if it hangs
             m._ensure_handle()
             big = m._ws["lds_sync"]
             side = torch.cuda.Stream()

@@ -1,5 +1,5 @@
 """Where a phase of the multi-phase propagation launch spends its time (tuning build: make -C recad_amd/csrc tuning, or the
--DRK_TUNING objects; run with RECAD_HIP_LIB=.../librecad_hip_tuning.so RK_LDS_MSTAMPS=1): per (workgroup, item) wall-clock
+-DRK_TUNING objects; run with RECAD_TUNING_LIB=.../librecad_hip_tuning.so RK_LDS_MSTAMPS=1): per (workgroup, item) wall-clock
 stamps {ticket known, wait over, staged, gathered, rows done, stores drained} of ONE forward pass on the ml1m-shaped graph."""
 import sys
 
@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib, dataset, model, synth  # noqa: E402
 
 

@@ -8,6 +8,7 @@ the two halves, rows grouped by total degree ("deg") or by a k-d split over the 
     python3 scripts/lds_panel_pad_sim.py  ->  profiles/r04_lds_panel_pad_sim.txt"""
 import sys, numpy as np, time
 sys.path.insert(0, ".")
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import synth
 d = synth.make("yelp")
 rp, ci = d["train"][0], d["train"][1]

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import dataset, model, synth  # noqa: E402
 from recad_amd.evaluate import eligible_users, full_catalog_topk, hit_counts  # noqa: E402
 

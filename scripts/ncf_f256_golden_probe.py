@@ -4,6 +4,7 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import model  # noqa: E402
 from tests import _golden as G  # noqa: E402
 from tests._stub import PW_KEYS, ReplayDataset  # noqa: E402

@@ -1,5 +1,6 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import dataset, model
 from tests import _golden as G
 dev = torch.device('cuda:0')

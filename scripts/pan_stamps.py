@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 os.environ["RK_PAN_STAMPS"] = "1"
 from recad_amd import _lib
 from recad_amd.evaluate import score_plan

@@ -1,5 +1,5 @@
 """Host time of the LDS plan builder (rk_lds_plan_build_host) on the ml1m-shaped graph: the cost that sits on the perturb-retrain
-loop.  With the tuning build (RECAD_HIP_LIB=.../librecad_hip_tuning.so): RK_LDS_PLAN_THREADS=n, RK_LDS_PLAN_PIN=0|1.
+loop.  With the tuning build (RECAD_TUNING_LIB=.../librecad_hip_tuning.so): RK_LDS_PLAN_THREADS=n, RK_LDS_PLAN_PIN=0|1.
     python3 scripts/plan_build_probe.py [workload=ml1m] [dim=64]"""
 import ctypes as C
 import os
@@ -10,6 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib, synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ml1m"

@@ -1,6 +1,7 @@
 """Times the scoring GEMM + top-K selection kernels (rk_score_topk) on synthetic tables."""
 import ctypes as C, sys, torch, numpy as np
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib
 from recad_amd.evaluate import score_plan
 dev = torch.device('cuda:0')

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib
 
 nu, I, d = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((1, 5893), (2, 3702), (3, 64)))

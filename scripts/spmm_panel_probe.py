@@ -8,6 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import _lib, synth
 from recad_amd.graph import CsrGraph
 

@@ -9,6 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import dataset, synth
 from recad_amd.sharded import HipOps
 

@@ -1,6 +1,7 @@
 """SpMM launches of one workload for profiling (kernel-trace / PMC passes): scripts/spmm_sweep.py <graph> [workload] [dim] [reps]"""
 import sys, os, torch, numpy as np
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 from recad_amd import synth, dataset, model, _lib
 dev = torch.device('cuda:0')
 which = sys.argv[1]

@@ -2,6 +2,7 @@
 on ml1m-shaped data, LightGCN d=64, rec_epoch epochs per training."""
 import sys, time, torch
 sys.path.insert(0, '.')
+import _tune  # noqa: E402,F401  (binds RECAD_TUNING_LIB's variant build, if set, before the product library is loaded)
 import recad_amd
 from recad_amd import dataset, model, synth, workflow
 dev = torch.device('cuda:0')

@@ -59,6 +59,33 @@ def test_product_never_imports_oracle():
             head[head.rfind("\ndef "):].startswith("\ndef " + fn + "("), f"{f}: the oracle import must live inside {fn}()"
 
 
+def test_product_reads_no_environment_variable():
+    """paths and shapes are arguments.  No Python file of the package touches os.environ / os.getenv, and the C side's
+    only getenv sits behind -DRK_TUNING (csrc/host/layout.h: compiled out of the shipped library).  A variant build is bound
+    through the explicit _lib.load(path) (scripts/_tune.py), never through the environment."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "recad_amd")):
+        for f in files:
+            p = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                code = "\n".join(l.split("#", 1)[0] for l in open(p).read().split("\n"))
+                assert not re.search(r"\bos\.environ\b|\bgetenv\b|\benviron\b", code), f"{p} reads the environment"
+            elif f.endswith((".hip", ".h")):
+                src = open(p).read()
+                for m in re.finditer(r"\bgetenv\s*\(", src):
+                    head = src[: m.start()]
+                    assert head.rfind("#ifdef RK_TUNING") > head.rfind("#endif") or head.rfind("#if defined(RK_TUNING)") > head.rfind("#endif"), \
+                        f"{p}: getenv outside an RK_TUNING block"
+    assert _lib.LIB_PATH == os.path.join(ROOT, "recad_amd", "lib", "librecad_hip.so")
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "from recad_amd import _lib; print(_lib.LIB_PATH)"], cwd=ROOT, capture_output=True, text=True,
+                         env=dict(os.environ, RECAD_HIP_LIB="/nonexistent/x.so", RECAD_TUNING_LIB="/nonexistent/y.so"))
+    assert out.stdout.strip() == _lib.LIB_PATH, out
+    with pytest.raises(_lib.HipCallError):
+        _lib.lib()
+        _lib.load("librecad_hip_tuning.so")   # too late: the product library is bound
+
+
 # ------------------------------------------------------------------ lazy-init contract (SURVEY 8b)
 def test_lazy_init_contract():
     lazy = model.from_config("victim", "lightgcn", latent_dim_rec=32, not_a_key=1)
