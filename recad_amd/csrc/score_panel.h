@@ -39,13 +39,14 @@ typedef float sel_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned score_key(float s)
 {
-    // monotone float -> uint; 0 is reserved for "excluded" (seen item, encoded as -inf).  -0.0 is
-    // folded onto +0.0 so that key equality is float equality (the oracle compares floats).
-    if (s == -INFINITY) return 0u;
-    unsigned u = __float_as_uint(s);
-    if (u == 0x80000000u) u = 0u;
-    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return k == 0u ? 1u : k;
+    // monotone float -> uint, branch-free; 0 is reserved for "excluded" (a seen item, encoded as -inf).  s + 0.0f folds -0.0 onto
+    // +0.0 so that key equality is float equality (the oracle compares floats) and changes no other number.  NaN scores (a diverged
+    // poisoned retrain; the oracle's float compares give them no place at all): a NaN with the sign bit set is excluded like -inf,
+    // a positive NaN keeps a key above +inf's, a signalling NaN is quieted by the addition -- the SAME key in every kernel that
+    // ranks scores (topk_wave_kernel, topk_rows_kernel, the panel form's final sort): round 5 had two encoders that disagreed there.
+    const unsigned u = __float_as_uint(s + 0.0f);
+    const unsigned k = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+    return k <= 0x007fffffu ? 0u : k;   // k <= 0x007fffff: -inf (exactly 0x007fffff) or a negative NaN
 }
 
 __device__ __forceinline__ float key_score(unsigned k)

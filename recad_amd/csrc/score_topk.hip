@@ -375,15 +375,8 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
     }
     return v;
 }
-// score_key() without a branch: the same key for every finite score, +-0 and +inf; 0 ("excluded") for -inf like score_key --
-// and for a NaN with the sign bit set, which score_key ranks below every number (a NaN score has no meaningful place either
-// way; a positive NaN keeps its key above +inf in both).  s + 0.0f folds -0.0 onto +0.0 and changes nothing else that matters.
-__device__ __forceinline__ unsigned score_key_sel(float s, bool excluded)
-{
-    const unsigned u = __float_as_uint(s + 0.0f);
-    const unsigned k = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
-    return (excluded || k <= 0x007fffffu) ? 0u : k;   // k <= 0x007fffff: -inf (exactly 0x007fffff) or a negative NaN
-}
+// score_key() (score_panel.h: the ONE encoder of every selection kernel) with the seen bit folded in: 0 for an excluded item.
+__device__ __forceinline__ unsigned score_key_sel(float s, bool excluded) { return excluded ? 0u : score_key(s); }
 
 #ifndef TOPK_STAMP   // (scripts/topk_wave_probe.sh builds this kernel alone with per-phase cycle stamps)
 #define TOPK_STAMP(i) do { } while (0)
@@ -418,8 +411,11 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
     auto sel_put = [&](int slot, unsigned not_id, unsigned k) { sel32[2 * slot] = not_id; sel32[2 * slot + hi] = k; };
 
     const float *grow = scores + (size_t)b * (size_t)ld;
-    // the row through a buffer descriptor of exactly its bytes: ONE address register for all NQ loads (4 * lane; 256 q goes into the
-    // instruction's offset field / a scalar), and lanes past the row's end read 0 instead of faulting (those positions are excluded)
+    // the row through a buffer descriptor of exactly its bytes: lanes past the row's end read 0 instead of faulting (those positions
+    // are excluded).  The whole displacement 4 * lane + 256 q is the VECTOR offset (the compiler keeps what fits -- 4 095 -- in the
+    // instruction's offset field and bumps the address register every 16 loads): the range check of a raw buffer covers vector
+    // offset + instruction offset and NOT the scalar offset, where the 256 q used to go -- rows then read up to NQ * 256 bytes whatever
+    // their length, the last row of a matrix that ends on a mapping boundary past its allocation (round-5 review)
     const unsigned long long gaddr = reinterpret_cast<unsigned long long>(grow);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gaddr >> 32)) << 32) |
@@ -427,7 +423,7 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
         (short)0, n_items * 4, 0x00020000);
     float v[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, q * 256, 0));
+    for (int q = 0; q < NQ; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + q * 256, 0, 0));
     TOPK_STAMP(1);
     // the seen list hangs off two dependent (scalar) loads; the row is already in flight
     const int u = user_ids[b];
@@ -463,7 +459,7 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
         // ---- target ranks:  #(s > st) + #(s == st and id < target), the target itself and excluded items not counted.
         for (int t = 0; t < n_targets; ++t) {
             const int tg = t == 0 ? tg0 : targets[t];
-            const unsigned kt = score_key(t == 0 ? ts0 : grow[tg]);
+            const unsigned kt = score_key_sel(t == 0 ? ts0 : grow[tg], false);   // (the row's own encoder: one key per score in this kernel)
             // per-lane counters (compare + add-with-carry), one wave sum of both at the end: counting ballots on the scalar side kept
             // 2 NQ mask registers alive (the sums are re-associated) and spilled
             int c_gt = 0, c_eq = 0;
@@ -623,7 +619,7 @@ extern "C" int rk_topk_rows_impl(float *scores, long long ld, int nb, int n_item
         RK_FAIL(RK_EINVAL, "top-K: bad targets");
     if (ld < n_items) RK_FAIL(RK_EINVAL, "top-K: row stride %lld < n_items %d", ld, n_items);
     // short rows (ml1m 3 702, Amazon-game 5 600 items): one wave per row, the row in registers.  Measured on 5 893 x 3 702
-    // (the headline evaluation): XX us against 50.5 us for the row-per-workgroup kernel below.
+    // (the headline evaluation): 37.9-39.6 us against 52.4 us for the row-per-workgroup kernel below (profiles/r05b_topk_ab.txt).
     static const int no_wave = RK_TUNE_INT("RK_TOPK_NO_WAVE", 0);   // A/B only
     if (!no_wave && n_items <= 96 * 64) {
         const int nq = (n_items + 63) / 64;

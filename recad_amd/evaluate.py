@@ -133,7 +133,9 @@ class EvalSession:
             raise TypeError("EvalSession: the victim scores through score_matrix() right now (logit dropout active); use full_catalog_topk")
         # victims whose tables are plain parameter views (MF: scoring_tables_static) are asked once -- their scoring_tables() reads
         # a scalar back, which a stream capture does not allow; LightGCN's launches the propagation and is called per run
-        self._static_tabs = tabs if getattr(victim, "scoring_tables_static", False) else None
+        self._static = bool(getattr(victim, "scoring_tables_static", False))
+        self._static_tabs = tabs if self._static else None
+        self._static_key = self._tables_key()
         utab, itab = tabs[0], tabs[1]
         dev = itab.device
         self.dev = dev
@@ -164,6 +166,28 @@ class EvalSession:
         self.want_graph = bool(graph) and not getattr(victim, "fuse_layers", False)
         self._graph, self._graph_key, self._runs = None, None, 0
 
+    def _tables_key(self):
+        """Static victims (MF): what the cached tables -- and a captured graph's pointers and baked `mean` -- depend on
+        (victim.scoring_tables_key(): storages, shapes, `mean`'s version, dropout state; no device read)."""
+        if not self._static:
+            return None
+        fn = getattr(self.victim, "scoring_tables_key", None)
+        return fn() if fn is not None else tuple((t.data_ptr(), tuple(t.shape)) for t in self._static_tabs[:4] if t is not None)
+
+    def _refresh_static(self):
+        """Called by run() in front of every launch / replay: re-query a static victim's tables when their key moved."""
+        if not self._static:
+            return
+        key = self._tables_key()
+        if key != self._static_key:
+            tabs = self.victim.scoring_tables()
+            if tabs is None:
+                raise RuntimeError("EvalSession: the victim scores through score_matrix() now (logit dropout active); use full_catalog_topk")
+            if tuple(tabs[1].shape) != (self.plan.n_items, self.plan.dim):
+                raise RuntimeError("EvalSession: the victim's item table changed shape; build a new session")
+            self._static_tabs, self._static_key = tabs, key
+            self._graph, self._graph_key = None, None     # the captured pointers / mean are stale: direct launches, re-capture
+
     def _launch(self):
         v, L, plan = self.victim, _lib.lib(), self.plan
         utab, itab, ubias, ibias, mean = self._static_tabs if self._static_tabs is not None else v.scoring_tables()   # (LightGCN: the propagation's launches)
@@ -186,7 +210,8 @@ class EvalSession:
         """-> dict of device tensors (top_ids [n, K], top_scores, target_score [n, T], target_rank, hit_counts [T, len(topks)]);
         no synchronisation."""
         self._runs += 1
-        key = getattr(self.victim, "_handle_key", None)
+        self._refresh_static()
+        key = (getattr(self.victim, "_handle_key", None), self._static_key)
         if self.want_graph and self._graph is not None and self._graph_key == key:
             self._graph.replay()
         else:
@@ -199,7 +224,7 @@ class EvalSession:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._launch()
-                    self._graph, self._graph_key = g, getattr(self.victim, "_handle_key", None)
+                    self._graph, self._graph_key = g, (getattr(self.victim, "_handle_key", None), self._static_key)
                     self._graph.replay()     # (the capture itself ran nothing: results must come from an execution)
                 except Exception as exc:    # noqa: BLE001
                     import warnings

@@ -161,6 +161,15 @@ class MF(BaseVictim):
         ue, ie, ub, ib = self._tables()
         return ue.data, ie.data, ub.data.reshape(-1), ib.data.reshape(-1), float(self.mean.item())
 
+    def scoring_tables_key(self):
+        """What a cached scoring_tables() answer depends on, without a device read: storage and shape of the four tables, the
+        storage and in-place version of `mean`, and whether a logit dropout is active.  evaluate.EvalSession compares it on every
+        run(): re-homed parameters (.to(), load_state_dict into new tensors) or a dropout switched on must not replay a graph that
+        holds the old pointers."""
+        ue, ie, ub, ib = self._tables()
+        return (tuple((t.data_ptr(), tuple(t.shape)) for t in (ue, ie, ub, ib)), self.mean.data_ptr(), self.mean._version,
+                bool(self.drop_p > 0.0 and self.training))
+
     def input_describe(self):
         return {
             "train_step": {

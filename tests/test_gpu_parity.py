@@ -528,6 +528,24 @@ def test_eval_session_matches_full_catalog_topk(gpu_device):
                 assert torch.equal(got[k], ref[k]), (name, use_lds, round_, k)
             assert torch.equal(got["hit_counts"], ref_hits), (name, use_lds, round_)
         assert sess._graph is not None, "the second run must have captured the evaluation"
+        if name == "mf":
+            # round-5 review: MF has no _handle_key; the session cached its tables and baked `mean` into the captured arguments.
+            # Re-homed parameters (new storage, new values) and a changed mean must be picked up, not replayed stale.
+            with torch.no_grad():
+                for p_ in v.parameters():
+                    p_.data = (p_.data * 1.5 + 0.01).clone()
+                v.mean.add_(0.25)     # (in place under no_grad, like load_state_dict's copy_: bumps the version the key holds)
+            for round_ in range(3):
+                got = {k: t.clone() for k, t in sess.run().items()}
+                ref = full_catalog_topk(v, users, ptr, idx, targets, K=100, chunk=max(64, len(users) // 3), to_host=False)
+                for k in ("top_ids", "top_scores", "target_score", "target_rank"):
+                    assert torch.equal(got[k], ref[k]), ("mf re-homed", round_, k)
+            assert sess._graph is not None
+            v.drop_p = 0.5
+            v.train()
+            with pytest.raises(RuntimeError):
+                sess.run()
+            v.drop_p = 0.0
 
 
 def test_defense_workflow_on_device(gpu_device):
@@ -1639,8 +1657,8 @@ def test_ncf_large_batch_wide_gemm_forms(gpu_device):
         assert G.relerr(got.cpu().numpy(), ref.reshape(got.shape)) < 5e-5
 
 
-def _topk_rows_vs_oracle(dev, scores, seen, K, targets):
-    """rk_topk_rows through the C-ABI against orc.topk_row, row by row, bit-exact."""
+def _topk_rows_run(dev, scores, seen, K, targets):
+    """rk_topk_rows through the C-ABI on a score matrix of EXACTLY nb x I floats (no slack behind the last row)."""
     from recad_amd import _lib
     nb, I = scores.shape
     n_targets = len(targets)
@@ -1657,7 +1675,13 @@ def _topk_rows_vs_oracle(dev, scores, seen, K, targets):
                                        _lib.ptr(top_sc), _lib.ptr(tg), n_targets, _lib.ptr(ts_), _lib.ptr(tr), _lib.stream_ptr()),
                "rk_topk_rows")
     torch.cuda.synchronize()
-    top_ids, top_sc, ts_, tr = top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts_.cpu().numpy(), tr.cpu().numpy()
+    return top_ids.cpu().numpy(), top_sc.cpu().numpy(), ts_.cpu().numpy(), tr.cpu().numpy()
+
+
+def _topk_rows_vs_oracle(dev, scores, seen, K, targets):
+    """rk_topk_rows through the C-ABI against orc.topk_row, row by row, bit-exact."""
+    nb, n_targets = scores.shape[0], len(targets)
+    top_ids, top_sc, ts_, tr = _topk_rows_run(dev, scores, seen, K, targets)
     for b in range(nb):
         rid, rsc, rts, rtr = orc.topk_row(scores[b], seen[b], K, targets)
         assert np.array_equal(top_ids[b], rid), (b, top_ids[b][:8], rid[:8])
@@ -1677,12 +1701,55 @@ def test_topk_rows_K_and_targets(gpu_device, K, n_targets):
     _topk_rows_vs_oracle(gpu_device, scores, seen, K, targets)
 
 
-@pytest.mark.parametrize("I", [50, 3702, 12000])
+def test_topk_rows_last_row_ends_on_its_allocation(gpu_device):
+    """Round-5 review: topk_wave_kernel's row loads carried their per-q displacement in the scalar offset, which a raw buffer does
+    not range-check: a row of I < NQ * 64 items read past its end, the last row past the matrix.  The displacement is the vector
+    offset now.  Here: matrices of exactly nb x I floats allocated at the END of a 2 MiB-granular block (I = 3 072 + 128 ... rounds
+    NQ up to 58 / 64 / 80 ...: 500-1 500 floats of overhang per row before the fix), rows checked against the oracle -- the values
+    behind a row's end must not matter, wherever the allocation ends."""
+    rng = np.random.default_rng(11)
+    for I in (3137, 3200, 4160, 5700):
+        nb = max(1, (2 << 20) // (4 * I))
+        scores = rng.standard_normal((nb, I), dtype=np.float32)
+        seen = [np.sort(rng.choice(I, size=int(rng.integers(0, 40)), replace=False)).astype(np.int32) for _ in range(nb)]
+        _topk_rows_vs_oracle(gpu_device, scores, seen, 100, np.array([0, I - 1], dtype=np.int32))
+
+
+def test_topk_rows_nan_scores_same_in_both_kernels(gpu_device):
+    """NaN scores (a diverged poisoned retrain): the oracle's float compares give a NaN no place, so the lists are not compared
+    with it -- but every selection kernel ranks them through ONE encoder (score_panel.h score_key: negative NaN = excluded,
+    positive NaN above +inf, signalling NaNs quieted).  The same rows go through topk_wave_kernel (I = 3702) and, padded with
+    seen items to I = 8000, through topk_rows_kernel<LDS_ROW>: identical ids, target ranks and score bits."""
+    rng = np.random.default_rng(5)
+    nb, I, I2, K = 16, 3702, 8000, 100
+    scores = rng.standard_normal((nb, I), dtype=np.float32)
+    bits = scores.view(np.uint32)
+    for b in range(nb):
+        pos = rng.choice(I, size=12, replace=False)
+        bits[b, pos[:4]] = 0x7fc00001 + np.arange(4, dtype=np.uint32)      # quiet positive NaNs (distinct payloads)
+        bits[b, pos[4:8]] = 0xffc00000 + np.arange(4, dtype=np.uint32)     # negative NaNs
+        bits[b, pos[8:10]] = 0x7f800001 + np.arange(2, dtype=np.uint32)    # signalling NaNs
+        scores[b, pos[10]] = np.inf
+        scores[b, pos[11]] = -np.inf
+    seen = [np.sort(rng.choice(I, size=int(rng.integers(0, 40)), replace=False)).astype(np.int32) for _ in range(nb)]
+    targets = np.array([3, I - 1, I // 2], dtype=np.int32)
+    a = _topk_rows_run(gpu_device, scores, seen, K, targets)
+    wide = np.concatenate([scores, rng.standard_normal((nb, I2 - I), dtype=np.float32) + 100.0], axis=1)
+    seen2 = [np.concatenate([s_, np.arange(I, I2, dtype=np.int32)]) for s_ in seen]
+    b_ = _topk_rows_run(gpu_device, wide, seen2, K, targets)
+    assert np.array_equal(a[0], b_[0]), "ids differ between the wave and the row-in-LDS kernel on NaN rows"
+    assert np.array_equal(a[1].view(np.uint32), b_[1].view(np.uint32))
+    assert np.array_equal(a[3], b_[3])
+    assert (a[0][:, :6] >= 0).all()    # 4 positive + 2 (quieted) signalling NaNs lead every list: their keys lie above +inf's
+
+
+@pytest.mark.parametrize("I", [50, 3702, 8000, 12000])
 @pytest.mark.parametrize("kind", ["const", "two_values", "tiny_spread", "signed_zero", "quantised", "mostly_seen"])
 def test_topk_rows_tie_heavy_rows(gpu_device, kind, I):
     """Rows whose candidates do not fit the first radix bin: constant rows (an untrained MF victim scores
     every item `mean`), a handful of distinct values, a spread of a few ulps, +-0, and rows with fewer
-    than K unseen items.  I = 12000 (48 KB rows) takes the row-in-L2 form of the kernel, the others the row-in-LDS form."""
+    than K unseen items.  I = 50 and 3702 take topk_wave_kernel (one wave per row, <= 6144 items), I = 8000 (32 KB rows) the
+    row-in-LDS form of topk_rows_kernel, I = 12000 (48 KB rows) its row-in-L2 form."""
     rng = np.random.default_rng(I)
     nb, K = 12, 100
     if kind == "const":
