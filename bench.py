@@ -169,7 +169,7 @@ def dry_run_worker(args, rank, world):
         out = {"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "parallel": args.parallel, "workload": args.workload,
                "metric": metric_for(args), "steps": args.steps, "warmup": args.warmup,
                "scaling": "strong" if (args.parallel in ("rows", "rows2d") and (world > 1 or args.force_collectives)) else "weak",
-               "also_sharded_legs": (["config4_rows2d", "config3_yelp_rows2d"] if (world > 1 and args.parallel == "replicas" and not args.no_also_sharded) else [])}
+               "also_sharded_legs": (also_sharded_leg_names(args.no_also_config4) if (world > 1 and args.parallel == "replicas" and not args.no_also_sharded) else [])}
         if args.workload not in ("c4s", "config4"):
             from recad_amd import synth
             d = synth.make(args.workload)
@@ -280,7 +280,7 @@ def cpu_baseline_aten(d, graph, dim, layers, batch, triplets, budget_s=12.0):
                            f"pair scores of the unseen items, sort, top-100), same {r['threads']} threads, {r['eval_seconds']:.1f} s"}
 
 
-def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0):
+def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0, parity_steps=0):
     """A short measurement of ANOTHER BASELINE.json config next to the headline one, so that the driver's record carries it:
     ms/step through the same reserve() -> epoch-call path, the SpMM's per-launch time and roofline (with the no-reuse gather
     figure as `effective`), and one full evaluation.  Config 3 = yelp-shaped d = 128; config 4 = 1M x 500K x 100M edges d = 64."""
@@ -304,8 +304,9 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
     N, nnz = g.n_rows, g.nnz
     ep = ds.generate_epoch()
     trip = tuple(ep[k][: (steps + warmup) * B].contiguous() for k in ("users", "positive_items", "negative_items"))
+    init_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (v.embedding_user.weight, v.embedding_item.weight)) if parity_steps else None
     v.reserve(max(steps, warmup) * B, B)
-    run_steps(v, trip, B, 0, warmup)
+    warm_losses = run_steps(v, trip, B, 0, warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     part = run_steps(v, trip, B, warmup, steps)
@@ -341,6 +342,32 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
     hits = hit_counts(res["target_rank"], (10, 20, 50, 100))
     torch.cuda.synchronize()
     ev = time.perf_counter() - t1
+    parity = None
+    if parity_steps:
+        # the large-shape train step next to the oracle in the driver's own record (round-5 review): the first `parity_steps` steps
+        # of this leg's triplets from this leg's initial tables -- losses from the run above (its warm-up call), tables through a second
+        # victim run through the same reserve() -> whole-call hipGraph sequence for exactly those steps (the run's own tables are
+        # `steps + warmup` steps old; the oracle needs ~2 s per step at this shape)
+        n_par = min(int(parity_steps), warmup)
+        torch.manual_seed(2023)
+        v2 = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=layers).I(dataset=ds).to(dev)
+        v2.embedding_user.weight.data.copy_(torch.from_numpy(init_tables[0]))
+        v2.embedding_item.weight.data.copy_(torch.from_numpy(init_tables[1]))
+        v2.reserve(n_par * B, B)
+        l2 = run_steps(v2, trip, B, 0, n_par).sum(dim=1).double().cpu().numpy()
+        run_losses = warm_losses.sum(dim=1).double().cpu().numpy()[:n_par]
+        tabs2 = tuple(p_.detach().cpu().numpy().copy() for p_ in (v2.embedding_user.weight, v2.embedding_item.weight))
+        rb = v2._ws.get("row_blocks")
+        used_list = int(rb[0].item()) if rb is not None else None
+        del v2
+        rep = oracle_replay(d, "train", layers, B, tuple(t[: n_par * B].cpu().numpy() for t in trip), init_tables[0], init_tables[1], n_par)
+        parity = parity_object(rep, run_losses, tabs2, f"a second victim from the same initial tables through the same call sequence ({n_par} steps)")
+        parity["second_victim_max_rel_loss_diff"] = float(np.abs(l2 - run_losses).max() / np.abs(run_losses).max())
+        parity["ok"] = bool(parity["ok"] and parity["second_victim_max_rel_loss_diff"] <= 1e-5)
+        parity["spmm"] = "lds" if lds else "csr"
+        parity["marked_block_list_count"] = used_list      # > 0: the row-filtered last forward layer ran from the list
+        parity["frontier_filter"] = bool(v._ws.get("row_bits") is not None)
+        parity["oracle_seconds"] = rep["seconds"]
     return {"workload": f"LightGCN victim, {workload}-shaped synthetic {ds.n_users}x{ds.n_items}, {ds.traindataSize} train edges (nnz {nnz}), "
                         f"dim={dim}, layers={layers}, batch={B}",
             "value": steps * B / el, "unit": "interactions/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
@@ -356,6 +383,7 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
             "topk": {"eligible_users": int(len(users)), "seconds": ev, "value": len(users) / ev, "unit": "users/s",
                      "hr@50": float(hits[0, 2].item()) / max(len(users), 1),
                      "gemm_tflops_e2e": 2.0 * len(users) * ds.n_items * dim / ev / 1e12},
+            "parity": parity,
             "seconds_total": time.perf_counter() - t_all}
 
 
@@ -584,35 +612,41 @@ def live_traffic_probe(args, timeout_s=150):
             "detail": {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "dispatches": vals["FETCH_SIZE"][1], "seconds": time.perf_counter() - t0}}
 
 
-def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, with_eval=True, with_replicas=True):
-    """ONE LightGCN training job whose node rows are dealt over the process group's ranks (recad_amd/sharded.py: 1-D row
-    partition with all-gathers; recad_amd/sharded2d.py: Pr x Pc tiling / column slabs with reduce-scatters), timed like the
-    headline (warm-up, barrier + synchronize, K steps, barrier + synchronize, MAX over ranks) -- plus ITS OWN denominators on
-    the same workload: the fused single-GPU step on rank 0 (`same_workload_1gpu`) and N independent replicas
-    (`same_workload_replicas`), the receive-bytes model, the user-sharded evaluation and `ranks_seen`.
-    Every rank calls it; rank 0 gets the dict."""
+# The A/B the first hardware SCALE run has to decide by itself (round-5 review, next #5): config 4 as ONE job over the N GPUs in the
+# three exchange forms this repository holds, each with 1 and 4 row chunks (chunk c's collective runs under chunk c + 1's SpMM).
+SHARDED_VARIANTS = (
+    # name suffix,            parallel, reduce,       gather,        chunks
+    ("collective_c1", "rows2d", "collective", "collective", 1),    # column slabs; reduce_scatter_tensor (RCCL picks the algorithm)
+    ("collective_c4", "rows2d", "collective", "collective", 4),
+    ("ordered_c1", "rows2d", "ordered", "collective", 1),          # column slabs; direct all-to-all + sum in group-rank order (one shot on the mesh)
+    ("ordered_c4", "rows2d", "ordered", "collective", 4),
+    ("rows_direct_c1", "rows", "collective", "direct", 1),         # 1-D rows; one batched group of W-1 sends / receives per rank (one-shot all-gather)
+    ("rows_direct_c4", "rows", "collective", "direct", 4),
+)
+
+
+def also_sharded_leg_names(no_config4=False):
+    """The `also` legs of an N > 1 default run, in the order they run (--dry-run lists them; tests/test_sharded_gloo.py asserts them)."""
+    names = [] if no_config4 else ["config4_rows2d"] + [f"config4_{v[0]}" for v in SHARDED_VARIANTS]
+    return names + ["config3_yelp_rows2d"]
+
+
+def sharded_context(args, dev, rank, world, workload, dim, steps, warmup):
+    """What every sharded variant of one workload shares: the synthetic graph (generated by every rank from the same seed and
+    cross-checked), the victim whose initial tables every variant starts from, the resident triplets (broadcast from rank 0)."""
     import torch
     import torch.distributed as dist
     from recad_amd import model
 
     collectives = world > 1 or args.force_collectives
     B = args.batch
-    t_leg = time.perf_counter()
     d, ds = load_workload(workload, dev, args.graph, B, 1234)
     torch.manual_seed(2023)
     victim = model.from_config("victim", "lightgcn", latent_dim_rec=dim, lightGCN_n_layers=args.layers,
                                deterministic=bool(args.deterministic)).I(dataset=ds).to(dev)
     victim.graph_steps = args.graph_steps
     g = ds.graph_csr()
-    N, nnz = g.n_rows, g.nnz
     users, pos, neg = resident_triplets(ds, (steps + warmup) * B)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if collectives:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # every rank must see the same triplets and start from the same tables
     if collectives:
         for t in (users, pos, neg):
@@ -626,43 +660,26 @@ def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, 
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not bool(torch.equal(lo, hi)):
             raise RuntimeError("the ranks generated different graphs (synthetic workload not reproducible across ranks)")
-    if parallel == "rows2d":
-        from recad_amd.sharded2d import Grid2DLightGCN
-        sharded = Grid2DLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, victim.embedding_user.weight,
-                                 victim.embedding_item.weight, device=dev, grid_rows=args.grid_rows or None, reduce=args.reduce,
-                                 deterministic=bool(args.deterministic), force_collectives=args.force_collectives)
-    else:
-        from recad_amd.sharded import ShardedLightGCN
-        sharded = ShardedLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, victim.embedding_user.weight,
-                                  victim.embedding_item.weight, device=dev, gather=args.gather,
-                                  force_collectives=args.force_collectives, deterministic=bool(args.deterministic))
-    sharded.reserve(max(steps, warmup) * B, B)
+    # the tables every variant starts from (the victim itself is trained by the denominators' runs, on rank 0 more than elsewhere)
+    init = tuple(p_.detach().clone() for p_ in (victim.embedding_user.weight, victim.embedding_item.weight))
+    return {"workload": workload, "dim": dim, "d": d, "ds": ds, "victim": victim, "g": g, "triplets": (users, pos, neg), "init": init,
+            "collectives": collectives, "same_1gpu": None, "replicas": None}
 
-    def run(lo, n_steps):
-        sl = slice(lo * B, (lo + n_steps) * B)
-        return sharded.train_epoch(users[sl], pos[sl], neg[sl], B)
 
-    if warmup > 0:
-        run(0, warmup)
-    barrier()
-    t0 = time.perf_counter()
-    losses = run(warmup, steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if collectives:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    last_loss = float(losses[-1])
-    assert np.isfinite(last_loss), "training diverged"
+def sharded_denominators(args, dev, rank, world, ctx, steps, warmup, with_replicas=True):
+    """A sharded job's OWN denominators on the same workload, measured once per workload: the fused single-GPU step on rank 0
+    (`same_workload_1gpu`) and N independent replicas (`same_workload_replicas`)."""
+    import torch
+    import torch.distributed as dist
+    victim, (users, pos, neg), B, collectives = ctx["victim"], ctx["triplets"], args.batch, ctx["collectives"]
 
-    ev = None
-    if with_eval:
-        ptr, idx = ds.train_csr_sorted()
-        ev = sharded.evaluate(ptr, idx, np.array([0], dtype=np.int32), K=100, topks=(10, 20, 50, 100), reps=2)
+    def barrier():
+        torch.cuda.synchronize()
+        if collectives:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     # like-for-like single-GPU reference on rank 0 (the others wait), then the same workload as N independent replicas
-    same_1gpu = replicas_same = None
     if rank == 0:
         victim.reserve(max(steps, warmup) * B, B)
         s1 = min(steps, 10)
@@ -673,9 +690,9 @@ def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, 
         victim._run_epoch(users[: s1 * B], pos[: s1 * B], neg[: s1 * B], B)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
-        same_1gpu = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
-                     "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait: "
-                             "the denominator of this leg's strong scaling"}
+        ctx["same_1gpu"] = {"value": s1 * B / e1, "unit": "interactions/s", "ms_per_step": e1 / s1 * 1e3, "steps": s1,
+                            "note": "the single-GPU fused path (hipGraph) on the same workload, timed on rank 0 while the other ranks wait: "
+                                    "the denominator of this workload's strong-scaling legs"}
     barrier()
     if world > 1 and with_replicas:
         # what the node delivers when the perturb-retrain loop is parallelised over jobs instead of inside one -- the comparison
@@ -690,32 +707,126 @@ def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, 
         barrier()
         tr_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
-        replicas_same = {"value": world * sr * B / float(tr_.item()), "unit": "interactions/s", "ms_per_step": float(tr_.item()) / sr * 1e3,
-                         "steps": sr, "note": f"{world} independent victims (one per GPU, fused single-GPU path) on this workload, all at once"}
+        ctx["replicas"] = {"value": world * sr * B / float(tr_.item()), "unit": "interactions/s", "ms_per_step": float(tr_.item()) / sr * 1e3,
+                           "steps": sr, "note": f"{world} independent victims (one per GPU, fused single-GPU path) on this workload, all at once"}
+
+
+def sharded_variant(args, dev, rank, world, ctx, parallel, steps, warmup, reduce=None, gather=None, chunks=None, with_eval=True,
+                    with_exposed=True):
+    """ONE LightGCN training job whose node rows are dealt over the process group's ranks (recad_amd/sharded.py: 1-D row
+    partition with all-gathers; recad_amd/sharded2d.py: Pr x Pc tiling / column slabs with reduce-scatters), timed like the
+    headline (warm-up, barrier + synchronize, K steps, barrier + synchronize, MAX over ranks), in ONE exchange form
+    (`reduce`, `gather`, `chunks`; None = the trainer's default) -- plus the exposed-communication share: the same rank's step
+    with every collective replaced by a copy of its own share (Grid2DLightGCN probe_rank_world: what the rank computes and
+    launches), so step - compute_only is what the chunk pipeline failed to hide.  Every rank calls it; rank 0 gets the dict."""
+    import torch
+    import torch.distributed as dist
+
+    collectives, B = ctx["collectives"], args.batch
+    ds, g, victim, dim = ctx["ds"], ctx["g"], ctx["victim"], ctx["dim"]
+    users, pos, neg = ctx["triplets"]
+    N, nnz = g.n_rows, g.nnz
+    reduce = reduce or args.reduce
+    gather = gather or args.gather
+    t_leg = time.perf_counter()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if collectives:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def make(probe=None):
+        if parallel == "rows2d":
+            from recad_amd.sharded2d import Grid2DLightGCN
+            return Grid2DLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, ctx["init"][0],
+                                  ctx["init"][1], device=dev, grid_rows=args.grid_rows or None, reduce=reduce,
+                                  deterministic=bool(args.deterministic), force_collectives=args.force_collectives and probe is None,
+                                  chunks=chunks, probe_rank_world=probe)
+        from recad_amd.sharded import ShardedLightGCN
+        return ShardedLightGCN(ds.n_users, ds.n_items, dim, args.layers, g, ctx["init"][0],
+                               ctx["init"][1], device=dev, gather=gather, chunks=chunks,
+                               force_collectives=args.force_collectives, deterministic=bool(args.deterministic))
+
+    def timed(tr):
+        tr.reserve(max(steps, warmup) * B, B)
+
+        def run(lo, n_steps):
+            sl = slice(lo * B, (lo + n_steps) * B)
+            return tr.train_epoch(users[sl], pos[sl], neg[sl], B)
+        if warmup > 0:
+            run(0, warmup)
+        barrier()
+        t0 = time.perf_counter()
+        losses = run(warmup, steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if collectives:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, float(losses[-1])
+
+    sharded = make()
+    elapsed, last_loss = timed(sharded)
+    assert np.isfinite(last_loss), "training diverged"
+    ev = None
+    if with_eval:
+        ptr, idx = ds.train_csr_sorted()
+        ev = sharded.evaluate(ptr, idx, np.array([0], dtype=np.int32), K=100, topks=(10, 20, 50, 100), reps=2)
+    describe, captured = sharded.describe(), bool(getattr(sharded, "_graph", None) is not None)
+    lay = getattr(sharded, "layout", None)
+    grid = (lay.Pr, lay.Pc) if parallel == "rows2d" else None
+    n_chunks = int(getattr(lay, "C", 0)) or None
+    del sharded
+    torch.cuda.empty_cache()
+    exposed = None
+    if with_exposed and parallel == "rows2d" and world > 1:
+        # the same rank's share of the same job without a process group: every collective is a local copy of this rank's own block
+        probe = make(probe=(rank, world))
+        el_p, _ = timed(probe)       # (MAX over ranks like the step itself: the slowest rank's compute)
+        del probe
+        torch.cuda.empty_cache()
+        exposed = {"compute_only_ms_per_step": el_p / steps * 1e3, "exposed_comm_ms_per_step": (elapsed - el_p) / steps * 1e3,
+                   "exposed_comm_share": max(0.0, (elapsed - el_p) / elapsed),
+                   "note": "compute_only = this job's step on every rank with each collective replaced by a copy of the rank's own share "
+                           "(Grid2DLightGCN probe_rank_world), slowest rank; exposed = step - compute_only: the communication the chunk "
+                           "pipeline did not hide"}
     seen = ranks_seen(dev, world, collectives)
     out = None
     if rank == 0:
         # the arithmetic the rows modes live under: bytes a rank must RECEIVE per propagation layer over its xGMI links
         # (7 links x ~77 GB/s one direction on MI355X) against the local SpMM time a layer needs
         blk = (N + world - 1) // world * dim * 4
-        if parallel == "rows2d":
-            recv = (sharded.layout.Pr - 1 + sharded.layout.Pc - 1) * blk
-        else:
-            recv = (world - 1) * blk
+        recv = (grid[0] - 1 + grid[1] - 1) * blk if parallel == "rows2d" else (world - 1) * blk
         comm_model = {"bytes_received_per_rank_and_layer": recv, "xgmi_in_GBps_assumed": 7 * 76.5,
                       "receive_floor_us_per_layer": recv / (7 * 76.5e3) if world > 1 else 0.0,
                       "layers_with_exchange_per_step": 2 * args.layers - 1,
                       "note": "a layer cannot finish before its inputs have arrived: when receive_floor_us_per_layer exceeds the local SpMM "
                               "time (same_workload_1gpu's step / (2 L) / N), the mode is communication-bound at this N"}
-        out = {"workload": workload_string(workload, ds.n_users, ds.n_items, ds.traindataSize, args.graph, nnz, dim, args.layers, B),
-               "mode": parallel, "parallelism": sharded.describe(), "backend": (dist.get_backend() if collectives else None),
+        out = {"workload": workload_string(ctx["workload"], ds.n_users, ds.n_items, ds.traindataSize, args.graph, nnz, dim, args.layers, B),
+               "mode": parallel, "exchange": {"reduce": reduce if parallel == "rows2d" else None, "gather": gather if parallel == "rows" else None,
+                                              "chunks": n_chunks, "chunks_requested": chunks},
+               "parallelism": describe, "backend": (dist.get_backend() if collectives else None),
                "scaling": "strong", "value": steps * B / elapsed, "unit": "interactions/s", "ms_per_step": elapsed / steps * 1e3,
                "steps": steps, "warmup": warmup, "n_gpus": world, "ranks_seen": seen, "last_step_loss": last_loss,
-               "step_captured": bool(getattr(sharded, "_graph", None) is not None),
-               "same_workload_1gpu": same_1gpu, "same_workload_replicas": replicas_same, "rows_comm_model": comm_model, "topk": ev,
+               "step_captured": captured, "exposed_communication": exposed,
+               "same_workload_1gpu": dict(ctx["same_1gpu"]) if ctx["same_1gpu"] else None,
+               "same_workload_replicas": ctx["replicas"], "rows_comm_model": comm_model, "topk": ev,
                "seconds_total": time.perf_counter() - t_leg}
-        same_1gpu["speedup_of_this_leg"] = out["value"] / same_1gpu["value"]
-    del sharded, victim
+        if out["same_workload_1gpu"]:
+            out["same_workload_1gpu"]["speedup_of_this_leg"] = out["value"] / out["same_workload_1gpu"]["value"]
+    return out
+
+
+def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, with_eval=True, with_replicas=True):
+    """One workload, one sharded job in the command line's exchange form (--reduce / --gather, the trainer's default chunk count),
+    with its denominators: what `--parallel rows | rows2d` prints as the top-level line and what the `*_rows2d` legs of `also` hold."""
+    import torch
+    ctx = sharded_context(args, dev, rank, world, workload, dim, steps, warmup)
+    sharded_denominators(args, dev, rank, world, ctx, steps, warmup, with_replicas=with_replicas)
+    out = sharded_variant(args, dev, rank, world, ctx, parallel, steps, warmup, with_eval=with_eval)
+    del ctx
     torch.cuda.empty_cache()
     return out
 
@@ -723,8 +834,10 @@ def sharded_leg(args, dev, rank, world, workload, dim, parallel, steps, warmup, 
 class Deadline:
     """The sharded `also` legs have never met a real 8-GPU RCCL fabric in this repository's history: if one of them hangs (a
     collective that never completes), the top-level line -- already measured -- must still come out.  Every rank arms the
-    same timer; on expiry rank 0 prints the line with what it has and every rank leaves with os._exit(0) (a rank stuck inside a
-    collective cannot unwind)."""
+    same timer; on expiry rank 0 prints the line with what it has (`also.error` says what happened) and THEN every rank leaves with
+    os._exit(EXIT_CODE) -- non-zero, so that the launcher / driver sees that a collective hung while the measured line is already on
+    stdout (a rank stuck inside a collective cannot unwind; rank 0 fires first, the others 3 s later)."""
+    EXIT_CODE = 75   # EX_TEMPFAIL
 
     def __init__(self, seconds, rank, emit):
         import threading
@@ -742,7 +855,7 @@ class Deadline:
                 self.emit(f"the sharded legs did not finish within {self.seconds:.0f} s (deadline; the top-level line was measured before them)")
         finally:
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(self.EXIT_CODE)   # non-zero: the line (printed above by rank 0) survives, the code tells the driver a collective hung
 
     def cancel(self):
         self.done = True
@@ -964,7 +1077,7 @@ def worker(args, traffic_live=None):
         mfma = mfma_gemm_probe(dev)
     also = None
     if rank == 0 and world == 1 and not collectives and args.workload == "ml1m" and not args.no_also:
-        also = {"config3_yelp": also_measure(dev, "yelp", 128, args.layers, B)}
+        also = {"config3_yelp": also_measure(dev, "yelp", 128, args.layers, B, parity_steps=0 if args.no_parity else 3)}
         if not args.no_also_config4:
             also["config4"] = also_measure(dev, "config4", 64, args.layers, B, steps=10, warmup=3, eval_users=65536)
     cpu = cpu_aten = parity = None
@@ -1033,15 +1146,41 @@ def worker(args, traffic_live=None):
                 print(json.dumps(out), flush=True)
 
         dl = Deadline(args.also_timeout, rank, emit)
-        for name, wl, dim_, st_, wu_ in (("config4_rows2d", "config4", 64, 10, 3), ("config3_yelp_rows2d", "yelp", 128, 20, 5)):
-            if name == "config4_rows2d" and args.no_also_config4:
-                continue
+
+        def leg_of(name, fn):
             try:
-                leg = sharded_leg(args, dev, rank, world, wl, dim_, "rows2d", st_, wu_)
+                leg = fn()
                 if rank == 0:
                     legs[name] = leg
             except Exception as e:   # noqa: BLE001 -- a failed leg is recorded; the ranks re-synchronise at the next leg's first collective
                 legs[name] = {"error": f"{type(e).__name__}: {e}"}
+
+        # config 4 first (north_star's row-sharded shape): the default form with its denominators and the user-sharded evaluation, then
+        # the SAME job in the three exchange forms x {1, 4} chunks (training step only, each with speedup_of_this_leg, ranks_seen and
+        # its exposed-communication share), so that the first run on real xGMI decides reduce_scatter_tensor vs the one-shot
+        # all-to-all vs the 1-D one-shot all-gather, and the chunk count, by itself; then the yelp shape in the default form.
+        if not args.no_also_config4:
+            ctx = None
+            try:
+                ctx = sharded_context(args, dev, rank, world, "config4", 64, 10, 3)
+                sharded_denominators(args, dev, rank, world, ctx, 10, 3)
+            except Exception as e:   # noqa: BLE001
+                legs["config4_rows2d"] = {"error": f"{type(e).__name__}: {e}"}
+                ctx = None
+            if ctx is not None:
+                leg_of("config4_rows2d", lambda: sharded_variant(args, dev, rank, world, ctx, "rows2d", 10, 3))
+                for suffix, par_, red_, gat_, ch_ in SHARDED_VARIANTS:
+                    leg_of("config4_" + suffix, lambda: sharded_variant(args, dev, rank, world, ctx, par_, 6, 2, reduce=red_, gather=gat_,
+                                                                        chunks=ch_, with_eval=False))
+                if rank == 0:
+                    ab = {k: {"ms_per_step": v["ms_per_step"], "speedup_vs_1gpu": (v.get("same_workload_1gpu") or {}).get("speedup_of_this_leg"),
+                              "exposed_comm_share": (v.get("exposed_communication") or {}).get("exposed_comm_share")}
+                          for k, v in legs.items() if k.startswith("config4_") and isinstance(v, dict) and "ms_per_step" in v}
+                    if ab:
+                        legs["config4_exchange_ab"] = dict(ab, best=min(ab, key=lambda k: ab[k]["ms_per_step"]))
+                del ctx
+                torch.cuda.empty_cache()
+        leg_of("config3_yelp_rows2d", lambda: sharded_leg(args, dev, rank, world, "yelp", 128, "rows2d", 20, 5))
         emit()
         dl.printed = True
         dist.barrier()       # (still under the deadline: a rank whose leg failed half-way may never arrive)

@@ -103,3 +103,49 @@ def adam_close(a, b, lr, steps, rtol=1e-4, outlier_frac=1e-3, travel_frac=0.25):
     n_bad = int((diff > rtol * scale).sum())
     # small tensors: a handful of near-cancelling entries is already above any sensible fraction
     return n_bad <= max(outlier_frac * diff.size, 8) and diff.max() <= travel_frac * lr * steps, (n_bad, diff.size, diff.max())
+
+
+def check_eval_rows_multi(g, users, target_score, target_rank, top_ids, top_scores, score_rtol=1e-5, min_exact=0.85, lists=True):
+    """An evaluation (per user: scores of the targets, their ranks among the unseen items, the top-101 list) against a golden that
+    holds the REFERENCE's evaluation rows for several targets -- eval_rows[t] = user_item_model_generate's [user, score(target),
+    hit@k...] (recad/workflow/normal.py:57-93), one target at a time -- and its top-100 lists.  North_star's bar: target scores to
+    `score_rtol`; hit flags identical on every row whose target is not within the observed score noise of the cutoff; HR@k within
+    1e-4 relative + those cutoff-ambiguous rows (asserted to stay a handful); lists identical on tie-free prefixes.  target_rank /
+    top_* may cover only the first rows of `users` when the caller scored the full catalogue for fewer users (the oracle at L = 5);
+    rows without a rank are compared on the target scores alone.  Returns (#lists identical outright, #lists, #ambiguous rows)."""
+    ref = g["eval_rows"]                       # [T, n, 2 + len(topks)]
+    T, n = ref.shape[0], ref.shape[1]
+    topks = [int(k) for k in g["topks"]]
+    assert np.array_equal(np.asarray(users), g["eval_users"]) and T == len(g["target_ids"])
+    ts = np.asarray(target_score, dtype=np.float64)
+    assert ts.shape == (n, T)
+    for t in range(T):
+        assert np.array_equal(ref[t][:, 0], np.asarray(users, dtype=np.float64))
+        # (an untrained victim's scores are sums of cancelling terms around 0: "1e-5" is of the largest target score, like every
+        # table / gradient tolerance of this suite, not of each -- possibly tiny -- entry)
+        assert np.abs(ts[:, t] - ref[t][:, 1]).max() <= score_rtol * np.abs(ref[:, :, 1]).max(), (t, np.abs(ts[:, t] - ref[t][:, 1]).max())
+    n_rank = 0 if target_rank is None else len(target_rank)
+    n_amb_total = 0
+    if n_rank:
+        K = top_scores.shape[1] - 1
+        sc = np.asarray(top_scores, dtype=np.float64)
+        tol = 4.0 * max(np.abs(ts[:, t] - ref[t][:, 1]).max() for t in range(T)) + 1e-12
+        for t in range(T):
+            rank = np.asarray(target_rank)[:, t]
+            for q, k in enumerate(topks):
+                mine = (rank < k).astype(np.float64)
+                other = np.where(rank < k, sc[:, min(k, K)], sc[:, k - 1])   # first item outside the cutoff / last item inside it
+                amb = np.isfinite(other) & (np.abs(ts[:n_rank, t] - other) <= tol)
+                rflag = ref[t][:n_rank, 2 + q]
+                assert np.array_equal(mine[~amb], rflag[~amb]), (t, k, np.nonzero(mine != rflag)[0])
+                if n_rank == n:
+                    assert abs(mine.mean() - rflag.mean()) <= 1e-4 * max(rflag.mean(), 1e-12) + amb.sum() / n, (t, k, int(amb.sum()))
+                assert amb.sum() <= 0.02 * n_rank + 2, (t, k, int(amb.sum()))   # a handful, not a blanket
+                n_amb_total += int(amb.sum())
+    exact = n_lists = 0
+    if lists and n_rank:
+        mine = [(np.asarray(top_ids)[r][:100], np.asarray(top_scores)[r][:100]) for r in range(n_rank)]
+        n_lists = n_rank
+        exact = compare_topk_lists(mine, g["top_ids"][:n_rank], g["top_scores"][:n_rank], score_rtol=score_rtol)
+        assert exact >= min_exact * n_lists, (exact, n_lists)
+    return exact, n_lists, n_amb_total

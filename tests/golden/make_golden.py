@@ -305,6 +305,102 @@ def golden_ncf(recad, torch, name, factor, layers, tag, max_steps=None, row_stri
     print(f"ncf_{tag}: U={U} I={I} E={E} steps={len(batches)} loss0={losses[0]:.6f} lossN={losses[-1]:.6f}")
 
 
+def golden_ncf_init_eval(recad, torch, name, factor, layers, tag, eval_max_users, full_score_users=8):
+    """The reference's evaluation (Normal.user_item_model_generate, recad/workflow/normal.py:57-93, through
+    recad/model/victim/ncf.py:112-131) of the UNTRAINED victim at the seeded initial parameters the tests regenerate
+    (tests/_golden.py ncf_init): pins the forward / scoring / top-K path at factor 256 with NO training history -- no ReLU gate
+    decided by an earlier step's rounding -- in front of it (round-5 review, next #2).  The scores are recorded from the
+    reference's own forward calls inside user_item_model_generate (a recording wrapper around model.forward: one pass)."""
+    torch.manual_seed(2023)
+    np.random.seed(2023)
+    ds = recad.dataset.from_config("implicit", name, need_graph=False, sample="pointwise", download=False)
+    info = ds.info_describe()
+    U, I = info["n_users"], info["n_items"]
+    model = recad.model.from_config("victim", "ncf", factor_num=factor, num_layers=layers).I(dataset=ds)
+    E = factor * 2 ** (layers - 1)
+    model.embed_user_GMF.weight.data.copy_(torch.from_numpy(seeded_table(31, U, factor, 0.01)))
+    model.embed_item_GMF.weight.data.copy_(torch.from_numpy(seeded_table(32, I, factor, 0.01)))
+    model.embed_user_MLP.weight.data.copy_(torch.from_numpy(seeded_table(33, U, E, 0.01)))
+    model.embed_item_MLP.weight.data.copy_(torch.from_numpy(seeded_table(34, I, E, 0.01)))
+    dense_names = [n for n, p in model.named_parameters() if not n.startswith("embed_") and p.dim() == 2]
+    for j, n in enumerate(dense_names):
+        p = dict(model.named_parameters())[n]
+        a = float(np.sqrt(6.0 / (p.shape[0] + p.shape[1])))
+        p.data.copy_(torch.from_numpy(seeded_uniform(40 + j, p.shape[0], p.shape[1], -a, a)))
+    for n, p in model.named_parameters():    # (the reference zeroes its biases: ncf.py:60-77; stated here, asserted by the tests' init)
+        if p.dim() == 1:
+            assert float(p.abs().max()) == 0.0, n
+    target_ids, topks = [0], [10, 20, 50, 100]
+    train_dict = info["train_dict"]
+    full = set(range(I))
+    cand = {}
+    for k, v in train_dict.items():
+        s_ = set(v)
+        if any(t in s_ for t in target_ids):
+            continue
+        cand[k] = list(full - s_)
+    cand = {k: cand[k] for k in sorted(cand)[:eval_max_users]}
+    calls, memo = [], {}
+    orig_forward = model.forward
+
+    def recording_forward(users, items):
+        # records every forward call of the reference's evaluation loop; a repeated call for the same user with the same items
+        # (the extra-target passes below) returns the recorded output instead of recomputing 5 600 towers
+        u = int(users[0])
+        if u in memo and np.array_equal(memo[u][0], items.numpy()):
+            return torch.from_numpy(memo[u][1].copy())
+        out = orig_forward(users, items)
+        memo[u] = (items.numpy().copy(), out.detach().numpy().copy())
+        calls.append((u, memo[u][0], memo[u][1]))
+        return out
+
+    model.forward = recording_forward
+    wf = object.__new__(recad.workflow.Normal)
+    rows0 = recad.workflow.Normal.user_item_model_generate(wf, model, cand, topks, target_ids, torch.device("cpu"))
+    users = np.array(sorted(cand.keys()), dtype=np.int32)
+    assert [c[0] for c in calls] == users.tolist()
+    # an untrained victim ranks item 0 nowhere near anybody's top-100 (all hit flags 0): three more targets, chosen among the items
+    # NONE of these users rated (so the candidate lists -- and the recorded forward calls -- stay what they are) as the ones inside the
+    # most users' top-50, evaluated by the reference's own loop one target at a time (its row indexing handles one target: normal.py:81-92)
+    common = full.copy()
+    for k in cand:
+        common &= set(cand[k])
+    common.discard(0)
+    common = np.array(sorted(common), dtype=np.int64)
+    in_top50 = np.zeros(I, dtype=np.int64)
+    for u, iids, sc in calls:
+        order = np.lexsort((iids, -sc.astype(np.float64)))
+        in_top50[iids[order[:50]]] += 1
+    extra = common[np.argsort(-in_top50[common], kind="stable")[:3]]
+    target_ids = [0] + [int(t) for t in extra]
+    rows = np.stack([rows0] + [recad.workflow.Normal.user_item_model_generate(wf, model, cand, topks, [int(t)], torch.device("cpu")) for t in extra])
+    model.forward = orig_forward
+    assert len(calls) == len(users), "the extra-target passes must have been served from the recorded calls"
+    top_ids = np.full((len(users), 100), -1, dtype=np.int32)
+    top_scores = np.zeros((len(users), 100), dtype=np.float32)
+    min_gap = np.zeros(len(users), dtype=np.float32)
+    scores_full = np.full((min(full_score_users, len(users)), I), np.nan, dtype=np.float32)   # NaN = a seen item (not scored)
+    for r, (u, iids, sc) in enumerate(calls):
+        order = np.lexsort((iids, -sc.astype(np.float64)))
+        k = min(100, len(order))
+        top_ids[r, :k] = iids[order[:k]]
+        top_scores[r, :k] = sc[order[:k]]
+        ss = sc[order[: min(101, len(order))]].astype(np.float64)
+        gaps = (ss[:-1] - ss[1:]) / np.maximum(np.abs(ss[:-1]), 1e-30)
+        min_gap[r] = gaps.min() if len(gaps) else 1.0
+        if r < scores_full.shape[0]:
+            scores_full[r, iids] = sc
+    tptr, tidx = dict_to_csr(train_dict, U)
+    np.savez_compressed(
+        os.path.join(OUT, f"ncf_{tag}_init_eval.npz"),
+        n_users=U, n_items=I, factor=factor, layers=layers, eval_stride=1, train_ptr=tptr, train_idx=tidx,
+        dense_names=np.asarray(dense_names), target_ids=np.asarray(target_ids, dtype=np.int32), topks=np.asarray(topks, dtype=np.int32),
+        eval_rows=rows, eval_users=users, top_ids=top_ids, top_scores=top_scores, top_min_gap=min_gap, scores_full=scores_full,
+    )
+    print(f"ncf_{tag}_init_eval: U={U} I={I} E={E} users={len(users)} targets={target_ids} hr={rows[:, :, 2:].mean(1).tolist()} "
+          f"min_gap>{2e-6}: {(min_gap > 2e-6).sum()}")
+
+
 def golden_graph_inject(recad, torch, name, tag):
     """Graph before/after inject_data: the normalised adjacency the
     reference builds for a poisoned dataset, for the build's own graph builder."""
@@ -367,6 +463,10 @@ def main():
                                                dense_stride=211, eval_max_users=24),
         "ncf_game_f256_l5": lambda: golden_ncf(recad, torch, "game", 256, 5, "game_f256_l5", max_steps=2, row_stride=256, eval_stride=1,
                                                dense_stride=3001, eval_max_users=3),
+        # ... and the reference's evaluation of the UNTRAINED victim at the seeded initial parameters, at the reference's default
+        # depth (default.py:124-125 num_layers = 5) and at 3: 64 eligible users each
+        "ncf_game_f256_l5_init": lambda: golden_ncf_init_eval(recad, torch, "game", 256, 5, "game_f256_l5", 64),
+        "ncf_game_f256_l3_init": lambda: golden_ncf_init_eval(recad, torch, "game", 256, 3, "game_f256_l3", 64),
         "inject_dev": lambda: golden_graph_inject(recad, torch, "dev", "dev"),
     }
     for k, fn in jobs.items():

@@ -164,3 +164,40 @@ def test_ncf_train(name):
     for nme, t in zip(names, P.tensors()):
         ok, info = G.adam_close(pick(nme, t), g["final_" + nme], 1e-3, steps)
         assert ok, (nme, info)
+
+
+@pytest.mark.parametrize("name", ["ncf_game_f256_l5", "ncf_game_f256_l3"])
+def test_ncf_init_eval(name):
+    """The oracle's NCF forward (recad/model/victim/ncf.py:112-131) against the REFERENCE's evaluation of the UNTRAINED victim at the
+    seeded initial parameters (tests/golden/make_golden.py golden_ncf_init_eval: normal.py:57-93 over 64 eligible users, four
+    targets), BASELINE config 5's factor at the reference's default depth 5 and at 3 -- no training history in front of the forward.
+    All 64 x 4 target scores (1e-5); the reference's top-100 items of the first users re-scored (1e-5, and in the recorded order
+    wherever the reference's scores are not tied); at L = 3, where the oracle scores a whole 5 600-item catalogue in ~14 s, the full
+    evaluation of the first two users: ranks, hit flags, top-100 lists on tie-free prefixes.  (The GPU test does all 64 users at both
+    depths and pins GPU == oracle bit for bit on a sample.)"""
+    g = G.load(name + "_init_eval")
+    f, L = int(g["factor"]), int(g["layers"])
+    (ug, ig, um, im), W, b, pw, pb = G.ncf_init(g)
+    P = orc.NCFParams(f, L, ug, ig, um, im, W, b, pw, pb)
+    users, targets = g["eval_users"], g["target_ids"]
+    n, T, I = len(users), len(targets), int(g["n_items"])
+    ts = orc.ncf_forward(P, np.repeat(users, T), np.tile(targets, n)).reshape(n, T)
+    n_full = 2 if L <= 3 else 0
+    rank = np.zeros((n_full, T), dtype=np.int32)
+    top_ids = np.zeros((n_full, 101), dtype=np.int32)
+    top_sc = np.zeros((n_full, 101), dtype=np.float32)
+    for r in range(n_full):
+        u = int(users[r])
+        s = orc.ncf_forward(P, np.full(I, u), np.arange(I))
+        seen = g["train_idx"][g["train_ptr"][u]:g["train_ptr"][u + 1]]
+        top_ids[r], top_sc[r], ts_r, rank[r] = orc.topk_row(s, seen, 101, targets)
+        assert np.array_equal(ts_r, ts[r])
+        ok = ~np.isnan(g["scores_full"][r])
+        assert G.relerr(s[ok], g["scores_full"][r][ok]) <= 1e-5      # (of the row's largest score)
+    G.check_eval_rows_multi(g, users, ts, rank if n_full else None, top_ids, top_sc, min_exact=0.5)
+    for r in range(2):
+        ids, ref = g["top_ids"][r], g["top_scores"][r].astype(np.float64)
+        s = orc.ncf_forward(P, np.full(100, int(users[r])), ids).astype(np.float64)
+        assert G.relerr(s, ref) <= 1e-5, (r, np.abs(s - ref).max())
+        gap = (ref[:-1] - ref[1:]) / np.maximum(np.abs(ref[:-1]), 1e-30)
+        assert (np.diff(s)[gap > G.TIE_RTOL] < 0).all(), r    # the oracle orders every untied neighbour pair like the reference

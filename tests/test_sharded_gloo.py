@@ -152,7 +152,17 @@ def test_bench_self_launch_dry_run():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["dry_run"] and d["n_gpus"] == 2 and d["rank_sum"] == 1.0 and d["parallel"] == "replicas" and d["scaling"] == "weak"
-    assert d["also_sharded_legs"] == ["config4_rows2d", "config3_yelp_rows2d"]   # the strong-scaling jobs live in `also`
+    # the strong-scaling jobs live in `also`: config 4 in the default form, then the SAME job in the three exchange forms the first
+    # hardware run has to choose between (reduce_scatter_tensor / one-shot all-to-all + ordered sum / 1-D one-shot all-gather), each
+    # with 1 and 4 row chunks, then the yelp shape
+    assert d["also_sharded_legs"] == ["config4_rows2d", "config4_collective_c1", "config4_collective_c4", "config4_ordered_c1",
+                                      "config4_ordered_c4", "config4_rows_direct_c1", "config4_rows_direct_c4", "config3_yelp_rows2d"]
+    import bench
+    assert d["also_sharded_legs"] == bench.also_sharded_leg_names() and bench.also_sharded_leg_names(True) == ["config3_yelp_rows2d"]
+    assert {(v[1], v[2], v[3], v[4]) for v in bench.SHARDED_VARIANTS} == {
+        ("rows2d", "collective", "collective", 1), ("rows2d", "collective", "collective", 4), ("rows2d", "ordered", "collective", 1),
+        ("rows2d", "ordered", "collective", 4), ("rows", "collective", "direct", 1), ("rows", "collective", "direct", 4)}
+    assert bench.Deadline.EXIT_CODE != 0
     # a world that disagrees with --gpus is refused
     env2 = dict(env, RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
@@ -229,3 +239,25 @@ def test_grid_tiles_cover_graph():
                 for e in range(a, b):
                     rebuilt[r, inv_col[int(cc[e])]] += vv[e]
         assert np.allclose(rebuilt, dense, rtol=0, atol=1e-12)
+
+
+def test_bench_deadline_prints_the_line_then_leaves_nonzero():
+    """bench.Deadline (the N > 1 `also` legs run under it): when a collective never completes, rank 0 prints the already-measured line
+    with also.error FIRST, then the process leaves with a NON-zero code -- the line survives, the code tells the driver something hung
+    (round 5 left with 0)."""
+    code = (
+        "import sys, time, json; sys.path.insert(0, %r); import bench\n"
+        "def emit(err=None): print(json.dumps({'value': 1.0, 'also': {'error': err}}), flush=True)\n"
+        "dl = bench.Deadline(0.5, 0, emit)\n"
+        "time.sleep(30)   # a collective that never completes\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    import bench
+    assert p.returncode == bench.Deadline.EXIT_CODE != 0, (p.returncode, p.stderr[-500:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] == 1.0 and "deadline" in d["also"]["error"]
+    # a cancelled deadline does nothing
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "dl = bench.Deadline(0.3, 0, lambda err=None: print('fired'))\n"
+             "dl.cancel(); time.sleep(1.0); print('ok')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok"
