@@ -306,7 +306,7 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
     trip = tuple(ep[k][: (steps + warmup) * B].contiguous() for k in ("users", "positive_items", "negative_items"))
     init_tables = tuple(p_.detach().cpu().numpy().copy() for p_ in (v.embedding_user.weight, v.embedding_item.weight)) if parity_steps else None
     v.reserve(max(steps, warmup) * B, B)
-    warm_losses = run_steps(v, trip, B, 0, warmup)
+    warm_losses = run_steps(v, trip, B, 0, warmup).sum(dim=1).double().cpu().numpy()   # (read now: the call returns a view of the handle's loss buffer, which the next call overwrites)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     part = run_steps(v, trip, B, warmup, steps)
@@ -355,7 +355,7 @@ def also_measure(dev, workload, dim, layers, B, steps=20, warmup=5, eval_users=0
         v2.embedding_item.weight.data.copy_(torch.from_numpy(init_tables[1]))
         v2.reserve(n_par * B, B)
         l2 = run_steps(v2, trip, B, 0, n_par).sum(dim=1).double().cpu().numpy()
-        run_losses = warm_losses.sum(dim=1).double().cpu().numpy()[:n_par]
+        run_losses = warm_losses[:n_par]
         tabs2 = tuple(p_.detach().cpu().numpy().copy() for p_ in (v2.embedding_user.weight, v2.embedding_item.weight))
         rb = v2._ws.get("row_blocks")
         used_list = int(rb[0].item()) if rb is not None else None

@@ -699,6 +699,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     const float *pa = MA == 1 ? sA + (wr * 64 + l16) * kWLd + lq : sA + lq * kWLdT + wr * 64 + l16;
     const float *pb = MB == 1 ? sB + (wc * 64 + l16) * kWLd + lq : sB + lq * kWLdT + wc * 64 + l16;
     const bool plain = PLAIN || (!g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask);
+    const bool c_lines = (g.ldc & 31) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 127) == 0;   // rows of C start on 128-byte lines
     // ONE software pipeline over all (tile, k-chunk) pairs of the run: the next pair's global loads fly under this chunk's
     // MFMAs, and a finished tile's stores drain under the next tile's MFMAs.
     int c = 0;
@@ -717,6 +718,68 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         float av[2][4], bv[2][4];
         __builtin_amdgcn_s_setprio(1);   // the wave in its MFMA phase wins issue slots over the co-resident one's stores (+1.4 %)
+        // PLAIN, a full tile's LAST chunk (k = 64: its only one): the 16 accumulator blocks are finished GROUP BY GROUP -- four groups
+        // of 2 x 2 blocks, each walked through all 16 k-steps (the same k-ordered chain per element: same bits) -- and a finished
+        // group's four 16-byte stores are issued right behind its last MFMA, so they drain under the next group's 64 MFMAs (2 048
+        // pipe cycles) instead of all 16 stores of every wave of the chip hitting the write path at once behind the tile's last MFMA
+        // (profiles/r05_gemm_stamps.txt: 4.7 us of stores per 7.2 us MFMA phase at 5 893 x 3 702 x 64, nothing overlapped; a second
+        // accumulator set to overlap them with the NEXT tile does not fit beside the operand prefetch).  Costs LDS operand reads:
+        // 4 per 4 MFMAs instead of 8 per 16.
+        // Only for score rows that start on 128-byte lines (rk_score_topk pads them: plan.ld_scores): with the natural stride of a
+        // 34 474- or 3 702-item catalogue every 64-byte store segment straddles two lines and the interleaved stores stall the MFMAs
+        // instead of hiding under them (profiles/r06d_gemm_ab.txt: 54 617 x 34 474 x 128 4.47 -> 7.3 ms unaligned, 4.69 -> 4.21 ms
+        // aligned; 5 893 x 3 702 x 64 58 -> 82 us unaligned, 44.3 -> 40.0 us aligned) -- unaligned callers keep the round-5 order.
+        const bool grouped = PLAIN && last && c_lines && m0 + 128 <= g.M && n0 + 128 <= g.N;
+        if (grouped) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int i0 = (gq >> 1) * 2, j0 = (gq & 1) * 2;
+                float ga[2][2], gb[2][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ga[0][e] = wide_operand<MA>(pa, i0 + e, 0);
+                    gb[0][e] = wide_operand<MB>(pb, j0 + e, 0);
+                }
+#pragma unroll
+                for (int st = 0; st < kWK / 4; ++st) {
+                    const int cur = st & 1, nxt = cur ^ 1;
+                    if (st + 1 < kWK / 4) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            ga[nxt][e] = wide_operand<MA>(pa, i0 + e, st + 1);
+                            gb[nxt][e] = wide_operand<MB>(pb, j0 + e, st + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[cur][j], ga[cur][i], acc[i0 + i][j0 + j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float *crow = g.C + (size_t)(m0 + wr * 64 + (i0 + i) * 16 + l16) * g.ldc + (n0 + wc * 64 + 4 * lq);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i0 + i][j0 + j], reinterpret_cast<f32x4_u *>(crow + (j0 + j) * 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (the group's stores stay in front of the next group's MFMAs)
+            }
+            __builtin_amdgcn_s_setprio(0);
+            GEMM_STAMP(it, 3);
+            m0 = m1; n0 = n1;
+            if (more) init_acc(m0, n0);
+            c = 0;
+            GEMM_STAMP(it, 4);
+            __syncthreads();
+            GEMM_STAMP(it, 5);
+            if (more) {
+                wide_store<MA>(ta, sA);
+                wide_store<MB>(tb, sB);
+            }
+            __syncthreads();
+            GEMM_STAMP(it, 6);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             av[0][i] = wide_operand<MA>(pa, i, 0);
@@ -788,6 +851,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             // is `s_waitcnt vmcnt(stores + younger loads)` -- which the compiler can only count where the number of stores behind
             // the loads is known.  With one shared tail it merged "16 stores", "some stores" (partial tile) and "none" (chunk
             // inside a tile) into vmcnt(15 .. 0): every finished tile's stores were drained before the next operands went to LDS.
+            // (PLAIN full tiles of a line-aligned C never get here: the grouped path above stores them and runs its own tail)
             if (PLAIN && m0 + 128 <= g.M && n0 + 128 <= g.N) {   // (the score-matrix instantiation: the others keep one tail and their register budget)
                 emit(std::false_type{});
                 m0 = m1; n0 = n1;

@@ -1,4 +1,4 @@
-// Timing probe for gemm.h (not part of the library): gemm_probe M N K [pad_a] [pad_b] [split] [forms: 0 = A[M,K] B[N,K]; 1 = dX form; 2 = dW form] [gather: 1 = rows of A through an index list]
+// Timing probe for gemm.h (not part of the library): gemm_probe M N K [pad_a] [pad_b] [split] [forms: 0 = A[M,K] B[N,K]; 1 = dX form; 2 = dW form] [gather: 1 = rows of A through an index list] [ldc: 1 = rows of C padded to 32 floats]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +21,10 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 255) / 256.f - 0.5f;
     hipMemcpy(A, h.data(), na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), nb * 4, hipMemcpyHostToDevice);
     GemmArgs g{};
-    g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.C = C; g.ldc = N;
+    // argv[9] = 1: rows of C padded to 32 floats (128-byte lines), as rk_score_topk's score matrix is (plan.ld_scores)
+    const long long ldc = (argc > 9 && atoi(argv[9])) ? (((long long)N + 31) & ~31LL) : N;
+    if (ldc != N) { hipFree(C); hipMalloc(&C, (size_t)M * ldc * 4); }
+    g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.C = C; g.ldc = ldc;
     if (form == 2) { g.a_rs = 1; g.a_cs = M + pa; } else { g.a_rs = K + pa; g.a_cs = 1; }
     if (form == 0) { g.b_rs = K + pb; g.b_cs = 1; } else { g.b_rs = 1; g.b_cs = N + pb; }
     if (argc > 8 && atoi(argv[8])) {

@@ -840,9 +840,9 @@ def test_ncf_init_eval_golden(gpu_device, name):
         p.weight.data.copy_(torch.from_numpy(a))
     for l, x in enumerate([x for x in m.MLP_layers if isinstance(x, torch.nn.Linear)]):
         x.weight.data.copy_(torch.from_numpy(W[l]))
-        assert float(x.bias.abs().max()) == 0.0    # (ncf.py:60-77 zeroes the biases; the golden run asserted the same of the reference)
+        assert float(x.bias.detach().abs().max()) == 0.0    # (ncf.py:60-77 zeroes the biases; the golden run asserted the same of the reference)
     m.predict_layer.weight.data.copy_(torch.from_numpy(pw))
-    assert float(m.predict_layer.bias.abs().max()) == 0.0
+    assert float(m.predict_layer.bias.detach().abs().max()) == 0.0
     m = m.to(gpu_device)
     users = eligible_users(g["train_ptr"], g["train_idx"], g["target_ids"][:1])[: len(g["eval_users"])]
     assert np.array_equal(users, g["eval_users"])
@@ -856,11 +856,13 @@ def test_ncf_init_eval_golden(gpu_device, name):
     got, ref = rows.cpu().numpy(), g["scores_full"]
     ok = ~np.isnan(ref)
     assert G.relerr(got[ok], ref[ok]) <= 1e-5, np.abs(got[ok] - ref[ok]).max()      # (of the largest score)
-    # ... and the same untrained victim against the oracle: bit-identical scores (one k-ordered chain in both) on a sample
+    # ... and the same untrained victim against the oracle on a sample (one k-ordered chain per layer in both; the GPU continues the
+    # per-user layer-0 prefix through MFMA k-blocks of four, the oracle adds term by term: last-bit differences over 8 192-term sums: 1.3e-6 of the largest score measured, 5e-6 allowed)
     P = orc.NCFParams(f, L, ug, ig, um, im, W, b, pw, pb)
     its = np.random.default_rng(3).choice(m.num_items, 96 if L > 3 else 512, replace=False)
     osc = orc.ncf_forward(P, np.full(len(its), int(users[0])), its)
-    assert np.array_equal(got[0][its], osc)
+    assert G.relerr(got[0][its], osc) <= 5e-6
+    assert float(m.predict_layer.bias.detach().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("name,chunks", [("lightgcn_game_d64_tg", 1), ("lightgcn_game_d64_tg", 3), ("lightgcn_dev_d128_l2_tg", 2)])
