@@ -630,7 +630,10 @@ __device__ __forceinline__ float wide_operand(const float *base, int i, int st)
 // epilogue options tested at run time, every one of a tile's 64 stored elements walked a chain of scalar branches: per-tile
 // stamps (scripts/gemm_probe.hip -DGEMM_STAMPS, profiles/r05_gemm_stamps.txt) showed 4.7 us of "stores" after every 8 us MFMA
 // phase at 5 893 x 3 702 x 64 -- instruction issue, not memory (half the workgroups storing at a time took just as long).
-template <int MA, int MB, bool PLAIN = false>
+// GROUPED (with PLAIN; the launcher takes it when C's rows start on 128-byte lines): full tiles finish their last chunk group by
+// group with the stores under the next group's MFMAs (below).  A separate instantiation on purpose: as a run-time branch inside one
+// kernel the grouped path cost the OTHER path its schedule (8192 x 34474 x 256 with the natural row stride: 1 209 -> 1 264 us).
+template <int MA, int MB, bool PLAIN = false, bool GROUPED = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_f32_wide_kernel(const GemmArgs g, const int gx, const int gy)
 {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
@@ -699,7 +702,6 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     const float *pa = MA == 1 ? sA + (wr * 64 + l16) * kWLd + lq : sA + lq * kWLdT + wr * 64 + l16;
     const float *pb = MB == 1 ? sB + (wc * 64 + l16) * kWLd + lq : sB + lq * kWLdT + wc * 64 + l16;
     const bool plain = PLAIN || (!g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask);
-    const bool c_lines = (g.ldc & 31) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 127) == 0;   // rows of C start on 128-byte lines
     // ONE software pipeline over all (tile, k-chunk) pairs of the run: the next pair's global loads fly under this chunk's
     // MFMAs, and a finished tile's stores drain under the next tile's MFMAs.
     int c = 0;
@@ -729,7 +731,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         // 34 474- or 3 702-item catalogue every 64-byte store segment straddles two lines and the interleaved stores stall the MFMAs
         // instead of hiding under them (profiles/r06d_gemm_ab.txt: 54 617 x 34 474 x 128 4.47 -> 7.3 ms unaligned, 4.69 -> 4.21 ms
         // aligned; 5 893 x 3 702 x 64 58 -> 82 us unaligned, 44.3 -> 40.0 us aligned) -- unaligned callers keep the round-5 order.
-        const bool grouped = PLAIN && last && c_lines && m0 + 128 <= g.M && n0 + 128 <= g.N;
+        const bool grouped = GROUPED && PLAIN && last && m0 + 128 <= g.M && n0 + 128 <= g.N;
         if (grouped) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -851,8 +853,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             // is `s_waitcnt vmcnt(stores + younger loads)` -- which the compiler can only count where the number of stores behind
             // the loads is known.  With one shared tail it merged "16 stores", "some stores" (partial tile) and "none" (chunk
             // inside a tile) into vmcnt(15 .. 0): every finished tile's stores were drained before the next operands went to LDS.
-            // (PLAIN full tiles of a line-aligned C never get here: the grouped path above stores them and runs its own tail)
-            if (PLAIN && m0 + 128 <= g.M && n0 + 128 <= g.N) {   // (the score-matrix instantiation: the others keep one tail and their register budget)
+            // (GROUPED: full tiles never get here -- the grouped path above stores them and runs its own tail)
+            if (PLAIN && !GROUPED && m0 + 128 <= g.M && n0 + 128 <= g.N) {   // (the score-matrix instantiation: the others keep one tail and their register budget)
                 emit(std::false_type{});
                 m0 = m1; n0 = n1;
                 if (more) init_acc(m0, n0);
@@ -955,8 +957,10 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
         if (!no_wide && variant == 0 && fa == 1 && fb && g.M >= 128 && Ni >= 128 && g.K % kWK == 0 && g.K >= wide_min_k &&
             (!g.acc_init || g.a_rmod > 0) && !g.drop_thresh24) {
             const bool plain_w = !g.row_bias && !g.col_bias && !g.relu && !g.sigmoid && !g.mask && !g.acc_init;
-            const void *fn[3] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
-                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1, true>)};
+            const bool c_lines = (g.ldc & 31) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 127) == 0;   // rows of C start on 128-byte lines
+            const void *fn[4] = {reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1>), reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 2>),
+                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1, true>),
+                                 reinterpret_cast<const void *>(gemm_f32_wide_kernel<1, 1, true, true>)};
             static RkPerDeviceOnce wide_attr;
             int wide_attr_dev;
             if (wide_attr.need(&wide_attr_dev)) {
@@ -969,7 +973,7 @@ inline hipError_t gemm_f32_launch(const GemmArgs &g, hipStream_t s)
             int gx = (Ni + 127) / 128, gy = (g.M + 127) / 128;
             const size_t lds = (size_t)(wide_floats<1>() + (fb == 1 ? wide_floats<1>() : wide_floats<2>())) * sizeof(float);
             void *params[3] = {const_cast<GemmArgs *>(&g), &gx, &gy};
-            hipError_t e = hipLaunchKernel(fn[fb == 2 ? 1 : plain_w ? 2 : 0], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
+            hipError_t e = hipLaunchKernel(fn[fb == 2 ? 1 : plain_w ? (c_lines ? 3 : 2) : 0], dim3(std::min(gx * gy, wide_wgs)), dim3(256), params, lds, s);
             if (e != hipSuccess) return e;
             if (Ni < g.N) {   // right strip: all rows, columns [Ni, N)
                 GemmArgs e1 = g;
