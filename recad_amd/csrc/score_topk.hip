@@ -377,6 +377,24 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 }
 // score_key() (score_panel.h: the ONE encoder of every selection kernel) with the seen bit folded in: 0 for an excluded item.
 __device__ __forceinline__ unsigned score_key_sel(float s, bool excluded) { return excluded ? 0u : score_key(s); }
+// The wave kernel's per-item form: score_key() WITHOUT its final clamp, the exclusion as an OR.  `ones` is 0 or 0xffffffff (the
+// item's seen bit sign-extended: one v_bfe_i32); OR-ed into the score's bits it makes them all ones, whose key is 0.  What score_key
+// clamps to 0 -- -inf (0x007fffff) and negative NaNs (below) -- stays where the monotone map puts it: below kKeyValid, the key of
+// -FLT_MAX.  Every compare of the kernel that means "a rankable item" is against kKeyValid instead of 1, so the results are the
+// clamped encoder's, at 4.5 vector instructions per item instead of 6.5 + a scalar OR (the ISA of the round-5 loop: v_and + v_cmp_ne
+// for the bit, v_cmp_gt against 0x800000, s_or, v_cndmask).
+// c += (a < b) / (a <= b) / (a == b) per lane, a wave-uniform (an SGPR), b the lane's key: a compare into VCC and ONE add-with-carry
+// (the compiler's form of `c += cond ? 1 : 0` is v_cmp + v_cndmask + v_add: three instructions at each of the kernel's three
+// counting sites per item -- target greater / equal, candidates -- i.e. 174 of the ~2 250 vector instructions of a 3 702-item row)
+__device__ __forceinline__ void count_lt(int &c, unsigned a, unsigned b) { asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(c) : "s"(a), "v"(b) : "vcc"); }
+__device__ __forceinline__ void count_le(int &c, unsigned a, unsigned b) { asm("v_cmp_le_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(c) : "s"(a), "v"(b) : "vcc"); }
+__device__ __forceinline__ void count_eq(int &c, unsigned a, unsigned b) { asm("v_cmp_eq_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(c) : "s"(a), "v"(b) : "vcc"); }
+static constexpr unsigned kKeyValid = 0x00800000u;
+__device__ __forceinline__ unsigned score_key_raw(float s, unsigned ones)
+{
+    const unsigned u = __float_as_uint(s + 0.0f) | ones;
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
 
 #ifndef TOPK_STAMP   // (scripts/topk_wave_probe.sh builds this kernel alone with per-phase cycle stamps)
 #define TOPK_STAMP(i) do { } while (0)
@@ -409,6 +427,14 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
     unsigned *sel32 = reinterpret_cast<unsigned *>(sel_all[w]);
     const int hi = opaque(1);
     auto sel_put = [&](int slot, unsigned not_id, unsigned k) { sel32[2 * slot] = not_id; sel32[2 * slot + hi] = k; };
+    // the candidates' form: the slot as an LDS BYTE ADDRESS that the lane bumps by 8, both dwords through it (immediate offset 4) --
+    // with a slot index each of the two stores formed its own address (v_lshl_add_u32 twice, the index's v_add: 6 vector instructions
+    // per executed candidate branch against 2 here, and that branch runs for ~50 of a 3 702-item row's 58 item positions).  The
+    // wave_lds_sync() in front of the list's first read drains lgkmcnt (its fence), so the compiler need not see these stores.
+    const unsigned sel_base = (unsigned)reinterpret_cast<unsigned long long>(sel32);   // (low half of the flat address = the LDS offset)
+    auto sel_put_at = [&](unsigned addr, unsigned not_id, unsigned k) {
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" : : "v"(addr), "v"(not_id), "v"(k) : "memory");
+    };
 
     const float *grow = scores + (size_t)b * (size_t)ld;
     // the row through a buffer descriptor of exactly its bytes: lanes past the row's end read 0 instead of faulting (those positions
@@ -453,27 +479,33 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
     TOPK_STAMP(2);
     unsigned key[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) key[q] = score_key_sel(v[q], (excl[q >> 5] & (1u << (q & 31))) != 0u);
+    for (int q = 0; q < NQ; ++q) key[q] = score_key_raw(v[q], (unsigned)__builtin_amdgcn_sbfe((int)excl[q >> 5], q & 31, 1));
     TOPK_STAMP(3);
     {
         // ---- target ranks:  #(s > st) + #(s == st and id < target), the target itself and excluded items not counted.
         for (int t = 0; t < n_targets; ++t) {
             const int tg = t == 0 ? tg0 : targets[t];
-            const unsigned kt = score_key_sel(t == 0 ? ts0 : grow[tg], false);   // (the row's own encoder: one key per score in this kernel)
+            // (score_key's clamped key: 0 for a target whose own score is -inf / a negative NaN.  Then every rankable item counts:
+            //  compared against the last unrankable key, since the row's keys are unclamped)
+            const unsigned kt0 = score_key(t == 0 ? ts0 : grow[tg]);
+            const unsigned kt = (unsigned)__builtin_amdgcn_readfirstlane((int)(kt0 != 0u ? kt0 : kKeyValid - 1u));   // (uniform: an SGPR operand below)
             // per-lane counters (compare + add-with-carry), one wave sum of both at the end: counting ballots on the scalar side kept
             // 2 NQ mask registers alive (the sums are re-associated) and spilled
+            // (per-lane counters, one wave sum of both at the end.  Counting on the scalar side instead -- v_cmp, s_bcnt1, s_add per
+            //  item: one vector instruction instead of two -- measured the same on one box, alternating: 36.5-38.4 us in all three
+            //  forms, profiles/r06h_topk_count_ab.txt; the kernel is not bound by these counters)
             int c_gt = 0, c_eq = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                c_gt += key[q] > kt ? 1 : 0;
-                c_eq += key[q] == kt ? 1 : 0;
+                count_lt(c_gt, kt, key[q]);
+                count_eq(c_eq, kt, key[q]);
             }
             const int packed = wave_sum_i(c_gt + (c_eq << 16));   // (both < 2^13 per wave)
             int cnt = packed & 0xffff;
             const int n_eq = packed >> 16;
             // the target itself is one of the keys equal to kt unless it is excluded: only OTHER items with its score need the id test
             const int self = (unsigned)tg < (unsigned)(NQ * 64) && !((bm[(tg >> 11) * 64 + (tg & 63)] >> ((tg >> 6) & 31)) & 1u) ? 1 : 0;
-            if (n_eq > self && kt != 0u) {
+            if (n_eq > self && kt0 != 0u) {
                 int ce = 0;
                 const int lane_here = opaque(lane);   // (loop-invariant otherwise: NQ hoisted `lane | 64 q` registers live across the target loop)
 #pragma unroll
@@ -489,44 +521,50 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
         // ---- lower bound of the K-th largest key from the 256 group maxima
         unsigned m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) m[q & 3] = max(m[q & 3], key[q]);
+        for (int q = 0; q < NQ; q += 8)   // (two keys per v_max3_u32)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (q + 4 + j < NQ) m[j] = max(max(m[j], key[q + j]), key[q + 4 + j]);
+                else if (q + j < NQ) m[j] = max(m[j], key[q + j]);
+            }
         auto count_ge = [&](unsigned x) -> int {
             int c = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) c += __popcll(__ballot(m[j] >= x));
             return c;
         };
-        unsigned cthr = 1u;   // candidates: keys >= cthr (1 = every valid key)
-        if (count_ge(1u) >= K) {
+        unsigned cthr = kKeyValid;   // candidates: keys >= cthr (kKeyValid = every rankable item)
+        if (count_ge(kKeyValid) >= K) {
             unsigned T = 0u;
 #pragma unroll 1
             for (int bit = 31; bit >= 12; --bit) {
                 const unsigned cand = T | (1u << bit);
                 if (count_ge(cand) >= K) T = cand;
             }
-            cthr = max(T, 1u);
+            cthr = max(T, kKeyValid);
         }
         TOPK_STAMP(5);
         // ---- candidates: per-lane counts, wave prefix sum, compaction into the wave's list
         auto compact = [&](unsigned thr0) -> int {   // the list <- composites of the keys >= thr0, if they fit; returns how many
             int cl = 0;
+            const unsigned thr_s = (unsigned)__builtin_amdgcn_readfirstlane((int)thr0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                cl += key[q] >= thr0 ? 1 : 0;
+                count_le(cl, thr_s, key[q]);
                 if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             const int incl = wave_incl_scan_i(cl, lane);
             const int total = __shfl(incl, 63, 64);
             if (total <= kMaxK) {
-                int slot = incl - cl;   // this lane's next list slot
+                unsigned addr = sel_base + 8u * (unsigned)(incl - cl);   // this lane's next list slot
                 // (a private copy of the threshold: sharing the first pass's NQ compare results kept 2 NQ scalar registers alive -- spills)
                 const unsigned thr = (unsigned)__builtin_amdgcn_readfirstlane(opaque((int)thr0));
                 const unsigned not_lane = ~(unsigned)lane;   // ~(lane + 64 q) = ~lane - 64 q
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     if (key[q] >= thr) {
-                        sel_put(slot, not_lane - scalar_here(64 * q), key[q]);
-                        ++slot;
+                        sel_put_at(addr, not_lane - scalar_here(64 * q), key[q]);
+                        addr += 8u;
                     }
             }
             return total;
@@ -549,7 +587,7 @@ __global__ __launch_bounds__(64 * TOPK_WAVE_WG) __attribute__((amdgpu_waves_per_
                 const unsigned cand = T | (1u << bit);
                 if (count_all_ge(cand) >= K) T = cand;
             }
-            // T >= cthr >= 1.  Everything above T in any order (fewer than K), then the ties in ascending item id = (q, lane) order
+            // T >= cthr >= kKeyValid.  Everything above T in any order (fewer than K), then the ties in ascending item id = (q, lane) order
             const int n_gt = T == 0xffffffffu ? 0 : compact(T + 1u);   // keys > T
             const int need = K - n_gt;
             int before = 0;
