@@ -109,7 +109,8 @@ typedef struct rk_spmm_epilogue {
      * the entries (r, c) are skipped (first backward layer of a train step: x = dL/dlight is non-zero on the minibatch's
      * rows only).  The surviving terms keep their CSR order but are dealt to the wave's lane groups anew, so a filtered sum
      * equals the unfiltered one up to summation order (rounding, ~1e-7 relative) and is deterministic for a fixed bitmap;
-     * NULL = gather everything.  rk_rows_mark_bits sets / clears the bits. */
+     * NULL = gather everything.  rk_rows_mark_bits sets / clears the bits.  When `add` is the SAME pointer as x (t = A x + x, the
+     * first backward layer), the addend of a row whose bit is clear is not read: it is zero by this contract. */
     const uint32_t *src_filter;
 } rk_spmm_epilogue;
 int rk_spmm_csr_ex(int32_t n_rows, const int32_t *rowptr, const int32_t *col, const float *val,

@@ -377,7 +377,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
         if (pk.x >= 0) {
             const size_t eoff = (size_t)pk.x * D + (size_t)sub * 4;
-            if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+            // (frontier-filtered launch whose addend IS the filtered operand -- the first backward layer: t1 = A g + g, g zero outside
+            //  the frontier -- reads the addend only for frontier rows: the other rows' 512 bytes are zeros by construction.  Same bits.)
+            const bool add_row = !(FILT && a.e.add == a.x) || ((a.src_filter[(unsigned)pk.x >> 5] >> (pk.x & 31)) & 1u);
+            if (a.e.add && add_row) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
             if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
         }
         for (int t0 = 0; t0 < ds.z; t0 += 8) {  // ds.z = longest row of this wave
@@ -416,7 +419,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         if (fin && lane < G) {
             float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), sumv = addv;
             const size_t eoff = (size_t)ds.x * D + (size_t)lane * 4;
-            if (a.e.add) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
+            const bool add_row = !(FILT && a.e.add == a.x) || ((a.src_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u);   // (see the packed path)
+            if (a.e.add && add_row) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
             if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
             spmm_epilogue<D>(a.e, ds.x, lane, acc, addv, sumv);
         }
