@@ -297,13 +297,18 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
     if (ticket != p.meta.x - 1) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the slot reads below the ticket)
     if (lane == 0) __hip_atomic_store(p.counters + p.meta.w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-    if (lane < g_lanes) {
+    const size_t slot_bytes = (size_t)p.n_slots * (size_t)p.stride * 4u;
+    if (lane < g_lanes && slot_bytes > 0x7fffffffULL) {   // (a slot area beyond a buffer descriptor's 32-bit range: one atomic load per slot half)
+        float4 t = slot_load(p.partials + (size_t)p.meta.z * p.stride, lane);
+        for (int q = 1; q < p.meta.x; ++q) t = f4_add(t, slot_load(p.partials + (size_t)(p.meta.z + q) * p.stride, lane));
+        acc = t;
+    } else if (lane < g_lanes) {
         // The last arriver adds the pieces' slots in piece order.  SIXTEEN (then four) slot reads in flight per round (sc1 buffer loads: the
         // hand-off's load form, MI355X_MICROARCH.md visibility table row 1 -- every handed-off byte was stored write-through and is
         // read with sc1 after the ticket has returned): as a loop of agent-scope atomic loads each slot was its own round trip, and
         // a popular item's row is 50-100 pieces -- the critical path of the row-filtered last forward layer, where nothing else
         // is left to hide it (yelp-shaped f3: 44 us for 9 % of a layer's nonzeros).  Same order of additions, same bits.
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partials, 0, (int)(unsigned)((size_t)p.n_slots * (size_t)p.stride * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partials, 0, (int)(unsigned)slot_bytes, 0x00020000);
         typedef unsigned u4_t __attribute__((ext_vector_type(4)));
         auto ld = [&](int q) -> float4 {
             const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((unsigned)(p.meta.z + q) * (unsigned)p.stride + (unsigned)lane * 4u) * 4u), 0, 16);
@@ -391,15 +396,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         }
     };
     if (a.row_filter && ds.w >= 0 && ds.x >= 0 && !((a.row_filter[(unsigned)ds.x >> 5] >> (ds.x & 31)) & 1u)) ds = make_int4(-1, 0, 0, 0);
-    // Row-filtered launch (the last forward layer: only the minibatch's rows are wanted): a wave whose row is not wanted ENDS here
-    // instead of idling to the workgroup's barrier.  s_barrier counts the waves that have not terminated, and a terminated wave's
-    // slot and registers go back to the CU at once -- so the workgroups of the marked-block list, in which typically one or two of
-    // the four waves hold a wanted row, stop occupying four wave slots each for the 10-15 us their active wave spends on its
-    // dependent gather rounds (yelp-shaped: 3 903 listed workgroups against 1 536 resident ones, i.e. three generations).  A row's
-    // waves (leader + followers, every piece of a long row) share the row id, so they stay or leave together; the marking launch
-    // (blk_mode 2) keeps every wave: its first thread appends behind the barrier.
-    const bool may_leave = a.row_filter != nullptr && a.blk_mode != 2;
-    if (may_leave && ds.w >= 0 && ds.x < 0) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PACKED && ds.w < 0) {
         // packed wave: lane group g owns short row packed[ds.x + g] (<= G nonzeros): no cross-group
@@ -408,7 +404,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
         int4 pk = make_int4(-1, 0, 0, 0);
         if (grp < ds.y) pk = pr.packed[ds.x + grp];
         if (a.row_filter && pk.x >= 0 && !((a.row_filter[(unsigned)pk.x >> 5] >> (pk.x & 31)) & 1u)) pk = make_int4(-1, 0, 0, 0);
-        if (may_leave && __ballot(pk.x >= 0) == 0ULL) return;   // (none of this wave's packed rows is wanted)
         const int n = pk.x >= 0 ? pk.z - pk.y : 0;
         int c = 0;
         float av = 0.f;
