@@ -303,7 +303,7 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
         for (int q = 1; q < p.meta.x; ++q) t = f4_add(t, slot_load(p.partials + (size_t)(p.meta.z + q) * p.stride, lane));
         acc = t;
     } else if (lane < g_lanes) {
-        // The last arriver adds the pieces' slots in piece order.  SIXTEEN (then four) slot reads in flight per round (sc1 buffer loads: the
+        // The last arriver adds the pieces' slots in piece order.  EIGHT slot reads in flight per round (sc1 buffer loads: the
         // hand-off's load form, MI355X_MICROARCH.md visibility table row 1 -- every handed-off byte was stored write-through and is
         // read with sc1 after the ticket has returned): as a loop of agent-scope atomic loads each slot was its own round trip, and
         // a popular item's row is 50-100 pieces -- the critical path of the row-filtered last forward layer, where nothing else
@@ -316,19 +316,12 @@ __device__ __forceinline__ bool piece_arrive(const PieceRef &p, int lane, int g_
         };
         float4 t = ld(0);
         int q = 1;
-        for (; q + 16 <= p.meta.x; q += 16) {   // (the leader's gather registers are free by now: sixteen in flight)
-            float4 u[16];
+        for (; q + 8 <= p.meta.x; q += 8) {   // (sixteen in flight measured the same -- 31.6 against 32.0 us -- and cost 32 more registers)
+            float4 u[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) u[k] = ld(q + k);
+            for (int k = 0; k < 8; ++k) u[k] = ld(q + k);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t = f4_add(t, u[k]);
-        }
-        for (; q + 4 <= p.meta.x; q += 4) {
-            float4 u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = ld(q + k);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t = f4_add(t, u[k]);
+            for (int k = 0; k < 8; ++k) t = f4_add(t, u[k]);
         }
         for (; q < p.meta.x; ++q) t = f4_add(t, ld(q));
         acc = t;
@@ -417,11 +410,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
             if (a.e.add && add_row) addv = *reinterpret_cast<const float4 *>(a.e.add + eoff);
             if (a.e.sum_out) sumv = *reinterpret_cast<const float4 *>(a.e.sum_in + eoff);
         }
-        for (int t0 = 0; t0 < ds.z; t0 += 8) {  // ds.z = longest row of this wave
-            float4 xv[8];
-            float aw[8];
+        constexpr int PU = UNMAX < 8 ? UNMAX : 8;   // (gathers in flight per round: the filtered launch's instantiation keeps four)
+        for (int t0 = 0; t0 < ds.z; t0 += PU) {  // ds.z = longest row of this wave
+            float4 xv[PU];
+            float aw[PU];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < PU; ++j) {
                 const int t = t0 + j;
                 int cc = __shfl(c, (grp * G + t) & 63, 64);
                 float aa = __shfl(av, (grp * G + t) & 63, 64);
@@ -432,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void spmm_csr_kernel(const SpmmAr
                 xv[j] = *reinterpret_cast<const float4 *>(a.x + (unsigned)(cc * D + sub * 4));
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = f4_fma(aw[j], xv[j], acc);
+            for (int j = 0; j < PU; ++j) acc = f4_fma(aw[j], xv[j], acc);
         }
         __syncthreads();  // keep the workgroup's barrier count uniform
         blk_append();
@@ -557,9 +551,17 @@ inline hipError_t spmm_launch(const SpmmArgs &a_in, hipStream_t s)
     static const int no_filt = RK_TUNE_INT("RK_SPMM_NO_FRONTIER", 0);   // A/B only
     if (no_filt || a.drop_thresh24 || !(a.d == 32 || a.d == 64 || a.d == 128 || a.d == 256)) a.src_filter = nullptr;
     const bool filt = a.src_filter != nullptr;
+    static const int no_filt8 = RK_TUNE_INT("RK_SPMM_NO_FILT8", 0);   // A/B only
+    (void)no_filt8;
+    // The frontier-filtered launch keeps one or two of a segment's 64 entries: four gathers in flight are plenty, and without the
+    // other four's registers the kernel fits 64 VGPRs -- eight waves per SIMD instead of six for a launch that is bound by its waves'
+    // dependent round trips (descriptor -> columns -> bitmap -> rows), not by bytes.
 #define RK_SPMM_CASE(D, UN, WV, MW)                                                              \
     do {                                                                                         \
-        if (filt) {                                                                              \
+        if (filt && (WV) <= 8 && !no_filt8) {                                                    \
+            if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, 4, WV, 8, true, false, true>), grid, block, 0, s, a);   \
+            else hipLaunchKernelGGL((spmm_csr_kernel<D, 4, WV, 8, false, false, true>), grid, block, 0, s, a);         \
+        } else if (filt) {                                                                       \
             if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true, false, true>), grid, block, 0, s, a);  \
             else hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, false, false, true>), grid, block, 0, s, a);        \
         } else if (packed) hipLaunchKernelGGL((spmm_csr_kernel<D, UN, WV, MW, true>), grid, block, 0, s, a); \
